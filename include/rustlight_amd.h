@@ -1,0 +1,250 @@
+/*
+ * rustlight_amd.h — C-ABI of the MI355X-native drop-in for rustlight's `path` integrator.
+ *
+ * Everything here is plain C: POD structs, pointers and sizes.  No torch / HIP / C++ types
+ * cross this boundary.  Each entry point cites the rustlight interface it replaces
+ * (paths relative to the reference tree).  INTEGRATION.md shows the Rust `extern "C"` block
+ * and the `impl Integrator for ...` a rustlight maintainer would add on top of this header.
+ *
+ * Conventions
+ *   - all functions return RL_OK (0) or a negative rl_status; they never throw or abort
+ *     (the reference panics instead: src/scene_loader.rs:34, examples/cli.rs:36,348);
+ *   - vectors are tightly packed f32 triples, matrices are column-major 4x4 f32 (cgmath);
+ *   - colours are linear RGB f32 triples (src/structure.rs:105-110);
+ *   - images are row-major, origin top-left, W*H*3 f32 (src/structure.rs:383-402).
+ */
+#ifndef RUSTLIGHT_AMD_H
+#define RUSTLIGHT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rl_status {
+    RL_OK = 0,
+    RL_ERR_INVALID_ARGUMENT = -1,
+    RL_ERR_NO_DEVICE = -2,       /* HIP runtime / GPU missing: the product path never falls back to CPU */
+    RL_ERR_HIP = -3,             /* a HIP call failed; see rl_last_error() */
+    RL_ERR_NOT_BUILT = -4,       /* scene used before rl_scene_build_emitters() */
+    RL_ERR_IO = -5,
+    RL_ERR_PARSE = -6,
+    RL_ERR_UNSUPPORTED = -7,
+    RL_ERR_NO_EMITTER = -8       /* NEE requested on a scene without emitters (reference: warn + crash, src/scene.rs:96-99) */
+} rl_status;
+
+/* ---------------------------------------------------------------- materials ------------- */
+
+/* BSDFColor (src/bsdfs/mod.rs:11-29) */
+typedef enum rl_tex_type {
+    RL_TEX_CONSTANT = 0,
+    RL_TEX_CHECKERBOARD = 1,
+    RL_TEX_GRID = 2,
+    RL_TEX_BITMAP = 3
+} rl_tex_type;
+
+typedef struct rl_color_desc {
+    int32_t type;          /* rl_tex_type */
+    float color0[3];       /* Constant colour / checker+grid colour 0 */
+    float color1[3];
+    float offset[2];
+    float scale[2];
+    float line_width;      /* grid only */
+    int32_t bitmap_id;     /* RL_TEX_BITMAP: id returned by rl_scene_add_bitmap */
+} rl_color_desc;
+
+/* concrete `impl BSDF` types (src/bsdfs/{diffuse,phong,metal,glass,substrate}.rs) */
+typedef enum rl_bsdf_type {
+    RL_BSDF_DIFFUSE = 0,
+    RL_BSDF_PHONG = 1,
+    RL_BSDF_METAL = 2,
+    RL_BSDF_GLASS = 3,
+    RL_BSDF_SUBSTRATE = 4
+} rl_bsdf_type;
+
+/* MicrofacetType (src/bsdfs/distribution.rs:13-17); 0 = `distribution: None` */
+typedef enum rl_microfacet_type {
+    RL_MICROFACET_NONE = 0,
+    RL_MICROFACET_BECKMANN = 1,
+    RL_MICROFACET_GGX = 2
+} rl_microfacet_type;
+
+typedef struct rl_bsdf_desc {
+    int32_t type;                 /* rl_bsdf_type */
+    rl_color_desc diffuse;        /* Diffuse.diffuse, Phong.diffuse, Substrate.diffuse */
+    rl_color_desc specular;       /* Phong.specular, Metal.specular, Substrate.specular, Glass.specular_reflectance */
+    rl_color_desc transmittance;  /* Glass.specular_transmittance */
+    rl_color_desc eta;            /* Metal.eta */
+    rl_color_desc k;              /* Metal.k */
+    float exponent;               /* Phong.exponent */
+    float weight_specular;        /* Phong.weight_specular */
+    int32_t distribution;         /* rl_microfacet_type (Metal / Substrate) */
+    float alpha_u, alpha_v;
+    float glass_eta;              /* BSDFGlass.eta = int_ior / ext_ior (src/bsdfs/glass.rs:44-49) */
+} rl_bsdf_desc;
+
+/* PhaseFunction (src/volume.rs:12-16) */
+typedef enum rl_phase_type { RL_PHASE_ISOTROPIC = 0, RL_PHASE_HG = 1 } rl_phase_type;
+
+/* ---------------------------------------------------------------- scene ----------------- */
+
+/* Opaque host-side scene: the flattened counterpart of `struct Scene` (src/scene.rs:16-30). */
+typedef struct rl_scene rl_scene;
+
+/* Scene { .. } literal (src/scene_loader.rs:302-312): empty scene, nb_samples = 1. */
+int rl_scene_create(rl_scene** out);
+void rl_scene_destroy(rl_scene* scene);
+
+/* Camera::new(img, fov, mat, flip) (src/camera.rs:31-67).
+ * fov_axis: 0 = Fov::X, 1 = Fov::Y (the reference multiplies Fov::Y by the aspect ratio, camera.rs:41-44).
+ * to_world: column-major camera-to-world matrix.  flip: true for the Mitsuba loader, false for PBRT. */
+int rl_scene_set_camera(rl_scene* scene, uint32_t width, uint32_t height, float fov_degrees,
+                        int fov_axis, const float to_world[16], int flip);
+
+/* Camera::scale_image (src/camera.rs:73-78), the CLI's -s flag. */
+int rl_scene_scale_image(rl_scene* scene, float scale);
+
+/* Mesh::new(name, vertices, indices, normals, uv) + `.bsdf = ...` + `.emission = EmissionType::Color`
+ * (src/geometry.rs:122-182, src/scene_loader.rs:134-150).  normals / uv / emission may be NULL.
+ * Returns the mesh index (>= 0) or a negative rl_status.  Meshes keep insertion order
+ * (it fixes the emitter order, src/scene.rs:64-69, and the BVH primitive order, src/accel.rs:206-219). */
+int rl_scene_add_mesh(rl_scene* scene, const float* vertices, size_t n_vertices,
+                      const uint32_t* indices, size_t n_triangles, const float* normals,
+                      const float* uv, const rl_bsdf_desc* bsdf, const float* emission_rgb);
+
+/* Bitmap used by BSDFColor::Bitmap (src/bsdfs/mod.rs:13-15): row-major W*H*3 f32.  Returns its id. */
+int rl_scene_add_bitmap(rl_scene* scene, uint32_t width, uint32_t height, const float* rgb);
+
+/* scene.volume = Some(HomogenousVolume{..}) — the CLI's `-m sigma_s[:sigma_a[:g]]` (examples/cli.rs:355-399).
+ * sigma_t = sigma_a + sigma_s is formed here exactly as cli.rs:383-385 does. */
+int rl_scene_set_medium(rl_scene* scene, const float sigma_a[3], const float sigma_s[3],
+                        int phase_type, float g);
+
+/* Scene::build_emitters(false) (src/scene.rs:53-123): scene bounding sphere, emitter list
+ * (emissive meshes in mesh order), CDF over flux().channel_max().  The ATS light tree
+ * (`-x ats`) is out of scope. */
+int rl_scene_build_emitters(rl_scene* scene);
+
+/* SceneLoaderManager::load(path, use_shading_normals) for the `.pbrt` subset the reference's
+ * PBRT loader consumes (src/scene_loader.rs:77-315): Transform/LookAt/Camera perspective/Film,
+ * MakeNamedMaterial matte|..., NamedMaterial, Shape trianglemesh, AreaLightSource diffuse. */
+int rl_scene_load_pbrt(const char* path, int use_shading_normals, rl_scene** out);
+
+int rl_scene_image_size(const rl_scene* scene, uint32_t* width, uint32_t* height);
+int rl_scene_counts(const rl_scene* scene, uint64_t* n_meshes, uint64_t* n_triangles,
+                    uint64_t* n_emitters);
+
+/* ---------------------------------------------------------------- sampler --------------- */
+
+/* IndependentSampler (src/samplers/independent.rs:5-34) over rand 0.8.5 SmallRng = Xoshiro256++.
+ * The reference trait object hides the raw u64 stream, so the drop-in owns the concrete sampler. */
+typedef struct rl_sampler {
+    uint64_t s[4];
+} rl_sampler;
+
+/* SmallRng::seed_from_u64(seed) as the CLI's `-r independent:SEED` does (examples/cli.rs:886-890).
+ * variant 0 = rand_core 0.6.4 default (PCG32 fill), 1 = SplitMix64 (see oracle header for why both). */
+void rl_sampler_seed(rl_sampler* sampler, uint64_t seed, int variant);
+uint64_t rl_sampler_next_u64(rl_sampler* sampler);
+/* Sampler::next() (samplers/independent.rs:9-11): rng.gen::<f32>() */
+float rl_sampler_next_f32(rl_sampler* sampler);
+
+/* ---------------------------------------------------------------- integrator ------------ */
+
+/* IntegratorPathTracingStrategies (src/integrators/explicit/path.rs:9-13) */
+typedef enum rl_path_strategy { RL_STRATEGY_ALL = 0, RL_STRATEGY_BSDF = 1, RL_STRATEGY_EMITTER = 2 } rl_path_strategy;
+
+/* How the per-block random stream is mapped onto GPU lanes:
+ *  RL_STREAM_REFERENCE_ORDER: one serial stream per 16x16 block, consumed over (iy, ix, sample)
+ *      exactly as compute_mc does (src/integrators/mod.rs:420-435) — equals rustlight proper, slow.
+ *  RL_STREAM_PER_SAMPLE: the block stream is forked with the reference's own clone_box rule
+ *      (samplers/independent.rs:18-22) once per pixel and once per sample — throughput mode. */
+typedef enum rl_stream_mode { RL_STREAM_REFERENCE_ORDER = 0, RL_STREAM_PER_SAMPLE = 1 } rl_stream_mode;
+
+/* struct IntegratorPathTracing (explicit/path.rs:14-20) + scene.nb_samples + sharding. */
+typedef struct rl_path_params {
+    uint32_t spp;              /* scene.nb_samples (CLI global -n) */
+    int32_t has_min_depth;     /* Option<u32>: 0 = None */
+    uint32_t min_depth;
+    int32_t has_max_depth;
+    uint32_t max_depth;
+    int32_t has_rr_depth;
+    uint32_t rr_depth;
+    int32_t strategy;          /* rl_path_strategy */
+    int32_t single_scattering;
+    int32_t stream_mode;       /* rl_stream_mode */
+    int32_t seed_variant;      /* 0 = PCG32 fill, 1 = SplitMix64; used when forking child streams */
+    /* multi-GPU sharding of the 16x16 blocks: this context renders blocks with
+     * b % shard_count == shard_index, b = (ix/16)*ceil(H/16) + iy/16 (creation order, mod.rs:357-358). */
+    uint32_t shard_index;
+    uint32_t shard_count;
+    /* tuning: number of path slots resident on the device (0 = auto). Does not change results. */
+    uint32_t pool_slots;
+    uint32_t reserved[3];
+} rl_path_params;
+
+void rl_path_params_default(rl_path_params* params);   /* CLI defaults: examples/cli.rs:53-61,167-168 */
+
+/* Counters returned by a render (device atomics). */
+typedef struct rl_render_stats {
+    uint64_t camera_samples;      /* W*H*spp of this shard */
+    uint64_t vertices;            /* expanded non-sensor vertices (Sigma V) */
+    uint64_t extension_rays;      /* closest-hit rays traced (primary + bounce) */
+    uint64_t shadow_rays;         /* NEE visibility rays traced (Sigma S) */
+    uint64_t rng_draws;           /* f32 draws consumed */
+    uint64_t iterations;          /* wavefront iterations */
+    uint64_t kernel_launches;
+    double render_ms;             /* wall time of the call (the reference's own timed region, mod.rs:324-334) */
+    /* per-kernel accumulated device time from HIP events on the render stream (ms) */
+    double ms_raygen, ms_extend, ms_shade, ms_shadow, ms_compact, ms_other;
+    uint64_t n_extend_launches;
+    uint64_t reserved[4];
+} rl_render_stats;
+
+/* Opaque device context: BVHAccel::new(scene) (src/accel.rs:202-239) + flattened scene in HBM. */
+typedef struct rl_context rl_context;
+
+/* IntegratorType::compute's untimed prologue (src/integrators/mod.rs:280): builds the BVH2
+ * (full-sweep SAH, leaf <= 2) on the host and uploads scene + BVH to `device` (HIP ordinal).
+ * Fails with RL_ERR_NO_DEVICE when no GPU is present — there is no CPU fallback. */
+int rl_context_create(const rl_scene* scene, int device, rl_context** out);
+void rl_context_destroy(rl_context* ctx);
+const char* rl_last_error(void);
+
+/* generate_img_blocks (src/integrators/mod.rs:351-374): number of <=16x16 blocks, and the
+ * per-block seeds `master.next_u64()` drawn in creation order (x-major). Advances `master`. */
+size_t rl_block_count(uint32_t width, uint32_t height);
+int rl_generate_block_seeds(rl_sampler* master, uint32_t width, uint32_t height,
+                            uint64_t* seeds_out, size_t n_blocks);
+
+/* Integrator::compute for IntegratorPathTracing (explicit/path.rs:186-196 -> compute_mc,
+ * integrators/mod.rs:403-450).  Renders this shard's blocks into `out_rgb` (W*H*3 f32; pixels of
+ * other shards are written as 0 so that a sum over shards is the full image).
+ * out_is_device != 0: `out_rgb` is a device pointer on the context's device (e.g. a torch tensor
+ * that is then reduced with RCCL); otherwise a host pointer (the framebuffer download is timed).
+ * `stream`: a hipStream_t to enqueue on, or NULL for the context's own stream.  Blocking. */
+int rl_render_path(rl_context* ctx, const rl_path_params* params, const uint64_t* block_seeds,
+                   size_t n_blocks, float* out_rgb, int out_is_device, void* stream,
+                   rl_render_stats* stats);
+
+/* Batched `Acceleration::trace` (src/accel.rs:292-315): rays (o, d, tnear=1e-4, tfar=MAX).
+ * Host pointers.  mesh[i] = -1 on a miss. */
+int rl_trace_batch(rl_context* ctx, size_t n, const float* origins, const float* directions,
+                   float* t_out, float* u_out, float* v_out, int32_t* mesh_out, int32_t* tri_out);
+
+/* Batched `Acceleration::visible` (src/accel.rs:316-343). visible_out[i] = 1 if unoccluded. */
+int rl_visible_batch(rl_context* ctx, size_t n, const float* p0, const float* p1,
+                     uint8_t* visible_out);
+
+/* Bitmap::save_pfm (src/structure.rs:547-560): bottom-up rows, |value|, little-endian, "-1.0" scale. */
+int rl_save_pfm(const char* path, const float* rgb, uint32_t width, uint32_t height);
+
+/* Library/build info (for tests: which arch the kernels were compiled for). */
+const char* rl_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUSTLIGHT_AMD_H */

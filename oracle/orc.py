@@ -1,0 +1,252 @@
+"""ctypes binding of the CPU oracle (TEST INFRASTRUCTURE — see oracle/rl_oracle.cpp).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from rustlight_amd import abi
+from rustlight_amd import scenes as S
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "librl_oracle.so")
+
+
+class OrcPathParams(C.Structure):
+    _fields_ = [("spp", C.c_uint32), ("has_min_depth", C.c_int32), ("min_depth", C.c_uint32),
+                ("has_max_depth", C.c_int32), ("max_depth", C.c_uint32), ("has_rr_depth", C.c_int32),
+                ("rr_depth", C.c_uint32), ("strategy", C.c_int32), ("single_scattering", C.c_int32),
+                ("stream_mode", C.c_int32), ("seed_variant", C.c_int32), ("shard_index", C.c_uint32),
+                ("shard_count", C.c_uint32), ("eval_order", C.c_int32)]
+
+
+class OrcStats(C.Structure):
+    _fields_ = [("camera_samples", C.c_uint64), ("vertices", C.c_uint64), ("extension_rays", C.c_uint64),
+                ("shadow_rays", C.c_uint64), ("rng_draws", C.c_uint64), ("threads", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in ("rl_oracle.cpp", "rl_oracle.h", "detmath.h")]
+    srcs.append(os.path.join(_HERE, "..", "include", "rustlight_amd.h"))
+    stale = force or not os.path.exists(_LIB_PATH) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_scene_create.restype = C.c_void_p
+        L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_scene_set_camera.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_int,
+                                           C.POINTER(C.c_float), C.c_int]
+        L.orc_scene_add_bitmap.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+        L.orc_scene_add_mesh.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_uint32),
+                                         C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                         C.POINTER(abi.BsdfDesc), C.POINTER(C.c_float)]
+        L.orc_scene_set_medium.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_float]
+        L.orc_scene_build.argtypes = [C.c_void_p]
+        L.orc_rng_seed.argtypes = [C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
+        L.orc_rng_next_u64.argtypes = [C.POINTER(C.c_uint64)]
+        L.orc_rng_next_u64.restype = C.c_uint64
+        L.orc_rng_next_f32.argtypes = [C.POINTER(C.c_uint64)]
+        L.orc_rng_next_f32.restype = C.c_float
+        L.orc_block_count.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_block_count.restype = C.c_size_t
+        L.orc_generate_block_seeds.argtypes = [C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+        L.orc_math_batch.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_camera_generate.argtypes = [C.c_void_p, C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+        L.orc_bvh_dump.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.orc_trace_batch.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
+                                      C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.orc_visible_batch.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint8)]
+        L.orc_trace_full.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_bsdf_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_sample_light.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]
+        L.orc_compute_pixel.argtypes = [C.c_void_p, C.POINTER(OrcPathParams), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64),
+                                        C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.orc_compute_pixel.restype = C.c_uint64
+        L.orc_render_path.argtypes = [C.c_void_p, C.POINTER(OrcPathParams), C.POINTER(C.c_uint64), C.c_size_t,
+                                      C.POINTER(C.c_float), C.c_int, C.POINTER(OrcStats)]
+        _lib = L
+    return _lib
+
+
+def path_params(spp=1, min_depth=0, max_depth=None, rr_depth=0, strategy=0, single_scattering=False,
+                stream_mode=1, seed_variant=0, shard_index=0, shard_count=1, eval_order=0) -> OrcPathParams:
+    p = OrcPathParams()
+    p.spp = spp
+    p.has_min_depth, p.min_depth = (0, 0) if min_depth is None else (1, min_depth)
+    p.has_max_depth, p.max_depth = (0, 0) if max_depth is None else (1, max_depth)
+    p.has_rr_depth, p.rr_depth = (0, 0) if rr_depth is None else (1, rr_depth)
+    p.strategy = strategy
+    p.single_scattering = int(single_scattering)
+    p.stream_mode = stream_mode
+    p.seed_variant = seed_variant
+    p.shard_index, p.shard_count = shard_index, shard_count
+    p.eval_order = eval_order
+    return p
+
+
+class Rng:
+    def __init__(self, seed: int, variant: int = 0):
+        self.state = (C.c_uint64 * 4)()
+        lib().orc_rng_seed(seed, variant, self.state)
+
+    @classmethod
+    def from_state(cls, s):
+        r = cls.__new__(cls)
+        r.state = (C.c_uint64 * 4)(*s)
+        return r
+
+    def next_u64(self) -> int:
+        return int(lib().orc_rng_next_u64(self.state))
+
+    def next_f32(self) -> float:
+        return float(lib().orc_rng_next_f32(self.state))
+
+
+def block_seeds(master_seed: int, width: int, height: int, variant: int = 0) -> np.ndarray:
+    """`-r independent:SEED` then generate_img_blocks: one next_u64 per block, x-major."""
+    r = Rng(master_seed, variant)
+    n = lib().orc_block_count(width, height)
+    seeds = np.zeros(n, dtype=np.uint64)
+    lib().orc_generate_block_seeds(r.state, width, height, abi.u64ptr(seeds))
+    return seeds
+
+
+class Scene:
+    def __init__(self, sd: S.SceneData):
+        L = lib()
+        self.sd = sd
+        self.h = C.c_void_p(L.orc_scene_create())
+        tw = np.ascontiguousarray(sd.to_world, dtype=np.float32)
+        rc = L.orc_scene_set_camera(self.h, sd.width, sd.height, sd.fov, sd.fov_axis, abi.fptr(tw), int(sd.flip))
+        assert rc == 0
+        for (w, h, rgb) in sd.bitmaps:
+            a = np.ascontiguousarray(rgb, dtype=np.float32)
+            L.orc_scene_add_bitmap(self.h, w, h, abi.fptr(a))
+        for m in sd.meshes:
+            v, i, n, uv, e = abi.mesh_arrays(m)
+            bd = abi.bsdf_desc(m.bsdf)
+            rc = L.orc_scene_add_mesh(self.h, abi.fptr(v), v.shape[0], abi.u32ptr(i), i.shape[0], abi.fptr(n),
+                                      abi.fptr(uv), C.byref(bd), abi.fptr(e))
+            assert rc >= 0
+        if sd.medium is not None:
+            sa = np.asarray(sd.medium.sigma_a, dtype=np.float32)
+            ss = np.asarray(sd.medium.sigma_s, dtype=np.float32)
+            L.orc_scene_set_medium(self.h, abi.fptr(sa), abi.fptr(ss), sd.medium.phase, sd.medium.g)
+        L.orc_scene_build(self.h)
+
+    def __del__(self):
+        try:
+            lib().orc_scene_destroy(self.h)
+        except Exception:
+            pass
+
+    def info(self):
+        nn, npr, ne = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        bs = (C.c_float * 4)()
+        lib().orc_scene_info(self.h, C.byref(nn), C.byref(npr), C.byref(ne), bs)
+        return {"nodes": nn.value, "prims": npr.value, "emitters": ne.value, "bsphere": list(bs)}
+
+    def bvh(self):
+        inf = self.info()
+        boxes = np.zeros((inf["nodes"], 6), dtype=np.float32)
+        info = np.zeros(inf["nodes"], dtype=np.uint64)
+        count = np.zeros(inf["nodes"], dtype=np.uint64)
+        pm = np.zeros(inf["prims"], dtype=np.int32)
+        pt = np.zeros(inf["prims"], dtype=np.int32)
+        lib().orc_bvh_dump(self.h, abi.fptr(boxes), abi.u64ptr(info), abi.u64ptr(count),
+                           pm.ctypes.data_as(C.POINTER(C.c_int32)), pt.ctypes.data_as(C.POINTER(C.c_int32)))
+        return boxes, info, count, pm, pt
+
+    def camera_generate(self, px, py):
+        o = (C.c_float * 3)()
+        d = (C.c_float * 3)()
+        lib().orc_camera_generate(self.h, px, py, o, d)
+        return np.array(o[:], dtype=np.float32), np.array(d[:], dtype=np.float32)
+
+    def trace(self, origins, directions, brute=False):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        t = np.zeros(n, np.float32); u = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+        m = np.zeros(n, np.int32); tr = np.zeros(n, np.int32)
+        lib().orc_trace_batch(self.h, n, abi.fptr(o), abi.fptr(d), int(brute), abi.fptr(t), abi.fptr(u), abi.fptr(v),
+                              m.ctypes.data_as(C.POINTER(C.c_int32)), tr.ctypes.data_as(C.POINTER(C.c_int32)))
+        return t, u, v, m, tr
+
+    def visible(self, p0, p1):
+        a = np.ascontiguousarray(p0, dtype=np.float32).reshape(-1, 3)
+        b = np.ascontiguousarray(p1, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros(a.shape[0], np.uint8)
+        lib().orc_visible_batch(self.h, a.shape[0], abi.fptr(a), abi.fptr(b), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return out
+
+    def trace_full(self, o, d):
+        oo = np.asarray(o, dtype=np.float32); dd = np.asarray(d, dtype=np.float32)
+        out = np.zeros(17, np.float32)
+        hit = lib().orc_trace_full(self.h, abi.fptr(oo), abi.fptr(dd), abi.fptr(out))
+        if not hit:
+            return None
+        return {"t": out[0], "p": out[1:4], "n_g": out[4:7], "n_s": out[7:10], "uv": out[10:12], "wi": out[12:15],
+                "mesh": int(out[15]), "tri": int(out[16])}
+
+    def bsdf_sample(self, mesh, wi, s):
+        w = np.asarray(wi, np.float32); ss = np.asarray(s, np.float32); out = np.zeros(9, np.float32)
+        lib().orc_bsdf_probe(self.h, mesh, 0, abi.fptr(w), abi.fptr(ss), abi.fptr(out))
+        if out[0] == 0:
+            return None
+        return {"weight": out[1:4], "d": out[4:7], "pdf": out[7], "pdf_kind": int(out[8])}
+
+    def bsdf_eval(self, mesh, wi, wo):
+        w = np.asarray(wi, np.float32); o = np.asarray(wo, np.float32); out = np.zeros(3, np.float32)
+        lib().orc_bsdf_probe(self.h, mesh, 1, abi.fptr(w), abi.fptr(o), abi.fptr(out))
+        return out
+
+    def bsdf_pdf(self, mesh, wi, wo):
+        w = np.asarray(wi, np.float32); o = np.asarray(wo, np.float32); out = np.zeros(2, np.float32)
+        lib().orc_bsdf_probe(self.h, mesh, 2, abi.fptr(w), abi.fptr(o), abi.fptr(out))
+        return float(out[0])
+
+    def sample_light(self, p, r_sel, r, ux, uy):
+        pp = np.asarray(p, np.float32); out = np.zeros(14, np.float32)
+        lib().orc_sample_light(self.h, abi.fptr(pp), r_sel, r, ux, uy, abi.fptr(out))
+        return {"pdf": out[0], "p": out[1:4], "n": out[4:7], "d": out[7:10], "weight": out[10:13], "emitter": int(out[13])}
+
+    def compute_pixel(self, ix, iy, rng: Rng, **kw):
+        p = path_params(**kw)
+        rgb = (C.c_float * 3)(); nv = C.c_uint64(); ns = C.c_uint64()
+        draws = lib().orc_compute_pixel(self.h, C.byref(p), ix, iy, rng.state, rgb, C.byref(nv), C.byref(ns))
+        return np.array(rgb[:], np.float32), int(draws), nv.value, ns.value
+
+    def render(self, master_seed=0, threads=0, seeds=None, **kw):
+        p = path_params(**kw)
+        sd = self.sd
+        if seeds is None:
+            seeds = block_seeds(master_seed, sd.width, sd.height, p.seed_variant)
+        img = np.zeros((sd.height, sd.width, 3), dtype=np.float32)
+        st = OrcStats()
+        rc = lib().orc_render_path(self.h, C.byref(p), abi.u64ptr(seeds), seeds.shape[0], abi.fptr(img), threads, C.byref(st))
+        if rc != 0:
+            raise RuntimeError(f"orc_render_path failed: {rc}")
+        return img, st.as_dict()

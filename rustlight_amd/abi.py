@@ -1,0 +1,95 @@
+"""ctypes mirror of include/rustlight_amd.h (POD structs only — no logic)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import scenes as S
+
+
+class ColorDesc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("color0", C.c_float * 3), ("color1", C.c_float * 3),
+                ("offset", C.c_float * 2), ("scale", C.c_float * 2), ("line_width", C.c_float),
+                ("bitmap_id", C.c_int32)]
+
+
+class BsdfDesc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("diffuse", ColorDesc), ("specular", ColorDesc),
+                ("transmittance", ColorDesc), ("eta", ColorDesc), ("k", ColorDesc),
+                ("exponent", C.c_float), ("weight_specular", C.c_float), ("distribution", C.c_int32),
+                ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("glass_eta", C.c_float)]
+
+
+class Sampler(C.Structure):
+    _fields_ = [("s", C.c_uint64 * 4)]
+
+
+class PathParams(C.Structure):
+    _fields_ = [("spp", C.c_uint32), ("has_min_depth", C.c_int32), ("min_depth", C.c_uint32),
+                ("has_max_depth", C.c_int32), ("max_depth", C.c_uint32), ("has_rr_depth", C.c_int32),
+                ("rr_depth", C.c_uint32), ("strategy", C.c_int32), ("single_scattering", C.c_int32),
+                ("stream_mode", C.c_int32), ("seed_variant", C.c_int32), ("shard_index", C.c_uint32),
+                ("shard_count", C.c_uint32), ("pool_slots", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [("camera_samples", C.c_uint64), ("vertices", C.c_uint64), ("extension_rays", C.c_uint64),
+                ("shadow_rays", C.c_uint64), ("rng_draws", C.c_uint64), ("iterations", C.c_uint64),
+                ("kernel_launches", C.c_uint64), ("render_ms", C.c_double), ("ms_raygen", C.c_double),
+                ("ms_extend", C.c_double), ("ms_shade", C.c_double), ("ms_shadow", C.c_double),
+                ("ms_compact", C.c_double), ("ms_other", C.c_double), ("n_extend_launches", C.c_uint64),
+                ("reserved", C.c_uint64 * 4)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+def color_desc(d: dict) -> ColorDesc:
+    c = ColorDesc()
+    c.type = int(d.get("type", S.TEX_CONSTANT))
+    c.color0 = (C.c_float * 3)(*d.get("color0", (1.0, 1.0, 1.0)))
+    c.color1 = (C.c_float * 3)(*d.get("color1", (0.0, 0.0, 0.0)))
+    c.offset = (C.c_float * 2)(*d.get("offset", (0.0, 0.0)))
+    c.scale = (C.c_float * 2)(*d.get("scale", (1.0, 1.0)))
+    c.line_width = float(d.get("line_width", 0.0))
+    c.bitmap_id = int(d.get("bitmap_id", -1))
+    return c
+
+
+def bsdf_desc(b: S.Bsdf) -> BsdfDesc:
+    d = BsdfDesc()
+    d.type = b.type
+    d.diffuse = color_desc(b.diffuse)
+    d.specular = color_desc(b.specular)
+    d.transmittance = color_desc(b.transmittance)
+    d.eta = color_desc(b.eta)
+    d.k = color_desc(b.k)
+    d.exponent = b.exponent
+    d.weight_specular = b.weight_specular
+    d.distribution = b.distribution
+    d.alpha_u = b.alpha_u
+    d.alpha_v = b.alpha_v
+    d.glass_eta = b.glass_eta
+    return d
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+def u32ptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def u64ptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def mesh_arrays(m: S.MeshData):
+    v = np.ascontiguousarray(m.vertices, dtype=np.float32)
+    i = np.ascontiguousarray(m.indices, dtype=np.uint32)
+    n = None if m.normals is None else np.ascontiguousarray(m.normals, dtype=np.float32)
+    uv = None if m.uv is None else np.ascontiguousarray(m.uv, dtype=np.float32)
+    e = None if m.emission is None else np.asarray(m.emission, dtype=np.float32)
+    return v, i, n, uv, e
