@@ -1,0 +1,135 @@
+#!/usr/bin/env python
+"""bench.py — Msamples/s of the `path` hot path on BASELINE.json configs[1]:
+cbox, 1920x1080, 128 spp, diffuse-only, per-sample stream mode, N x MI355X (pixel-tile shards +
+one RCCL framebuffer reduce).  One "step" = one full render (W*H*spp camera samples).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_extend): algorithmic bytes
+per launch / mean launch duration from HIP events on the render stream.  `cpu_baseline` times the
+CPU oracle (a C++ restatement of rustlight's path integrator — NOT rustlight itself) on a bounded
+sample of the same workload on the host cores."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=128)
+    ap.add_argument("--scene", default="cbox", choices=["cbox", "cbox_medium", "living_room"])
+    ap.add_argument("--pool", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from rustlight_amd import api, scenes
+    from rustlight_amd import distributed as rd
+
+    rank, world, local_rank = rd.init_from_env(args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback path exists)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    if args.scene == "cbox":
+        sd = scenes.cbox(args.width, args.height)
+        workload = f"cbox {args.width}x{args.height}x{args.spp}spp-per-GPU diffuse path (BASELINE configs[1]; configs[3] at 8 GPUs)"
+    elif args.scene == "cbox_medium":
+        sd = scenes.cbox_medium(args.width, args.height, 0.5)
+        workload = f"cbox + homogeneous medium sigma_s=0.5 {args.width}x{args.height}x{args.spp}spp (BASELINE configs[4])"
+    else:
+        sd = scenes.living_room(args.width, args.height)
+        workload = f"living-room-class {sd.n_triangles} tris {args.width}x{args.height}x{args.spp}spp (BASELINE configs[2])"
+    scene = api.Scene(sd)
+    ctx = api.Context(scene, local_rank)          # BVH build + upload: untimed, like the reference (mod.rs:280)
+    fb = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # weak scaling: the image is fixed and spp grows with the GPU count (128 spp at N=1 ... 1024 spp at N=8 =
+    # BASELINE configs[3]), so every GPU always traces W*H*128 camera samples per step.
+    spp_total = args.spp * world
+
+    def step(seed):
+        seeds = api.IndependentSampler(seed).block_seeds(args.width, args.height)     # same master stream on every rank
+        p = api.path_params(spp=spp_total, shard_index=rank, shard_count=world, pool_slots=args.pool)
+        _, st = ctx.render(seeds, p, out_device_ptr=fb.data_ptr(), stream=stream)
+        if world > 1:
+            rd.reduce_framebuffer(fb)                                                   # one RCCL reduce over xGMI
+        return st
+
+    for w in range(args.warmup):
+        step(1000 + w)
+    rd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats = []
+    for s in range(args.steps):
+        stats.append(step(s))
+    rd.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dt = rd.max_over_ranks(dt)
+    host_img = fb.cpu().numpy() if rank == 0 else None
+
+    samples_per_step = args.width * args.height * spp_total
+    value = samples_per_step * args.steps / dt / 1e6
+    agg = {k: sum(s[k] for s in stats) for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "iterations", "n_extend_launches")}
+    ms = {k: sum(s[k] for s in stats) for k in ("ms_raygen", "ms_extend", "ms_shade", "ms_shadow")}
+    agg_all = rd.sum_over_ranks(agg)
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel.  Algorithmic bytes:
+        # k_extend reads a ray {o 12, d 12, flags 4} and writes a hit {t, u, v, prim = 16} per live slot.
+        dominant = max(ms, key=ms.get)
+        per_unit = {"ms_extend": 28 + 16, "ms_shade": 2 * (80 + 28) + 16 + 4 + 44, "ms_shadow": 44 + 4 + 2 * 12, "ms_raygen": 80 + 28}[dominant]
+        units = {"ms_extend": agg["extension_rays"], "ms_shade": agg["extension_rays"], "ms_shadow": agg["shadow_rays"], "ms_raygen": agg["camera_samples"]}[dominant]
+        launches = max(1, agg["n_extend_launches"])
+        avg_ms = ms[dominant] / launches
+        achieved = (per_unit * units / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # whole-pipeline figure: 248 B per camera sample + 352 B per vertex + 12 B per pixel
+        pipe_bytes = 248 * agg["camera_samples"] + 352 * agg["vertices"] + 12 * args.width * args.height * args.steps / world
+        pipe_gbs = pipe_bytes / (dt) / 1e9
+        roofline = {"bound": "hbm", "kernel": {"ms_extend": "k_extend", "ms_shade": "k_shade", "ms_shadow": "k_shadow", "ms_raygen": "k_raygen"}[dominant],
+                    "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                    "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_unit": per_unit,
+                    "pipeline_algorithmic_GBps": pipe_gbs, "pipeline_frac": pipe_gbs / 8000.0,
+                    "kernel_ms_per_step": {k: v / args.steps for k, v in ms.items()},
+                    "rays_per_s": (agg_all["extension_rays"] + agg_all["shadow_rays"]) / dt}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import orc
+            cw, ch, cspp = 480, 270, 16                           # bounded sample of the same workload (same scene, 1/16 res, 1/8 spp)
+            osc = orc.Scene(scenes.cbox(cw, ch) if args.scene == "cbox" else (scenes.cbox_medium(cw, ch, 0.5) if args.scene == "cbox_medium" else scenes.living_room(cw, ch)))
+            t1 = time.perf_counter()
+            _, ost = osc.render(master_seed=0, spp=cspp, stream_mode=0, threads=0)
+            ct = time.perf_counter() - t1
+            cpu = {"value": cw * ch * cspp / ct / 1e6, "unit": "Msamples/s", "cores": ost["threads"], "kind": "port",
+                   "sample": f"{args.scene} {cw}x{ch}x{cspp}spp, reference-order streams, CPU restatement of rustlight `path` (C++), {ost['threads']} threads"}
+        out = {"metric": "Msamples/s (paths/s) at 1080p x 128spp cbox", "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": workload, "spp_total": spp_total, "stream_mode": "per_sample", "parallelism": f"tile-shard x{world} + 1 RCCL reduce",
+                          "mean_vertices_per_sample": agg_all["vertices"] / max(1, agg_all["camera_samples"]),
+                          "image_mean": float(host_img.mean())},
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    rd.finalize()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,7 +80,7 @@ typedef struct rl_bsdf_desc {
     rl_color_desc k;              /* Metal.k */
     float exponent;               /* Phong.exponent */
     float weight_specular;        /* Phong.weight_specular */
-    int32_t distribution;         /* rl_microfacet_type (Metal / Substrate) */
+    int32_t distribution;         /* one of rl_microfacet_type; Metal and Substrate only */
     float alpha_u, alpha_v;
     float glass_eta;              /* BSDFGlass.eta = int_ior / ext_ior (src/bsdfs/glass.rs:44-49) */
 } rl_bsdf_desc;

@@ -1,0 +1,314 @@
+"""ctypes binding of the product C-ABI (include/rustlight_amd.h) + the Python mirror of rustlight's
+`Integrator` surface for the `path` hot path.
+
+The library must already be built in-tree (``python -m rustlight_amd.build`` or
+``__graft_entry__.build()``); there is no CPU fallback — on a machine without a GPU
+``Context`` raises ``NoDeviceError`` (RL_ERR_NO_DEVICE).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import abi
+from . import scenes as S
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librustlight_amd.so")
+
+RL_OK = 0
+RL_ERR_NO_DEVICE = -2
+STRATEGY_ALL, STRATEGY_BSDF, STRATEGY_EMITTER = 0, 1, 2
+STREAM_REFERENCE_ORDER, STREAM_PER_SAMPLE = 0, 1
+
+# every symbol include/rustlight_amd.h declares (tests check the .so exports all of them)
+PUBLIC_SYMBOLS = [
+    "rl_scene_create", "rl_scene_destroy", "rl_scene_set_camera", "rl_scene_scale_image", "rl_scene_add_mesh",
+    "rl_scene_add_bitmap", "rl_scene_set_medium", "rl_scene_build_emitters", "rl_scene_load_pbrt",
+    "rl_scene_image_size", "rl_scene_counts", "rl_sampler_seed", "rl_sampler_next_u64", "rl_sampler_next_f32",
+    "rl_path_params_default", "rl_context_create", "rl_context_destroy", "rl_last_error", "rl_block_count",
+    "rl_generate_block_seeds", "rl_render_path", "rl_trace_batch", "rl_visible_batch", "rl_save_pfm", "rl_build_info",
+]
+
+
+class RustlightError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__(f"rustlight_amd error {code}: {msg}")
+        self.code = code
+
+
+class NoDeviceError(RustlightError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m rustlight_amd.build` "
+                           "(the HIP extension is mandatory, there is no fallback path)")
+    L = C.CDLL(LIB_PATH)
+    vp, f32p, u32p, u64p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    L.rl_scene_create.argtypes = [C.POINTER(vp)]
+    L.rl_scene_destroy.argtypes = [vp]
+    L.rl_scene_destroy.restype = None
+    L.rl_scene_set_camera.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_float, C.c_int, f32p, C.c_int]
+    L.rl_scene_scale_image.argtypes = [vp, C.c_float]
+    L.rl_scene_add_mesh.argtypes = [vp, f32p, C.c_size_t, u32p, C.c_size_t, f32p, f32p, C.POINTER(abi.BsdfDesc), f32p]
+    L.rl_scene_add_bitmap.argtypes = [vp, C.c_uint32, C.c_uint32, f32p]
+    L.rl_scene_set_medium.argtypes = [vp, f32p, f32p, C.c_int, C.c_float]
+    L.rl_scene_build_emitters.argtypes = [vp]
+    L.rl_scene_load_pbrt.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.rl_scene_image_size.argtypes = [vp, u32p, u32p]
+    L.rl_scene_counts.argtypes = [vp, u64p, u64p, u64p]
+    L.rl_sampler_seed.argtypes = [C.POINTER(abi.Sampler), C.c_uint64, C.c_int]
+    L.rl_sampler_seed.restype = None
+    L.rl_sampler_next_u64.argtypes = [C.POINTER(abi.Sampler)]
+    L.rl_sampler_next_u64.restype = C.c_uint64
+    L.rl_sampler_next_f32.argtypes = [C.POINTER(abi.Sampler)]
+    L.rl_sampler_next_f32.restype = C.c_float
+    L.rl_path_params_default.argtypes = [C.POINTER(abi.PathParams)]
+    L.rl_path_params_default.restype = None
+    L.rl_context_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.rl_context_destroy.argtypes = [vp]
+    L.rl_context_destroy.restype = None
+    L.rl_last_error.restype = C.c_char_p
+    L.rl_block_count.argtypes = [C.c_uint32, C.c_uint32]
+    L.rl_block_count.restype = C.c_size_t
+    L.rl_generate_block_seeds.argtypes = [C.POINTER(abi.Sampler), C.c_uint32, C.c_uint32, u64p, C.c_size_t]
+    L.rl_render_path.argtypes = [vp, C.POINTER(abi.PathParams), u64p, C.c_size_t, vp, C.c_int, vp, C.POINTER(abi.RenderStats)]
+    L.rl_trace_batch.argtypes = [vp, C.c_size_t, f32p, f32p, f32p, f32p, f32p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.rl_visible_batch.argtypes = [vp, C.c_size_t, f32p, f32p, C.POINTER(C.c_uint8)]
+    L.rl_save_pfm.argtypes = [C.c_char_p, f32p, C.c_uint32, C.c_uint32]
+    L.rl_build_info.restype = C.c_char_p
+    # test hooks
+    L.rl_debug_numerics.argtypes = [C.c_int, C.c_size_t, f32p, f32p, f32p]
+    L.rl_debug_bvh.argtypes = [vp, u64p, u64p, f32p, u64p, u64p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.rl_debug_bvh_sizes.argtypes = [vp, u64p, u64p, u32p, C.POINTER(C.c_int)]
+    L.rl_debug_camera_ray.argtypes = [vp, C.c_float, C.c_float, f32p, f32p]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc < 0:
+        msg = (lib().rl_last_error() or b"").decode()
+        raise (NoDeviceError if rc == RL_ERR_NO_DEVICE else RustlightError)(rc, msg)
+    return rc
+
+
+class IndependentSampler:
+    """IndependentSampler { rnd: SmallRng::seed_from_u64(seed) } (examples/cli.rs:886-890)."""
+
+    def __init__(self, seed: int, variant: int = 0):
+        self.s = abi.Sampler()
+        self.variant = variant
+        lib().rl_sampler_seed(C.byref(self.s), seed, variant)
+
+    def next(self) -> float:
+        return float(lib().rl_sampler_next_f32(C.byref(self.s)))
+
+    def next_u64(self) -> int:
+        return int(lib().rl_sampler_next_u64(C.byref(self.s)))
+
+    def block_seeds(self, width: int, height: int) -> np.ndarray:
+        """generate_img_blocks: one clone_box seed per 16x16 block, x-major (integrators/mod.rs:357-371)."""
+        n = lib().rl_block_count(width, height)
+        seeds = np.zeros(n, dtype=np.uint64)
+        _check(lib().rl_generate_block_seeds(C.byref(self.s), width, height, abi.u64ptr(seeds), n))
+        return seeds
+
+
+class Scene:
+    """Host-side flattened `Scene` (src/scene.rs:16-30)."""
+
+    def __init__(self, sd: Optional[S.SceneData] = None, handle=None):
+        L = lib()
+        self.sd = sd
+        if handle is not None:
+            self.h = handle
+        else:
+            h = C.c_void_p()
+            _check(L.rl_scene_create(C.byref(h)))
+            self.h = h
+            tw = np.ascontiguousarray(sd.to_world, dtype=np.float32)
+            _check(L.rl_scene_set_camera(self.h, sd.width, sd.height, sd.fov, sd.fov_axis, abi.fptr(tw), int(sd.flip)))
+            for (w, hgt, rgb) in sd.bitmaps:
+                a = np.ascontiguousarray(rgb, dtype=np.float32)
+                _check(L.rl_scene_add_bitmap(self.h, w, hgt, abi.fptr(a)))
+            for m in sd.meshes:
+                v, i, n, uv, e = abi.mesh_arrays(m)
+                bd = abi.bsdf_desc(m.bsdf)
+                _check(L.rl_scene_add_mesh(self.h, abi.fptr(v), v.shape[0], abi.u32ptr(i), i.shape[0], abi.fptr(n),
+                                           abi.fptr(uv), C.byref(bd), abi.fptr(e)))
+            if sd.medium is not None:
+                sa = np.asarray(sd.medium.sigma_a, dtype=np.float32)
+                ss = np.asarray(sd.medium.sigma_s, dtype=np.float32)
+                _check(L.rl_scene_set_medium(self.h, abi.fptr(sa), abi.fptr(ss), sd.medium.phase, sd.medium.g))
+        _check(L.rl_scene_build_emitters(self.h))
+
+    @classmethod
+    def load_pbrt(cls, path: str, use_shading_normals: bool = True) -> "Scene":
+        h = C.c_void_p()
+        _check(lib().rl_scene_load_pbrt(path.encode(), int(use_shading_normals), C.byref(h)))
+        return cls(None, handle=h)
+
+    def set_medium(self, sigma_a, sigma_s, phase=S.PHASE_ISOTROPIC, g=0.0):
+        sa = np.asarray(sigma_a, dtype=np.float32)
+        ss = np.asarray(sigma_s, dtype=np.float32)
+        _check(lib().rl_scene_set_medium(self.h, abi.fptr(sa), abi.fptr(ss), phase, g))
+
+    def __del__(self):
+        try:
+            lib().rl_scene_destroy(self.h)
+        except Exception:
+            pass
+
+    @property
+    def size(self):
+        w, h = C.c_uint32(), C.c_uint32()
+        _check(lib().rl_scene_image_size(self.h, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def counts(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib().rl_scene_counts(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"meshes": a.value, "triangles": b.value, "emitters": c.value}
+
+    def debug_bvh(self):
+        nn, npr = C.c_uint64(), C.c_uint64()
+        _check(lib().rl_debug_bvh(self.h, C.byref(nn), C.byref(npr), None, None, None, None, None))
+        boxes = np.zeros((nn.value, 6), np.float32)
+        info = np.zeros(nn.value, np.uint64)
+        count = np.zeros(nn.value, np.uint64)
+        pm = np.zeros(npr.value, np.int32)
+        pt = np.zeros(npr.value, np.int32)
+        _check(lib().rl_debug_bvh(self.h, C.byref(nn), C.byref(npr), abi.fptr(boxes), abi.u64ptr(info), abi.u64ptr(count),
+                                  pm.ctypes.data_as(C.POINTER(C.c_int32)), pt.ctypes.data_as(C.POINTER(C.c_int32))))
+        return boxes, info, count, pm, pt
+
+    def camera_ray(self, px, py):
+        o = (C.c_float * 3)()
+        d = (C.c_float * 3)()
+        _check(lib().rl_debug_camera_ray(self.h, px, py, o, d))
+        return np.array(o[:], np.float32), np.array(d[:], np.float32)
+
+
+def path_params(spp=1, min_depth=0, max_depth=None, rr_depth=0, strategy=STRATEGY_ALL, single_scattering=False,
+                stream_mode=STREAM_PER_SAMPLE, seed_variant=0, shard_index=0, shard_count=1, pool_slots=0) -> abi.PathParams:
+    p = abi.PathParams()
+    lib().rl_path_params_default(C.byref(p))
+    p.spp = spp
+    p.has_min_depth, p.min_depth = (0, 0) if min_depth is None else (1, min_depth)
+    p.has_max_depth, p.max_depth = (0, 0) if max_depth is None else (1, max_depth)
+    p.has_rr_depth, p.rr_depth = (0, 0) if rr_depth is None else (1, rr_depth)
+    p.strategy = strategy
+    p.single_scattering = int(single_scattering)
+    p.stream_mode = stream_mode
+    p.seed_variant = seed_variant
+    p.shard_index, p.shard_count = shard_index, shard_count
+    p.pool_slots = pool_slots
+    return p
+
+
+class Context:
+    """Device context = BVHAccel::new(scene) + the scene uploaded to one MI355X."""
+
+    def __init__(self, scene: Scene, device: int = 0):
+        self.scene = scene
+        self.device = device
+        h = C.c_void_p()
+        _check(lib().rl_context_create(scene.h, device, C.byref(h)))
+        self.h = h
+        self.width, self.height = scene.size
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rl_context_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, seeds: np.ndarray, params: abi.PathParams, out_device_ptr: Optional[int] = None, stream: Optional[int] = None):
+        """Integrator::compute.  Returns (image HxWx3 f32 | None when rendering into a device pointer, stats dict)."""
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        st = abi.RenderStats()
+        if out_device_ptr is None:
+            img = np.zeros((self.height, self.width, 3), dtype=np.float32)
+            _check(lib().rl_render_path(self.h, C.byref(params), abi.u64ptr(seeds), seeds.shape[0], img.ctypes.data_as(C.c_void_p), 0,
+                                        C.c_void_p(stream) if stream else None, C.byref(st)))
+            return img, st.as_dict()
+        _check(lib().rl_render_path(self.h, C.byref(params), abi.u64ptr(seeds), seeds.shape[0], C.c_void_p(out_device_ptr), 1,
+                                    C.c_void_p(stream) if stream else None, C.byref(st)))
+        return None, st.as_dict()
+
+    def trace(self, origins, directions):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        t = np.zeros(n, np.float32); u = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+        m = np.zeros(n, np.int32); tr = np.zeros(n, np.int32)
+        _check(lib().rl_trace_batch(self.h, n, abi.fptr(o), abi.fptr(d), abi.fptr(t), abi.fptr(u), abi.fptr(v),
+                                    m.ctypes.data_as(C.POINTER(C.c_int32)), tr.ctypes.data_as(C.POINTER(C.c_int32))))
+        return t, u, v, m, tr
+
+    def visible(self, p0, p1):
+        a = np.ascontiguousarray(p0, dtype=np.float32).reshape(-1, 3)
+        b = np.ascontiguousarray(p1, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros(a.shape[0], np.uint8)
+        _check(lib().rl_visible_batch(self.h, a.shape[0], abi.fptr(a), abi.fptr(b), out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def debug_sizes(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        d = C.c_uint32()
+        l = C.c_int()
+        _check(lib().rl_debug_bvh_sizes(self.h, C.byref(a), C.byref(b), C.byref(d), C.byref(l)))
+        return {"ref_nodes": a.value, "prims": b.value, "stack_depth": d.value, "lds_scene": bool(l.value)}
+
+
+class IntegratorPathTracing:
+    """struct IntegratorPathTracing (src/integrators/explicit/path.rs:14-20) + Integrator::compute."""
+
+    def __init__(self, min_depth=0, max_depth=None, rr_depth=0, strategy=STRATEGY_ALL, single_scattering=False,
+                 stream_mode=STREAM_PER_SAMPLE, device=0):
+        self.min_depth, self.max_depth, self.rr_depth = min_depth, max_depth, rr_depth
+        self.strategy, self.single_scattering = strategy, single_scattering
+        self.stream_mode, self.device = stream_mode, device
+        self.last_stats = None
+        self._ctx = None
+
+    def compute(self, sampler: IndependentSampler, scene: Scene, nb_samples: int = 1):
+        """IntegratorType::compute (integrators/mod.rs:274-338): BVH build (untimed) then the render."""
+        if self._ctx is None or self._ctx.scene is not scene:
+            self._ctx = Context(scene, self.device)
+        w, h = scene.size
+        seeds = sampler.block_seeds(w, h)
+        p = path_params(nb_samples, self.min_depth, self.max_depth, self.rr_depth, self.strategy, self.single_scattering,
+                        self.stream_mode, sampler.variant)
+        img, self.last_stats = self._ctx.render(seeds, p)
+        return img
+
+
+def save_pfm(path: str, img: np.ndarray):
+    a = np.ascontiguousarray(img, dtype=np.float32)
+    _check(lib().rl_save_pfm(path.encode(), abi.fptr(a), a.shape[1], a.shape[0]))
+
+
+def numerics_probe(a: np.ndarray, b: np.ndarray, device: int = 0) -> np.ndarray:
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    out = np.zeros((8, a.shape[0]), np.float32)
+    _check(lib().rl_debug_numerics(device, a.shape[0], abi.fptr(a), abi.fptr(b), abi.fptr(out)))
+    return out

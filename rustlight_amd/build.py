@@ -1,0 +1,69 @@
+"""Build the product library IN-TREE: rustlight_amd/lib/librustlight_amd.so (HIP kernels for gfx950 +
+host C++), so it travels to the GPU box with the repo snapshot.  hipcc cross-compiles without a GPU."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIB_DIR, "librustlight_amd.so")
+BIN = os.path.join(LIB_DIR, "rustlight-amd")
+
+HIP_SOURCES = ["kernels/wavefront.hip"]
+CXX_SOURCES = ["host/scene.cpp", "host/bvh.cpp", "host/io.cpp", "host/pbrt.cpp"]
+# -ffp-contract=off: rustlight's f32 arithmetic is never contracted into FMAs
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-value", "-Wno-unused-function"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CXX = os.environ.get("CXX", "g++")
+
+
+def _deps():
+    out = []
+    for root, _, files in os.walk(CSRC):
+        out += [os.path.join(root, f) for f in files]
+    out.append(os.path.join(HERE, "..", "include", "rustlight_amd.h"))
+    return out
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIB_DIR, exist_ok=True)
+    deps = _deps()
+    if not force and not _stale(LIB, deps) and not _stale(BIN, deps):
+        return LIB
+    objs = []
+    for src in HIP_SOURCES:
+        obj = os.path.join(LIB_DIR, os.path.basename(src) + ".o")
+        cmd = [HIPCC, "--offload-arch=gfx950", *COMMON, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    for src in CXX_SOURCES:
+        obj = os.path.join(LIB_DIR, os.path.basename(src) + ".o")
+        cmd = [CXX, *COMMON, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-o", LIB, *objs]
+    subprocess.check_call(cmd)
+    # the CLI (examples/cli.rs counterpart)
+    cli = os.path.join(CSRC, "host", "cli.cpp")
+    if os.path.exists(cli):
+        subprocess.check_call([CXX, *COMMON, cli, "-o", BIN, "-L" + LIB_DIR, "-lrustlight_amd", "-Wl,-rpath,$ORIGIN",
+                               "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,121 @@
+// device_types.h — POD layouts shared by the host code (C++) and the HIP kernels.
+//
+// HBM layout of the flattened scene (DESIGN.md §Data layout).  The reference keeps AoS
+// `Vec<Vector3<f32>>` per mesh behind `Arc<Mesh>` and 40-byte BVH nodes with separate child
+// boxes (src/accel.rs:79-94, src/geometry.rs:107-119); here everything a ray touches is packed
+// into 64-byte records so that one lane fetches a whole record with four 16-byte loads.
+#pragma once
+#include <stdint.h>
+
+namespace rl {
+
+// ---- BVH2 node: both child boxes in the parent (one fetch decides the descent order) ------
+// child encoding: >= 0 : index of an inner node;  < 0 : leaf = ~((first_prim << 2) | count), count in {1,2}
+//                 RL_CHILD_NONE: empty slot (box never hit)
+struct alignas(16) BvhNode {
+    float lmin[3]; float lmax0;     // left child  p_min, p_max.x
+    float lmax12[2]; float rmin01[2];  // left p_max.yz, right p_min.xy
+    float rmin2; float rmax[3];     // right p_min.z, p_max
+    int32_t left, right; int32_t pad0, pad1;
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+static const int32_t RL_CHILD_NONE = (int32_t)0x80000000;
+
+// ---- triangle record in BVH leaf order: ray-independent terms of Mesh::intersection_tri
+//      (src/geometry.rs:358-410) are precomputed once on the host with the reference's f32 ops.
+struct alignas(16) TriRecord {
+    float v0[3]; float n0;   // v0, n_geo.x
+    float e1[3]; float n1;   // e1 = v1 - v0, n_geo.y
+    float e2[3]; float n2;   // e2 = v2 - v0, n_geo.z
+    float det;               // |e1 x e2|
+    int32_t mesh;            // mesh index
+    int32_t tri;             // triangle index inside the mesh
+    int32_t gtri;            // global triangle index (into tri_indices / shading arrays)
+};
+static_assert(sizeof(TriRecord) == 64, "TriRecord must be 64 bytes");
+
+// ---- BSDFColor (src/bsdfs/mod.rs:11-29)
+struct ColorTex {
+    int32_t type;       // rl_tex_type
+    float c0[3];
+    float c1[3];
+    float offset[2];
+    float scale[2];
+    float line_width;
+    int32_t bitmap;     // index into bitmap table
+    int32_t pad[3];
+};
+static_assert(sizeof(ColorTex) == 64, "ColorTex must be 64 bytes");
+
+struct BitmapDesc { uint32_t w, h; uint64_t offset; };  // offset (in float3 texels) into bitmap_texels
+
+// ---- material = one `impl BSDF` object (src/bsdfs/*.rs)
+struct Material {
+    int32_t type;            // rl_bsdf_type
+    int32_t distribution;    // rl_microfacet_type
+    float exponent, weight_specular;
+    float alpha_u, alpha_v;
+    float glass_eta, glass_inv_eta;
+    int32_t smooth;          // BSDFType::is_smooth()
+    int32_t twosided;        // BSDF::is_twosided()
+    int32_t pad[2];
+    ColorTex diffuse, specular, transmittance, eta, k;
+};
+
+// ---- per-mesh record (struct Mesh, src/geometry.rs:107-119)
+struct MeshRecord {
+    int32_t material;        // index into materials (one per mesh: `bsdf: Box<dyn BSDF>`)
+    int32_t flags;           // MESH_*
+    float emission[3];       // EmissionType::Color
+    float inv_area;          // Mesh::pdf() = 1 / cdf.total()
+    float emitter_pdf;       // EmitterSampler::pdf(self) = emitters_cdf.pdf(i); 0 if not an emitter
+    uint32_t vertex_base;    // first vertex in the global vertex arrays
+    uint32_t tri_base;       // first triangle in the global index array
+    uint32_t n_tris;
+    uint32_t cdf_base;       // first entry of this mesh's area cdf (n_tris + 1 entries)
+    uint32_t pad;
+};
+enum { MESH_HAS_NORMALS = 1, MESH_HAS_UV = 2, MESH_IS_LIGHT = 4 };
+
+struct CameraRecord {   // struct Camera (src/camera.rs:5-15)
+    float sample_to_camera[16];  // column-major
+    float to_world[16];
+    float position[3];
+    uint32_t width, height;
+};
+
+struct MediumRecord {   // HomogenousVolume (src/volume.rs:73-80)
+    int32_t enabled;
+    float sigma_a[3], sigma_s[3], sigma_t[3];
+    int32_t phase;
+    float g;
+};
+
+// Everything the kernels need about the scene (device pointers).
+struct DeviceScene {
+    const BvhNode* nodes;
+    const TriRecord* tris;
+    float root_min[3], root_max[3];
+    int32_t root;            // child encoding of the root (inner 0, a leaf, or NONE for an empty scene)
+    uint32_t n_nodes, n_prims;
+    uint32_t stack_depth;    // max number of simultaneously pending far children (+1)
+    // shading data
+    const uint32_t* tri_indices;   // 3 per global triangle, already offset by vertex_base
+    const float* positions;        // 3 per vertex
+    const float* normals;          // 3 per vertex (zeros where the mesh has none)
+    const float* uvs;              // 2 per vertex
+    const MeshRecord* meshes;
+    const Material* materials;
+    const BitmapDesc* bitmaps;
+    const float* bitmap_texels;
+    // EmitterSampler (non-ATS): emitters in mesh order + cdf over flux.channel_max()
+    const int32_t* emitters;       // mesh ids
+    const float* emitters_cdf;     // n_emitters + 1
+    uint32_t n_emitters;
+    const float* mesh_cdf;         // concatenated per-mesh area cdfs
+    uint32_t n_meshes;
+    CameraRecord camera;
+    MediumRecord medium;
+};
+
+}  // namespace rl

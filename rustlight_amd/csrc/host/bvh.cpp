@@ -1,0 +1,164 @@
+// bvh.cpp — host BVH2 construction in the GPU layout (untimed, like `BVHAccel::new` which
+// IntegratorType::compute calls before starting its timer: src/integrators/mod.rs:280 vs 324).
+//
+// Algorithm = the reference's (src/accel.rs:115-239): per node a full sweep of the SAH cost
+// n_l * A(left) + n_r * A(right) on the three axes over the primitives sorted by box centre,
+// leaves of at most two triangles, median split as fallback.  Rust's `sort_by` with the
+// comparator `a < b ? Less : Greater` is a stable sort by key (the stable merge sort only asks
+// "is a less than b"), so std::stable_sort reproduces the primitive order — and therefore the
+// same closest hit on exact-distance ties — exactly.
+//
+// Output layout (device_types.h): inner nodes only, each carrying both child boxes; leaves are
+// folded into the parent's child slots; triangles are pre-transformed into 64-byte TriRecords.
+#include <algorithm>
+#include <cstring>
+
+#include "scene.h"
+
+namespace rl {
+namespace {
+
+struct PrimBox { Box3 box; int32_t mesh; uint32_t tri; };
+struct RefNode { Box3 box; size_t info; size_t count; };
+
+struct Builder {
+    std::vector<PrimBox> prims;
+    std::vector<RefNode> nodes;
+
+    Box3 range_box(size_t first, size_t count) const {
+        Box3 b;
+        for (size_t i = 0; i < count; i++) b.grow(prims[first + i].box);
+        return b;
+    }
+    void sort_axis(size_t first, size_t count, int axis) {
+        std::stable_sort(prims.begin() + first, prims.begin() + first + count,
+                         [axis](const PrimBox& a, const PrimBox& b) { return a.box.centre().get(axis) < b.box.centre().get(axis); });
+    }
+    void subdivide(size_t id) {
+        if (nodes[id].count <= 2) return;
+        const size_t n = nodes[id].count, first = nodes[id].info;
+        nodes[id].count = 0;
+        nodes[id].info = nodes.size();
+        size_t best_pos = 0;
+        float best_cost = INFINITY;
+        int best_axis = 3;
+        std::vector<float> cost(n - 1, 0.0f);
+        for (int axis = 0; axis < 3; axis++) {
+            sort_axis(first, n, axis);
+            Box3 acc;
+            for (size_t k = 0; k + 1 < n; k++) {       // right-to-left sweep
+                size_t idx = n - k - 1;
+                acc.grow(prims[first + idx].box);
+                cost[idx - 1] = acc.half_area() * (float)(k + 1);
+            }
+            acc = Box3();
+            for (size_t k = 0; k + 1 < n; k++) {       // left-to-right sweep
+                acc.grow(prims[first + k].box);
+                cost[k] += acc.half_area() * (float)(k + 1);
+                if (cost[k] < best_cost) { best_cost = cost[k]; best_axis = axis; best_pos = k + 1; }
+            }
+        }
+        if (best_axis < 3) sort_axis(first, n, best_axis);
+        size_t split = (best_pos == n || best_pos == 0) ? std::max<size_t>((size_t)((float)n * 0.5f), 1) : best_pos;
+        RefNode l{range_box(first, split), first, split};
+        RefNode r{range_box(first + split, n - split), first + split, n - split};
+        size_t li = nodes.size();
+        nodes.push_back(l);
+        nodes.push_back(r);
+        subdivide(li);
+        subdivide(li + 1);
+    }
+};
+
+}  // namespace
+
+void build_bvh(const rl_scene& scene, BvhBuild* out) {
+    *out = BvhBuild();
+    Builder b;
+    Box3 root;
+    std::vector<uint32_t> tri_base;
+    uint32_t tb = 0;
+    for (size_t m = 0; m < scene.meshes.size(); m++) {
+        const HostMesh& mesh = scene.meshes[m];
+        tri_base.push_back(tb);
+        tb += (uint32_t)mesh.n_tris();
+        for (size_t t = 0; t < mesh.n_tris(); t++) {
+            Box3 bx;   // Mesh::compute_aabb_tri (src/geometry.rs:423-439)
+            for (int k = 0; k < 3; k++) bx.grow(mesh.positions[mesh.indices[3 * t + k]]);
+            bx.pad_degenerate(0.0001f);
+            b.prims.push_back({bx, (int32_t)m, (uint32_t)t});
+            root.grow(bx);
+        }
+    }
+    b.nodes.push_back({root, 0, b.prims.size()});
+    b.subdivide(0);
+
+    // reference-shaped dump (tests compare it with the oracle's)
+    for (const RefNode& n : b.nodes) {
+        out->ref_boxes.insert(out->ref_boxes.end(), {n.box.lo.x, n.box.lo.y, n.box.lo.z, n.box.hi.x, n.box.hi.y, n.box.hi.z});
+        out->ref_info.push_back(n.info);
+        out->ref_count.push_back(n.count);
+    }
+    for (const PrimBox& p : b.prims) { out->ref_prim_mesh.push_back(p.mesh); out->ref_prim_tri.push_back((int32_t)p.tri); }
+
+    // triangle records in leaf order
+    out->tris.resize(b.prims.size());
+    for (size_t i = 0; i < b.prims.size(); i++) {
+        const HostMesh& mesh = scene.meshes[b.prims[i].mesh];
+        uint32_t t = b.prims[i].tri;
+        Vec3 v0 = mesh.positions[mesh.indices[3 * t]], v1 = mesh.positions[mesh.indices[3 * t + 1]], v2 = mesh.positions[mesh.indices[3 * t + 2]];
+        Vec3 e1 = vsub(v1, v0), e2 = vsub(v2, v0);
+        Vec3 c = vcross(e1, e2);
+        Vec3 n = vnormalize(c);   // n_geo (geometry.rs:370)
+        TriRecord& r = out->tris[i];
+        r.v0[0] = v0.x; r.v0[1] = v0.y; r.v0[2] = v0.z;
+        r.e1[0] = e1.x; r.e1[1] = e1.y; r.e1[2] = e1.z;
+        r.e2[0] = e2.x; r.e2[1] = e2.y; r.e2[2] = e2.z;
+        r.n0 = n.x; r.n1 = n.y; r.n2 = n.z;
+        r.det = vlen(c);          // det (geometry.rs:381)
+        r.mesh = b.prims[i].mesh;
+        r.tri = (int32_t)t;
+        r.gtri = (int32_t)(tri_base[b.prims[i].mesh] + t);
+    }
+
+    out->root_min[0] = root.lo.x; out->root_min[1] = root.lo.y; out->root_min[2] = root.lo.z;
+    out->root_max[0] = root.hi.x; out->root_max[1] = root.hi.y; out->root_max[2] = root.hi.z;
+    if (b.prims.empty()) { out->root = RL_CHILD_NONE; return; }
+
+    // inner-node numbering in creation order; leaves folded into child slots
+    std::vector<int32_t> inner_id(b.nodes.size(), -1);
+    int32_t n_inner = 0;
+    for (size_t i = 0; i < b.nodes.size(); i++)
+        if (b.nodes[i].count == 0) inner_id[i] = n_inner++;
+    auto encode = [&](size_t i) -> int32_t {
+        const RefNode& n = b.nodes[i];
+        if (n.count == 0) return inner_id[i];
+        return ~(int32_t)(((uint32_t)n.info << 2) | (uint32_t)n.count);
+    };
+    out->nodes.resize(n_inner);
+    for (size_t i = 0; i < b.nodes.size(); i++) {
+        if (b.nodes[i].count != 0) continue;
+        const RefNode& l = b.nodes[b.nodes[i].info];
+        const RefNode& r = b.nodes[b.nodes[i].info + 1];
+        BvhNode& d = out->nodes[inner_id[i]];
+        std::memset(&d, 0, sizeof(d));
+        d.lmin[0] = l.box.lo.x; d.lmin[1] = l.box.lo.y; d.lmin[2] = l.box.lo.z;
+        d.lmax0 = l.box.hi.x; d.lmax12[0] = l.box.hi.y; d.lmax12[1] = l.box.hi.z;
+        d.rmin01[0] = r.box.lo.x; d.rmin01[1] = r.box.lo.y; d.rmin2 = r.box.lo.z;
+        d.rmax[0] = r.box.hi.x; d.rmax[1] = r.box.hi.y; d.rmax[2] = r.box.hi.z;
+        d.left = encode(b.nodes[i].info);
+        d.right = encode(b.nodes[i].info + 1);
+    }
+    out->root = encode(0);
+    // traversal stack bound: one pending far child per inner level
+    std::vector<uint32_t> depth(b.nodes.size(), 0);
+    uint32_t max_depth = 0;
+    for (size_t i = 0; i < b.nodes.size(); i++) {
+        if (b.nodes[i].count != 0) continue;
+        depth[b.nodes[i].info] = depth[b.nodes[i].info + 1] = depth[i] + 1;
+        max_depth = std::max(max_depth, depth[i] + 1);
+    }
+    out->stack_depth = max_depth + 1;
+}
+
+}  // namespace rl

@@ -1,0 +1,111 @@
+// cli.cpp — `rustlight-amd`: the reference CLI's flags for the `path` subcommand (examples/cli.rs:
+// global flags 106-145, `path` 162-169, medium 355-399, sampler 876-896, run/save 898-923).
+//   rustlight-amd <scene.pbrt> -n SPP -o out.pfm [-r independent:SEED] [-m s[:a[:g]]] [-s SCALE] [-t N]
+//                 [--device D] [--stream-mode reference|per-sample]
+//                 path [-m MAX|inf] [-n MIN] [-r RR|inf] [-x] [-s all|bsdf|emitter]
+// Note `-n` / `-m` / `-r` / `-s` mean spp / medium / sampler / scale before the subcommand and
+// min-depth / max-depth / rr-depth / strategy after it, exactly as in the reference.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <random>
+#include <sstream>
+
+#include "integrator.hpp"
+
+using namespace rustlight;
+
+static std::optional<uint32_t> match_infinity(const std::string& s) {   // cli.rs:31-39
+    if (s == "inf") return std::nullopt;
+    char* e = nullptr;
+    unsigned long v = std::strtoul(s.c_str(), &e, 10);
+    if (!e || *e) { std::fprintf(stderr, "wrong input for inf type parameter\n"); std::exit(2); }
+    return (uint32_t)v;
+}
+
+int main(int argc, char** argv) {
+    std::string scene_path, output, medium = "0.0", rng = "independent", strategy = "all";
+    std::string max_depth = "inf", min_depth = "0", rr_depth = "0";
+    size_t nbsamples = 1;
+    float scale_image = 1.0f;
+    int device = 0;
+    bool single_scattering = false, have_cmd = false;
+    rl_stream_mode mode = RL_STREAM_PER_SAMPLE;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto val = [&]() -> std::string { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
+        if (!have_cmd) {
+            if (a == "path") have_cmd = true;
+            else if (a == "-n" || a == "--nbsamples") nbsamples = std::strtoull(val().c_str(), nullptr, 10);
+            else if (a == "-o" || a == "--output") output = val();
+            else if (a == "-r" || a == "--random-number-generator") rng = val();
+            else if (a == "-m" || a == "--medium") medium = val();
+            else if (a == "-s" || a == "--scale-image") scale_image = std::strtof(val().c_str(), nullptr);
+            else if (a == "-t" || a == "--threads") (void)val();   // host threads are irrelevant on the GPU path
+            else if (a == "--device") device = std::atoi(val().c_str());
+            else if (a == "--stream-mode") mode = val() == "reference" ? RL_STREAM_REFERENCE_ORDER : RL_STREAM_PER_SAMPLE;
+            else if (a == "-a" || a == "-e" || a == "-l" || a == "-x") { std::fprintf(stderr, "option %s is not supported by this drop-in yet\n", a.c_str()); return 2; }
+            else if (a[0] == '-') { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+            else if (scene_path.empty()) scene_path = a;
+            else { std::fprintf(stderr, "only the `path` subcommand is provided (got %s)\n", a.c_str()); return 2; }
+        } else {
+            if (a == "-m" || a == "--max-depth") max_depth = val();
+            else if (a == "-n" || a == "--min-depth") min_depth = val();
+            else if (a == "-r" || a == "--rr-depth") rr_depth = val();
+            else if (a == "-x" || a == "--single-scattering") single_scattering = true;
+            else if (a == "-s" || a == "--strategy") strategy = val();
+            else { std::fprintf(stderr, "unknown path option %s\n", a.c_str()); return 2; }
+        }
+    }
+    if (scene_path.empty() || output.empty() || !have_cmd) {
+        std::fprintf(stderr, "usage: rustlight-amd <scene.pbrt> -n SPP -o out.pfm [-r independent:SEED] [-m s[:a[:g]]] path [-m max] [-n min] [-r rr] [-x] [-s all|bsdf|emitter]\n");
+        return 2;
+    }
+    try {
+        std::unique_ptr<Scene> scene(Scene::load(scene_path));
+        scene->nb_samples = nbsamples;
+        scene->output_img_path = output;
+        {   // medium: sigma_s[:sigma_a[:g]] (cli.rs:355-399)
+            std::vector<std::string> parts;
+            std::stringstream ss(medium);
+            for (std::string tok; std::getline(ss, tok, ':');) parts.push_back(tok);
+            float sigma_s = parts.size() > 0 ? std::strtof(parts[0].c_str(), nullptr) : 0.0f;
+            float sigma_a = parts.size() > 1 ? std::strtof(parts[1].c_str(), nullptr) : 0.0f;
+            if (parts.size() > 3) { std::fprintf(stderr, "invalid medium_density\n"); return 2; }
+            if (sigma_a + sigma_s != 0.0f) {
+                float sa[3] = {sigma_a, sigma_a, sigma_a}, s3[3] = {sigma_s, sigma_s, sigma_s};
+                float g = parts.size() > 2 ? std::strtof(parts[2].c_str(), nullptr) : 0.0f;
+                rl_scene_set_medium(scene->handle, sa, s3, parts.size() > 2 ? RL_PHASE_HG : RL_PHASE_ISOTROPIC, g);
+            }
+        }
+        if (scale_image != 1.0f) rl_scene_scale_image(scene->handle, scale_image);
+        scene->build_emitters();
+        IntegratorPathTracing integrator;
+        integrator.min_depth = match_infinity(min_depth);
+        integrator.max_depth = match_infinity(max_depth);
+        integrator.rr_depth = match_infinity(rr_depth);
+        if (strategy == "all") integrator.strategy = IntegratorPathTracingStrategies::All;
+        else if (strategy == "bsdf") integrator.strategy = IntegratorPathTracingStrategies::BSDF;
+        else if (strategy == "emitter") integrator.strategy = IntegratorPathTracingStrategies::Emitter;
+        else { std::fprintf(stderr, "invalid strategy: %s\n", strategy.c_str()); return 2; }
+        integrator.single_scattering = single_scattering;
+        integrator.device = device;
+        integrator.stream_mode = mode;
+        uint64_t seed;
+        if (rng == "independent") seed = std::random_device{}();   // IndependentSampler::default(): OS entropy
+        else if (rng.rfind("independent:", 0) == 0) seed = std::strtoull(rng.c_str() + 12, nullptr, 10);
+        else { std::fprintf(stderr, "Wrong sampler type provided %s (only independent[:seed])\n", rng.c_str()); return 2; }
+        IndependentSampler sampler(seed);
+        BufferCollection img = integrator.compute(sampler, *scene);
+        std::fprintf(stderr, "INFO Elapsed Integrator: %.0f ms\n", integrator.last_stats.render_ms);
+        std::fprintf(stderr, "INFO Save final image: %s\n", output.c_str());
+        if (output.size() < 4 || output.substr(output.size() - 4) != ".pfm") { std::fprintf(stderr, "only .pfm output is supported\n"); return 2; }
+        img.save("primal", output);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "ERROR %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

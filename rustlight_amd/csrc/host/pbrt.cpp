@@ -1,0 +1,335 @@
+// pbrt.cpp — loader for the PBRT-v3 subset rustlight's PBRT front end consumes
+// (src/scene_loader.rs:77-315 + the material converter src/bsdfs/mod.rs:217-390).  The reference
+// delegates parsing to the un-vendored `pbrt_rs` crate; this is a from-scratch tokenizer + a small
+// graphics-state machine that produces the same `Scene` content:
+//   * camera  = Camera::new(image_size, Fov::Y(fov), inverse(CTM at `Camera`), flip = false)
+//   * meshes  = every `Shape "trianglemesh"` in file order, points/normals transformed by the CTM
+//   * bsdf    = named / current material: matte, mirror, metal, glass, substrate (constant colours)
+//   * emission= `AreaLightSource "diffuse" "rgb L"` active in the current attribute scope
+// Unsupported directives (Include, Texture, ply shapes, LightSource ...) return RL_ERR_UNSUPPORTED.
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+
+#include "../kernels/wavefront.h"
+#include "scene.h"
+
+namespace rl {
+namespace {
+
+struct Token { enum Kind { Word, Str, Num, LBr, RBr, End } kind; std::string text; double num; };
+
+struct Lexer {
+    std::string src;
+    size_t pos = 0;
+    Token peeked; bool has_peek = false;
+    Token next() {
+        if (has_peek) { has_peek = false; return peeked; }
+        while (pos < src.size()) {
+            char c = src[pos];
+            if (std::isspace((unsigned char)c)) { pos++; continue; }
+            if (c == '#') { while (pos < src.size() && src[pos] != '\n') pos++; continue; }
+            break;
+        }
+        if (pos >= src.size()) return {Token::End, "", 0};
+        char c = src[pos];
+        if (c == '[') { pos++; return {Token::LBr, "[", 0}; }
+        if (c == ']') { pos++; return {Token::RBr, "]", 0}; }
+        if (c == '"') {
+            size_t e = src.find('"', pos + 1);
+            if (e == std::string::npos) e = src.size();
+            Token t{Token::Str, src.substr(pos + 1, e - pos - 1), 0};
+            pos = e + 1;
+            return t;
+        }
+        size_t s = pos;
+        while (pos < src.size() && !std::isspace((unsigned char)src[pos]) && src[pos] != '[' && src[pos] != ']' && src[pos] != '"') pos++;
+        std::string w = src.substr(s, pos - s);
+        char* endp = nullptr;
+        double v = std::strtod(w.c_str(), &endp);
+        if (endp && *endp == 0 && !w.empty()) return {Token::Num, w, v};
+        return {Token::Word, w, 0};
+    }
+    Token peek() { if (!has_peek) { peeked = next(); has_peek = true; } return peeked; }
+};
+
+struct Param { std::string type, name; std::vector<double> nums; std::vector<std::string> strs; };
+
+// reads `"type name" value|[values]` pairs until the next directive
+static bool read_params(Lexer& lx, std::vector<Param>* out) {
+    out->clear();
+    while (lx.peek().kind == Token::Str) {
+        Token decl = lx.next();
+        Param p;
+        std::istringstream is(decl.text);
+        is >> p.type >> p.name;
+        Token t = lx.next();
+        if (t.kind == Token::LBr) {
+            for (;;) {
+                Token v = lx.next();
+                if (v.kind == Token::RBr) break;
+                if (v.kind == Token::Num) p.nums.push_back(v.num);
+                else if (v.kind == Token::Str || v.kind == Token::Word) p.strs.push_back(v.text);
+                else return false;
+            }
+        } else if (t.kind == Token::Num) p.nums.push_back(t.num);
+        else if (t.kind == Token::Str || t.kind == Token::Word) p.strs.push_back(t.text);
+        else return false;
+        out->push_back(std::move(p));
+    }
+    return true;
+}
+static const Param* find(const std::vector<Param>& ps, const char* name) {
+    for (const Param& p : ps) if (p.name == name) return &p;
+    return nullptr;
+}
+
+static rl_color_desc constant_color(float r, float g, float b) {
+    rl_color_desc c;
+    std::memset(&c, 0, sizeof(c));
+    c.type = RL_TEX_CONSTANT;
+    c.color0[0] = r; c.color0[1] = g; c.color0[2] = b;
+    c.scale[0] = c.scale[1] = 1.0f;
+    c.bitmap_id = -1;
+    return c;
+}
+static rl_color_desc color_param(const std::vector<Param>& ps, const char* name, float dr, float dg, float db) {
+    const Param* p = find(ps, name);
+    if (p && p->nums.size() >= 3) return constant_color((float)p->nums[0], (float)p->nums[1], (float)p->nums[2]);
+    if (p && p->nums.size() == 1) return constant_color((float)p->nums[0], (float)p->nums[0], (float)p->nums[0]);
+    return constant_color(dr, dg, db);
+}
+static float float_param(const std::vector<Param>& ps, const char* name, float def) {
+    const Param* p = find(ps, name);
+    return (p && !p->nums.empty()) ? (float)p->nums[0] : def;
+}
+
+// pbrt roughness -> alpha (distribution_pbrt, src/bsdfs/mod.rs:254-293); host-only setup arithmetic
+static float remap_roughness(float v, bool remap) {
+    if (!remap) return v;
+    float x = std::log(std::fmax(v, 1e-3f));
+    return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+}
+
+// bsdf_pbrt (src/bsdfs/mod.rs:295-390)
+static rl_bsdf_desc make_material(const std::string& type, const std::vector<Param>& ps) {
+    rl_bsdf_desc b;
+    std::memset(&b, 0, sizeof(b));
+    b.diffuse = b.specular = b.transmittance = constant_color(1, 1, 1);
+    b.eta = constant_color(1, 1, 1);
+    b.k = constant_color(0, 0, 0);
+    b.glass_eta = 1.0f;
+    const Param* remap_p = find(ps, "remaproughness");
+    bool remap = !(remap_p && !remap_p->strs.empty() && remap_p->strs[0] == "false");
+    float rough = float_param(ps, "roughness", 0.1f);
+    float ur = float_param(ps, "uroughness", rough), vr = float_param(ps, "vroughness", rough);
+    if (type == "matte") {
+        b.type = RL_BSDF_DIFFUSE;
+        b.diffuse = color_param(ps, "Kd", 0.5f, 0.5f, 0.5f);
+    } else if (type == "mirror") {
+        b.type = RL_BSDF_METAL;
+        b.specular = color_param(ps, "Kr", 0.9f, 0.9f, 0.9f);
+        b.distribution = RL_MICROFACET_NONE;
+    } else if (type == "metal") {
+        b.type = RL_BSDF_METAL;
+        b.eta = color_param(ps, "eta", 0.2004376970f, 0.9240334304f, 1.1022119527f);
+        b.k = color_param(ps, "k", 3.9129485033f, 2.4528477015f, 2.1421879552f);
+        b.distribution = RL_MICROFACET_GGX;
+        b.alpha_u = remap_roughness(ur, remap); b.alpha_v = remap_roughness(vr, remap);
+    } else if (type == "glass") {
+        b.type = RL_BSDF_GLASS;
+        b.specular = color_param(ps, "Kr", 1, 1, 1);
+        b.transmittance = color_param(ps, "Kt", 1, 1, 1);
+        float eta = float_param(ps, "eta", float_param(ps, "index", 1.5f));
+        b.glass_eta = eta / 1.0f;   // BSDFGlass::eta(eta, 1.0)
+    } else if (type == "substrate") {
+        b.type = RL_BSDF_SUBSTRATE;
+        b.diffuse = color_param(ps, "Kd", 0.5f, 0.5f, 0.5f);
+        b.specular = color_param(ps, "Ks", 0.5f, 0.5f, 0.5f);
+        b.distribution = RL_MICROFACET_GGX;
+        b.alpha_u = remap_roughness(ur, remap); b.alpha_v = remap_roughness(vr, remap);
+    } else {   // unknown material: BSDFDiffuse(0.8) (bsdfs/mod.rs:384-389)
+        b.type = RL_BSDF_DIFFUSE;
+        b.diffuse = constant_color(0.8f, 0.8f, 0.8f);
+    }
+    return b;
+}
+
+static rl_bsdf_desc default_material() {   // no material bound: BSDFDiffuse(0.5) (scene_loader.rs:124-132)
+    std::vector<Param> none;
+    rl_bsdf_desc b = make_material("matte", none);
+    return b;
+}
+
+struct GState {
+    Mat4 ctm = Mat4::identity();
+    bool has_material = false; rl_bsdf_desc material;
+    bool has_emission = false; float emission[3] = {0, 0, 0};
+    bool reverse_orientation = false;
+};
+
+static Mat4 look_at(const double* v) {
+    // pbrt LookAt: camera-to-world from eye/look/up, returns world-to-camera (its inverse)
+    Vec3 eye{(float)v[0], (float)v[1], (float)v[2]}, look{(float)v[3], (float)v[4], (float)v[5]}, up{(float)v[6], (float)v[7], (float)v[8]};
+    Vec3 dir = vnormalize(vsub(look, eye));
+    Vec3 right = vnormalize(vcross(vnormalize(up), dir));
+    Vec3 new_up = vcross(dir, right);
+    Mat4 c2w = Mat4::identity();
+    c2w.m[0][0] = right.x; c2w.m[0][1] = right.y; c2w.m[0][2] = right.z;
+    c2w.m[1][0] = new_up.x; c2w.m[1][1] = new_up.y; c2w.m[1][2] = new_up.z;
+    c2w.m[2][0] = dir.x; c2w.m[2][1] = dir.y; c2w.m[2][2] = dir.z;
+    c2w.m[3][0] = eye.x; c2w.m[3][1] = eye.y; c2w.m[3][2] = eye.z;
+    Mat4 w2c;
+    c2w.inverse(&w2c);
+    return w2c;
+}
+
+}  // namespace
+
+int load_pbrt(const char* path, bool use_shading_normals, rl_scene** out, std::string* err) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) { *err = std::string("cannot open ") + path; return RL_ERR_IO; }
+    std::stringstream ss;
+    ss << f.rdbuf();
+    Lexer lx;
+    lx.src = ss.str();
+    std::vector<GState> stack;
+    GState gs;
+    std::map<std::string, rl_bsdf_desc> named;
+    rl_scene* scene = new rl_scene();
+    uint32_t width = 512, height = 512;
+    float fov = 90.0f;
+    bool have_camera = false;
+    Mat4 world_to_camera = Mat4::identity();
+    std::vector<Param> ps;
+    auto fail = [&](int code, const std::string& msg) { *err = msg; delete scene; return code; };
+    for (;;) {
+        Token t = lx.next();
+        if (t.kind == Token::End) break;
+        if (t.kind != Token::Word) return fail(RL_ERR_PARSE, "unexpected token '" + t.text + "'");
+        const std::string& d = t.text;
+        if (d == "Transform" || d == "ConcatTransform") {
+            if (lx.next().kind != Token::LBr) return fail(RL_ERR_PARSE, d + ": expected [");
+            float m[16]; int n = 0;
+            for (;;) { Token v = lx.next(); if (v.kind == Token::RBr) break; if (v.kind != Token::Num || n >= 16) return fail(RL_ERR_PARSE, d + ": bad matrix"); m[n++] = (float)v.num; }
+            if (n != 16) return fail(RL_ERR_PARSE, d + ": need 16 numbers");
+            Mat4 mm = Mat4::from_cols(m);
+            gs.ctm = d == "Transform" ? mm : gs.ctm.times(mm);
+        } else if (d == "Identity") {
+            gs.ctm = Mat4::identity();
+        } else if (d == "Translate" || d == "Scale") {
+            double v[3];
+            for (int i = 0; i < 3; i++) { Token n = lx.next(); if (n.kind != Token::Num) return fail(RL_ERR_PARSE, d + ": need 3 numbers"); v[i] = n.num; }
+            gs.ctm = gs.ctm.times(d == "Translate" ? Mat4::translate((float)v[0], (float)v[1], (float)v[2]) : Mat4::scale((float)v[0], (float)v[1], (float)v[2]));
+        } else if (d == "LookAt") {
+            double v[9];
+            for (int i = 0; i < 9; i++) { Token n = lx.next(); if (n.kind != Token::Num) return fail(RL_ERR_PARSE, "LookAt: need 9 numbers"); v[i] = n.num; }
+            gs.ctm = gs.ctm.times(look_at(v));
+        } else if (d == "Camera") {
+            Token ty = lx.next();
+            if (!read_params(lx, &ps)) return fail(RL_ERR_PARSE, "Camera: bad parameters");
+            if (ty.text != "perspective") return fail(RL_ERR_UNSUPPORTED, "Camera: only perspective is supported");
+            fov = float_param(ps, "fov", 90.0f);
+            world_to_camera = gs.ctm;
+            have_camera = true;
+        } else if (d == "Film") {
+            lx.next();
+            if (!read_params(lx, &ps)) return fail(RL_ERR_PARSE, "Film: bad parameters");
+            width = (uint32_t)float_param(ps, "xresolution", 512.0f);
+            height = (uint32_t)float_param(ps, "yresolution", 512.0f);
+        } else if (d == "Sampler" || d == "PixelFilter" || d == "Integrator" || d == "Accelerator") {
+            lx.next();
+            if (!read_params(lx, &ps)) return fail(RL_ERR_PARSE, d + ": bad parameters");
+        } else if (d == "WorldBegin") {
+            gs = GState();
+            stack.clear();
+        } else if (d == "WorldEnd") {
+        } else if (d == "AttributeBegin" || d == "TransformBegin") {
+            stack.push_back(gs);
+        } else if (d == "AttributeEnd" || d == "TransformEnd") {
+            if (stack.empty()) return fail(RL_ERR_PARSE, d + " without Begin");
+            if (d == "TransformEnd") { Mat4 keep = stack.back().ctm; stack.pop_back(); gs.ctm = keep; }
+            else { gs = stack.back(); stack.pop_back(); }
+        } else if (d == "ReverseOrientation") {
+            gs.reverse_orientation = !gs.reverse_orientation;
+        } else if (d == "MakeNamedMaterial") {
+            Token name = lx.next();
+            if (!read_params(lx, &ps)) return fail(RL_ERR_PARSE, "MakeNamedMaterial: bad parameters");
+            const Param* ty = find(ps, "type");
+            named[name.text] = make_material(ty && !ty->strs.empty() ? ty->strs[0] : "matte", ps);
+        } else if (d == "NamedMaterial") {
+            Token name = lx.next();
+            auto it = named.find(name.text);
+            if (it != named.end()) { gs.material = it->second; gs.has_material = true; }
+            else gs.has_material = false;
+        } else if (d == "Material") {
+            Token ty = lx.next();
+            if (!read_params(lx, &ps)) return fail(RL_ERR_PARSE, "Material: bad parameters");
+            gs.material = make_material(ty.text, ps);
+            gs.has_material = true;
+        } else if (d == "AreaLightSource") {
+            lx.next();
+            if (!read_params(lx, &ps)) return fail(RL_ERR_PARSE, "AreaLightSource: bad parameters");
+            const Param* L = find(ps, "L");
+            gs.has_emission = true;
+            for (int i = 0; i < 3; i++) gs.emission[i] = (L && L->nums.size() >= 3) ? (float)L->nums[i] : 1.0f;
+        } else if (d == "Shape") {
+            Token ty = lx.next();
+            if (!read_params(lx, &ps)) return fail(RL_ERR_PARSE, "Shape: bad parameters");
+            if (ty.text != "trianglemesh") return fail(RL_ERR_UNSUPPORTED, "Shape \"" + ty.text + "\" is not supported (trianglemesh only)");
+            const Param* P = find(ps, "P");
+            const Param* I = find(ps, "indices");
+            const Param* N = find(ps, "N");
+            const Param* UV = find(ps, "uv");
+            if (!UV) UV = find(ps, "st");
+            if (!P || !I || P->nums.size() % 3 || I->nums.size() % 3) return fail(RL_ERR_PARSE, "Shape trianglemesh: bad P / indices");
+            size_t nv = P->nums.size() / 3;
+            std::vector<float> pos(3 * nv), nrm, uv;
+            for (size_t i = 0; i < nv; i++) {   // mat.transform_point(p) (scene_loader.rs:118-121)
+                Vec3 p = gs.ctm.xform_point({(float)P->nums[3 * i], (float)P->nums[3 * i + 1], (float)P->nums[3 * i + 2]});
+                pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
+            }
+            if (N && use_shading_normals && N->nums.size() == 3 * nv) {
+                nrm.resize(3 * nv);
+                for (size_t i = 0; i < nv; i++) {   // mat.transform_vector(+-n) (scene_loader.rs:101-116)
+                    Vec3 n{(float)N->nums[3 * i], (float)N->nums[3 * i + 1], (float)N->nums[3 * i + 2]};
+                    if (gs.reverse_orientation) n = {-n.x, -n.y, -n.z};
+                    n = gs.ctm.xform_vector(n);
+                    nrm[3 * i] = n.x; nrm[3 * i + 1] = n.y; nrm[3 * i + 2] = n.z;
+                }
+            }
+            if (UV && UV->nums.size() == 2 * nv) { uv.resize(2 * nv); for (size_t i = 0; i < 2 * nv; i++) uv[i] = (float)UV->nums[i]; }
+            std::vector<uint32_t> idx(I->nums.size());
+            for (size_t i = 0; i < idx.size(); i++) idx[i] = (uint32_t)I->nums[i];
+            rl_bsdf_desc b = gs.has_material ? gs.material : default_material();
+            int rc = rl_scene_add_mesh(scene, pos.data(), nv, idx.data(), idx.size() / 3, nrm.empty() ? nullptr : nrm.data(),
+                                       uv.empty() ? nullptr : uv.data(), &b, gs.has_emission ? gs.emission : nullptr);
+            if (rc < 0) return fail(rc, "Shape trianglemesh: invalid mesh");
+        } else {
+            return fail(RL_ERR_UNSUPPORTED, "directive '" + d + "' is not supported");
+        }
+    }
+    if (!have_camera) return fail(RL_ERR_PARSE, "The camera is not set!");
+    Mat4 to_world;
+    if (!world_to_camera.inverse(&to_world)) return fail(RL_ERR_PARSE, "singular camera transform");
+    float cols[16];
+    to_world.to_cols(cols);
+    int rc = rl_scene_set_camera(scene, width, height, fov, 1 /* Fov::Y */, cols, 0 /* flip = false */);
+    if (rc != RL_OK) return fail(rc, "invalid camera");
+    *out = scene;
+    return RL_OK;
+}
+
+}  // namespace rl
+
+extern "C" int rl_scene_load_pbrt(const char* path, int use_shading_normals, rl_scene** out) {
+    if (!path || !out) return RL_ERR_INVALID_ARGUMENT;
+    std::string err;
+    int rc = rl::load_pbrt(path, use_shading_normals != 0, out, &err);
+    if (rc != RL_OK) rl_set_error(err);
+    return rc;
+}

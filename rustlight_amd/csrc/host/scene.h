@@ -1,0 +1,94 @@
+// scene.h — host-side flattened scene: the POD counterpart of rustlight's `Scene` / `Mesh` /
+// `Camera` / `EmitterSampler` / `HomogenousVolume` (src/scene.rs:16-30, src/geometry.rs:107-119,
+// src/camera.rs:5-15, src/emitter.rs:1491-1496, src/volume.rs:73-80).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../../include/rustlight_amd.h"
+#include "../device_types.h"
+#include "hostmath.h"
+
+namespace rl {
+
+struct HostMesh {
+    std::vector<Vec3> positions;
+    std::vector<uint32_t> indices;   // 3 per triangle
+    std::vector<Vec3> normals;       // empty if None
+    std::vector<float> uvs;          // 2 per vertex, empty if None
+    rl_bsdf_desc bsdf;
+    bool is_light = false;
+    float emission[3] = {0, 0, 0};
+    // Distribution1D over triangle areas (src/math.rs:398-445)
+    std::vector<float> cdf;
+    float func_int = 0.0f;
+    size_t n_tris() const { return indices.size() / 3; }
+    float area_total() const { return func_int * (float)(cdf.size() - 1); }   // Distribution1D::total
+};
+
+struct HostBitmap { uint32_t w, h; std::vector<float> rgb; };
+
+}  // namespace rl
+
+// The opaque handle of the C-ABI.
+struct rl_scene {
+    // camera
+    bool has_camera = false;
+    uint32_t width = 0, height = 0;
+    float fov_degrees = 0;
+    int fov_axis = 1;
+    bool flip = false;
+    rl::Mat4 to_world, sample_to_camera;
+    rl::Vec3 cam_pos{0, 0, 0};
+    // geometry
+    std::vector<rl::HostMesh> meshes;
+    std::vector<rl::HostBitmap> bitmaps;
+    // medium
+    rl::MediumRecord medium{};
+    // emitters (Scene::build_emitters)
+    bool emitters_built = false;
+    std::vector<int32_t> emitters;          // mesh ids in mesh order
+    std::vector<float> emitters_cdf;        // n + 1
+    float bsphere_center[3] = {0, 0, 0};
+    float bsphere_radius = 0;
+
+    bool rebuild_camera();   // Camera::new
+};
+
+namespace rl {
+
+// Distribution1DConstruct::normalize (src/math.rs:419-443)
+void build_cdf(const std::vector<float>& elements, std::vector<float>* cdf, float* func_int);
+
+// BVH build result in the GPU layout.
+struct BvhBuild {
+    std::vector<BvhNode> nodes;
+    std::vector<TriRecord> tris;
+    float root_min[3], root_max[3];
+    int32_t root = RL_CHILD_NONE;
+    uint32_t stack_depth = 1;
+    // the reference-shaped node list, kept for tests (node boxes / info / count, primitive refs)
+    std::vector<float> ref_boxes;       // 6 per node
+    std::vector<uint64_t> ref_info, ref_count;
+    std::vector<int32_t> ref_prim_mesh, ref_prim_tri;
+};
+// BVHAccel::new (src/accel.rs:115-239): full-sweep SAH over all triangles, leaves of <= 2.
+void build_bvh(const rl_scene& scene, BvhBuild* out);
+
+// Flattened shading arrays (global vertex / index / cdf / material tables).
+struct FlatScene {
+    std::vector<uint32_t> tri_indices;
+    std::vector<float> positions, normals, uvs;
+    std::vector<MeshRecord> meshes;
+    std::vector<Material> materials;
+    std::vector<BitmapDesc> bitmaps;
+    std::vector<float> bitmap_texels;
+    std::vector<float> mesh_cdf;
+    std::vector<uint32_t> mesh_tri_base;
+};
+void flatten_scene(const rl_scene& scene, FlatScene* out);
+
+int load_pbrt(const char* path, bool use_shading_normals, rl_scene** out, std::string* err);
+
+}  // namespace rl

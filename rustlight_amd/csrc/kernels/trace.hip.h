@@ -1,0 +1,153 @@
+// trace.hip.h — BVH2 traversal for gfx950: `Acceleration::{trace,visible}` of rustlight's BVHAccel
+// (src/accel.rs:243-343) restated as an iterative, stack-based, wave64-friendly loop.
+//
+//  * ordered traversal: both child boxes come with the parent's 64-byte record; the nearer child
+//    (by slab entry distance, ties keep the left child first) is entered first and the farther
+//    one is pushed with its entry distance, which is re-checked against the current closest hit
+//    when popped — exactly the order and the pruning rule of the reference's recursion;
+//  * the per-lane stack lives in LDS (layout [level][lane], conflict-free);
+//  * small scenes (nodes + triangles fit the LDS budget) are staged into LDS once per workgroup,
+//    so the inner loop never leaves the CU; otherwise records stream from L2/HBM as four
+//    16-byte loads per lane;
+//  * triangle test = Mesh::intersection_tri (src/geometry.rs:358-410) with the ray-independent
+//    terms (e1, e2, n_geo, det) precomputed in the TriRecord.
+#pragma once
+#include "../device_types.h"
+#include "devmath.hip.h"
+
+namespace rl {
+
+struct Hit { float t, u, v; int prim; };
+
+// AABB::intersect (src/structure.rs:849-869) with 1/d hoisted out of the loop
+RL_DEV bool slab(V3 lo, V3 hi, V3 o, V3 inv_d, float tnear, float tfar, float* t_entry) {
+    float t_min = tnear, t_max = tfar;
+    {
+        float t0 = (lo.x - o.x) * inv_d.x, t1 = (hi.x - o.x) * inv_d.x;
+        if (inv_d.x < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+        t_min = t0 > t_min ? t0 : t_min;
+        t_max = t1 < t_max ? t1 : t_max;
+        if (t_max <= t_min) return false;
+    }
+    {
+        float t0 = (lo.y - o.y) * inv_d.y, t1 = (hi.y - o.y) * inv_d.y;
+        if (inv_d.y < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+        t_min = t0 > t_min ? t0 : t_min;
+        t_max = t1 < t_max ? t1 : t_max;
+        if (t_max <= t_min) return false;
+    }
+    {
+        float t0 = (lo.z - o.z) * inv_d.z, t1 = (hi.z - o.z) * inv_d.z;
+        if (inv_d.z < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+        t_min = t0 > t_min ? t0 : t_min;
+        t_max = t1 < t_max ? t1 : t_max;
+        if (t_max <= t_min) return false;
+    }
+    *t_entry = t_min;
+    return true;
+}
+
+// Mesh::intersection_tri; returns true and updates `hit` if the triangle is the new closest hit
+RL_DEV bool tri_test(const float4 q0, const float4 q1, const float4 q2, const float4 q3, V3 o, V3 d, Hit& hit, int prim) {
+    V3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z);
+    V3 n = mk3(q0.w, q1.w, q2.w);
+    float det = q3.x;
+    float denom = dot(d, n);
+    if (denom == 0.0f) return false;
+    float t = div_rn(-dot(o - v0, n), denom);
+    if (t < 0.0f) return false;
+    V3 p = o + t * d;
+    V3 pv = p - v0;
+    V3 u0 = cross(e1, pv);
+    V3 w0 = cross(pv, e2);
+    if (dot(u0, n) < 0.0f || dot(w0, n) < 0.0f) return false;
+    float v = div_rn(length(u0), det);
+    float u = div_rn(length(w0), det);
+    if (u < 0.0f || v < 0.0f || u > 1.0f || v > 1.0f) return false;
+    if (u + v <= 1.0f) {
+        if (t < hit.t && t > 0.00001f) { hit.t = t; hit.u = u; hit.v = v; hit.prim = prim; return true; }
+    }
+    return false;
+}
+
+// Scene records either in LDS (staged) or in global memory.
+struct SceneRecs {
+    const float4* nodes;   // 4 float4 per BvhNode
+    const float4* tris;    // 4 float4 per TriRecord
+};
+
+// Traverse.  ANY_HIT: return as soon as one triangle is accepted (Acceleration::visible only asks
+// whether `intersect` found something; its.t starts at the segment length, accel.rs:316-343).
+// `stack` points at this lane's column of the LDS stack, entries are `stride` ints apart;
+// two ints per level: child code and the bits of its entry distance.
+template <bool ANY_HIT>
+RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3 o, V3 d, float tnear, float tfar,
+                     Hit& hit, int* stack, int stride) {
+    V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
+    float dummy;
+    if (!slab(root_lo, root_hi, o, inv_d, tnear, tfar, &dummy)) return false;   // accel.rs:293-295 / 338-340
+    if (root == RL_CHILD_NONE) return false;
+    int sp = 0;
+    int cur = root;
+    bool found = false;
+    for (;;) {
+        if (cur < 0) {
+            // leaf: test its (<= 2) triangles in order (accel.rs:245-254)
+            unsigned int code = (unsigned int)(~cur);
+            int first = (int)(code >> 2), count = (int)(code & 3u);
+            for (int k = 0; k < count; k++) {
+                const float4* q = recs.tris + 4 * (first + k);
+                if (tri_test(q[0], q[1], q[2], q[3], o, d, hit, first + k)) {
+                    found = true;
+                    if (ANY_HIT) return true;
+                }
+            }
+            // pop
+            for (;;) {
+                if (sp == 0) return found;
+                sp--;
+                int code2 = stack[(2 * sp) * stride];
+                float dist = __int_as_float(stack[(2 * sp + 1) * stride]);
+                if (dist < hit.t) { cur = code2; break; }
+            }
+            continue;
+        }
+        const float4* q = recs.nodes + 4 * cur;
+        float4 a = q[0], b = q[1], c = q[2], e = q[3];
+        V3 llo = mk3(a.x, a.y, a.z), lhi = mk3(a.w, b.x, b.y);
+        V3 rlo = mk3(b.z, b.w, c.x), rhi = mk3(c.y, c.z, c.w);
+        int id1 = __float_as_int(e.x), id2 = __float_as_int(e.y);
+        float d1, d2;
+        if (!slab(llo, lhi, o, inv_d, tnear, tfar, &d1)) d1 = f32_inf();
+        if (!slab(rlo, rhi, o, inv_d, tnear, tfar, &d2)) d2 = f32_inf();
+        if (d1 > d2) { float s = d1; d1 = d2; d2 = s; int si = id1; id1 = id2; id2 = si; }
+        if (d1 < hit.t) {
+            if (d2 < hit.t) {   // can only be pruned later by a closer hit; re-checked at pop time
+                stack[(2 * sp) * stride] = id2;
+                stack[(2 * sp + 1) * stride] = __float_as_int(d2);
+                sp++;
+            }
+            cur = id1;
+            continue;
+        }
+        // neither child qualifies: pop
+        for (;;) {
+            if (sp == 0) return found;
+            sp--;
+            int code2 = stack[(2 * sp) * stride];
+            float dist = __int_as_float(stack[(2 * sp + 1) * stride]);
+            if (dist < hit.t) { cur = code2; break; }
+        }
+    }
+}
+
+// Stage the node / triangle records into LDS (cooperatively, 16 bytes per lane per step).
+RL_DEV void stage_scene_lds(const DeviceScene& sc, float4* lds_nodes, float4* lds_tris) {
+    const float4* gn = reinterpret_cast<const float4*>(sc.nodes);
+    const float4* gt = reinterpret_cast<const float4*>(sc.tris);
+    for (unsigned int i = threadIdx.x; i < 4u * sc.n_nodes; i += blockDim.x) lds_nodes[i] = gn[i];
+    for (unsigned int i = threadIdx.x; i < 4u * sc.n_prims; i += blockDim.x) lds_tris[i] = gt[i];
+    __syncthreads();
+}
+
+}  // namespace rl

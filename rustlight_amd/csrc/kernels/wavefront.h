@@ -1,0 +1,20 @@
+// wavefront.h — test/debug hooks exported next to the public C-ABI (not part of the drop-in surface).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+
+struct rl_context;
+struct rl_scene;
+void rl_set_error(const std::string& s);
+
+extern "C" {
+// runs div/sqrt/mul-add and the deterministic transcendentals on the device: out8 = 8 arrays of n
+int rl_debug_numerics(int device, size_t n, const float* a, const float* b, float* out8);
+int rl_debug_bvh_sizes(const rl_context* ctx, uint64_t* n_ref_nodes, uint64_t* n_prims, uint32_t* stack_depth, int* lds_scene);
+// host-only: builds the BVH of `scene` and returns it in the reference's node shape (no GPU needed)
+int rl_debug_bvh(const rl_scene* scene, uint64_t* n_nodes, uint64_t* n_prims, float* boxes, uint64_t* info, uint64_t* count,
+                 int32_t* prim_mesh, int32_t* prim_tri);
+// host-only: Camera::generate for one pixel position
+int rl_debug_camera_ray(const rl_scene* scene, float px, float py, float* origin, float* direction);
+}

@@ -1,0 +1,1010 @@
+// wavefront.hip — the gfx950 wavefront path tracer behind `IntegratorPathTracing::compute`
+// (src/integrators/explicit/path.rs:186-238 -> compute_mc, src/integrators/mod.rs:403-450).
+//
+// One path "slot" per GPU lane; all per-path state lives in HBM as structure-of-arrays so that
+// lane i of every kernel touches element i of every array (fully coalesced, 4/8-byte words).
+// A slot owns one work item — a pixel (throughput stream mode) or a whole 16x16 block
+// (reference-order stream mode) — and regenerates a fresh camera sample in place when its path
+// ends, so every slot carries exactly one extension ray per iteration until its item is done.
+//
+// Per iteration (one HIP launch each, same stream):
+//   k_raygen   persistent threads: finished samples are folded into the pixel accumulator in
+//              sample order, the next (pixel, sample) is seeded and its camera ray generated
+//              (Path::from_sensor + Camera::generate; paths/path.rs:56-73, camera.rs:81-91)
+//   k_extend   BVH2 closest-hit traversal (Acceleration::trace; accel.rs:292-315)
+//   k_shade<M> per-BSDF kernels: medium distance sampling, fill_intersection, emission + MIS of
+//              the arriving edge, BSDF / phase sampling, Russian roulette, NEE light sampling with
+//              its MIS weight (strategies/directional.rs, strategies/emitters.rs, path.rs:37-111)
+//   k_shadow   any-hit traversal for the NEE shadow rays (Acceleration::visible; accel.rs:316-343),
+//              adds the pre-weighted contribution to the path's radiance
+// plus k_sort (stream compaction / material binning with wave64 ballot + prefix) when the scene
+// mixes BSDF types.  Radiance is accumulated front-to-back (DESIGN.md §Radiance order).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/rustlight_amd.h"
+#include "../device_types.h"
+#include "../host/scene.h"
+#include "devmath.hip.h"
+#include "shading.hip.h"
+#include "trace.hip.h"
+#include "wavefront.h"
+
+namespace rl {
+
+// ------------------------------------------------------------------------------------------
+// path-state pool (SoA): field f of slot i is at base[f * P + i]
+enum FField {
+    F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ,         // extension ray (origin doubles as the NEE origin)
+    F_T, F_U, F_V,                               // hit record (with U_PRIM)
+    F_BR, F_BG, F_BB,                            // beta: throughput of evaluate()'s edge products
+    F_TR, F_TG, F_TB,                            // thr: generate()'s Russian-roulette throughput
+    F_LR, F_LG, F_LB,                            // radiance of the current sample
+    F_AR, F_AG, F_AB,                            // pixel accumulator (sum over samples, in sample order)
+    F_WR, F_WG, F_WB,                            // weight of the edge being traced (BSDF / phase weight)
+    F_RR, F_PDF,                                 // its rr_weight and directional pdf
+    F_SX, F_SY, F_SZ,                            // NEE target point on the light
+    F_CR, F_CG, F_CB,                            // NEE contribution, already times beta and MIS weight
+    F_XI,                                        // medium distance-sampling random number of the edge
+    F_COUNT
+};
+enum UField { U_FLAGS, U_DEPTH, U_PRIM, U_ITEM, U_CURSOR, U_SAMPLE, U_COUNT };
+enum QField { Q_R0, Q_R1, Q_R2, Q_R3, Q_I0, Q_I1, Q_I2, Q_I3, Q_COUNT };
+
+enum : unsigned {
+    ST_FINISHED = 1u,      // slot has no work left
+    ST_REGEN = 2u,         // sample ended: raygen must fold it and start the next one
+    ST_FRESH = 4u,         // no sample has run in this slot yet
+    ST_RAY = 8u,           // extension ray valid
+    ST_SHADOW = 16u,       // NEE shadow ray valid
+    ST_PREV_SHIFT = 5u,    // 2 bits: kind of the vertex the traced edge leaves
+    ST_PDF_SA = 128u,      // edge pdf is PDF::SolidAngle (else Discrete)
+    ST_ZEROED = 256u,      // single_scattering: a surface vertex has been passed (path.rs:122-124)
+};
+enum : unsigned { PREV_SENSOR = 0u, PREV_SURFACE = 1u, PREV_SURFACE_SMOOTH = 2u, PREV_VOLUME = 3u };
+
+static constexpr unsigned kDepthCap = 2048u;   // same cut as the oracle (NaN-throughput paths never die)
+
+struct Pool {
+    float* f;
+    unsigned* u;
+    unsigned long long* q;
+    unsigned P;
+};
+
+struct Counters {
+    unsigned long long camera_samples, vertices, extension_rays, shadow_rays, rng_draws;
+    unsigned int active;        // slots that still own work
+    unsigned int next_item;     // work-item dispenser
+    unsigned int pad[2];
+};
+
+struct RenderConst {
+    // IntegratorPathTracing fields (explicit/path.rs:14-20)
+    unsigned spp;
+    int has_min, has_max, has_rr;
+    unsigned min_depth, max_depth, rr_depth;
+    int strategy, single_scattering;
+    int stream_mode, seed_variant;
+    float inv_spp;
+    // image / work decomposition
+    unsigned W, H, nby;
+    unsigned n_items;
+    const unsigned* owned_blocks;       // block ids of this shard, in creation order
+    const unsigned* block_item_base;    // per owned block: first pixel item (per-sample mode)
+    unsigned n_owned;
+    const unsigned long long* block_seeds;   // one per block of the whole image
+    unsigned long long* item_seed;      // per pixel item (per-sample mode)
+    unsigned* item_pixel;               // per pixel item: y * W + x
+    float* out;                         // W*H*3 framebuffer
+    Counters* counters;
+};
+
+#define PF(field) pool.f[(size_t)(field) * pool.P + slot]
+#define PU(field) pool.u[(size_t)(field) * pool.P + slot]
+#define PQ(field) pool.q[(size_t)(field) * pool.P + slot]
+
+RL_DEV V3 load3(const Pool& pool, unsigned slot, int f0) { return mk3(PF(f0), PF(f0 + 1), PF(f0 + 2)); }
+RL_DEV Col loadc(const Pool& pool, unsigned slot, int f0) { return mkc(PF(f0), PF(f0 + 1), PF(f0 + 2)); }
+RL_DEV void store3(const Pool& pool, unsigned slot, int f0, V3 v) { PF(f0) = v.x; PF(f0 + 1) = v.y; PF(f0 + 2) = v.z; }
+RL_DEV void storec(const Pool& pool, unsigned slot, int f0, Col c) { PF(f0) = c.r; PF(f0 + 1) = c.g; PF(f0 + 2) = c.b; }
+RL_DEV Rng load_rng(const Pool& pool, unsigned slot, int q0) { Rng r; r.s0 = PQ(q0); r.s1 = PQ(q0 + 1); r.s2 = PQ(q0 + 2); r.s3 = PQ(q0 + 3); return r; }
+RL_DEV void store_rng(const Pool& pool, unsigned slot, int q0, const Rng& r) { PQ(q0) = r.s0; PQ(q0 + 1) = r.s1; PQ(q0 + 2) = r.s2; PQ(q0 + 3) = r.s3; }
+
+// wave64 sum; lane 0 of each wave publishes with one atomic
+RL_DEV void wave_add(unsigned long long* dst, unsigned v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63u) == 0u && v) atomicAdd(dst, (unsigned long long)v);
+}
+
+RL_DEV void block_geometry(const RenderConst& rc, unsigned b, unsigned* bx, unsigned* by, unsigned* bw, unsigned* bh) {
+    *bx = (b / rc.nby) * 16u;            // block index b = (ix/16) * ceil(H/16) + iy/16 (mod.rs:357-358)
+    *by = (b % rc.nby) * 16u;
+    *bw = min(16u, rc.W - *bx);
+    *bh = min(16u, rc.H - *by);
+}
+
+// ------------------------------------------------------------------------------------------
+// per-sample stream mode: fork the block sampler once per pixel in the block's (iy, ix) loop order
+// with the reference's own clone_box rule (samplers/independent.rs:18-22)
+__global__ void k_seed_pixels(RenderConst rc) {
+    unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= rc.n_owned) return;
+    unsigned b = rc.owned_blocks[j];
+    unsigned bx, by, bw, bh;
+    block_geometry(rc, b, &bx, &by, &bw, &bh);
+    Rng rng = rng_seed(rc.block_seeds[b], rc.seed_variant);
+    unsigned base = rc.block_item_base[j];
+    for (unsigned iy = 0; iy < bh; iy++)
+        for (unsigned ix = 0; ix < bw; ix++) {
+            unsigned k = base + iy * bw + ix;
+            rc.item_seed[k] = rng_next_u64(rng);
+            rc.item_pixel[k] = (by + iy) * rc.W + (bx + ix);
+        }
+}
+
+__global__ void k_init(RenderConst rc, Pool pool) {
+    unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= pool.P) return;
+    PU(U_ITEM) = slot;
+    PU(U_CURSOR) = 0u;
+    PU(U_SAMPLE) = 0u;
+    PU(U_DEPTH) = 0u;
+    PU(U_PRIM) = 0xffffffffu;
+    PU(U_FLAGS) = slot < rc.n_items ? (ST_REGEN | ST_FRESH) : ST_FINISHED;
+    storec(pool, slot, F_AR, czero());
+    storec(pool, slot, F_LR, czero());
+}
+
+// ------------------------------------------------------------------------------------------
+// k_raygen — persistent threads (grid-stride): sample completion, work-item hand-out, seeding,
+// Path::from_sensor (2 draws) and Camera::generate.
+__global__ void __launch_bounds__(256) k_raygen(RenderConst rc, DeviceScene sc, Pool pool) {
+    unsigned n_samples = 0, n_draws = 0;
+    for (unsigned slot = blockIdx.x * blockDim.x + threadIdx.x; slot < pool.P; slot += gridDim.x * blockDim.x) {
+        unsigned flags = PU(U_FLAGS);
+        if (!(flags & ST_REGEN)) continue;
+        const bool fresh = (flags & ST_FRESH) != 0u;
+        unsigned item = PU(U_ITEM), s = PU(U_SAMPLE), cursor = PU(U_CURSOR);
+        Col acc = loadc(pool, slot, F_AR);
+        bool need_item = fresh;
+        unsigned bx = 0, by = 0, bw = 1, bh = 1;
+        if (rc.stream_mode == RL_STREAM_REFERENCE_ORDER && item < rc.n_items) block_geometry(rc, rc.owned_blocks[item], &bx, &by, &bw, &bh);
+        if (!fresh) {
+            // im_block.accumulate(.., c, "primal") in sample order (mod.rs:431)
+            acc = acc + loadc(pool, slot, F_LR);
+            s++;
+            if (s == rc.spp) {
+                unsigned pix = rc.stream_mode == RL_STREAM_PER_SAMPLE ? rc.item_pixel[item] : (by + cursor / bw) * rc.W + (bx + cursor % bw);
+                Col px = scale_unguarded(acc, rc.inv_spp);            // im_block.scale(1 / spp) (mod.rs:436)
+                rc.out[3 * (size_t)pix] = px.r; rc.out[3 * (size_t)pix + 1] = px.g; rc.out[3 * (size_t)pix + 2] = px.b;
+                acc = czero();
+                s = 0;
+                if (rc.stream_mode == RL_STREAM_PER_SAMPLE) need_item = true;
+                else { cursor++; if (cursor == bw * bh) need_item = true; }
+            }
+        }
+        Rng rng;
+        if (need_item) {
+            if (!fresh) item = atomicAdd(&rc.counters->next_item, 1u);
+            if (item >= rc.n_items) {
+                PU(U_FLAGS) = ST_FINISHED;
+                atomicSub(&rc.counters->active, 1u);
+                continue;
+            }
+            cursor = 0;
+            if (rc.stream_mode == RL_STREAM_PER_SAMPLE) {
+                Rng item_rng = rng_seed(rc.item_seed[item], rc.seed_variant);   // pixel sampler = block_sampler.clone_box()
+                rng = rng_seed(rng_next_u64(item_rng), rc.seed_variant);        // sample sampler = pixel_sampler.clone_box()
+                store_rng(pool, slot, Q_I0, item_rng);
+            } else {
+                unsigned b = rc.owned_blocks[item];
+                block_geometry(rc, b, &bx, &by, &bw, &bh);
+                rng = rng_seed(rc.block_seeds[b], rc.seed_variant);            // the block's own sampler (mod.rs:371)
+            }
+            PU(U_ITEM) = item;
+        } else if (rc.stream_mode == RL_STREAM_PER_SAMPLE) {
+            Rng item_rng = load_rng(pool, slot, Q_I0);
+            rng = rng_seed(rng_next_u64(item_rng), rc.seed_variant);
+            store_rng(pool, slot, Q_I0, item_rng);
+        } else {
+            rng = load_rng(pool, slot, Q_R0);
+        }
+        unsigned px, py;
+        if (rc.stream_mode == RL_STREAM_PER_SAMPLE) { unsigned pix = rc.item_pixel[item]; px = pix % rc.W; py = pix / rc.W; }
+        else { px = bx + cursor % bw; py = by + cursor / bw; }
+        // Path::from_sensor: uv = (ix + next(), iy + next())
+        float u = (float)px + rng_next_f32(rng);
+        float v = (float)py + rng_next_f32(rng);
+        n_draws += 2;
+        n_samples++;
+        storec(pool, slot, F_AR, acc);
+        storec(pool, slot, F_LR, czero());
+        PU(U_SAMPLE) = s;
+        PU(U_CURSOR) = cursor;
+        const bool expand = (!rc.has_max || 1u < rc.max_depth);   // TechniquePathTracing::expand at depth 1
+        if (!expand) {   // sensor not expanded: the sample is 0 (next raygen pass folds it)
+            store_rng(pool, slot, Q_R0, rng);
+            PU(U_FLAGS) = ST_REGEN;
+            continue;
+        }
+        // Camera::generate (camera.rs:81-91)
+        const float* m = sc.camera.sample_to_camera;
+        float sx = div_rn(u, (float)sc.camera.width), sy = div_rn(v, (float)sc.camera.height), sz = 0.0f;
+        float hx = ((m[0] * sx + m[4] * sy) + m[8] * sz) + m[12] * 1.0f;
+        float hy = ((m[1] * sx + m[5] * sy) + m[9] * sz) + m[13] * 1.0f;
+        float hz = ((m[2] * sx + m[6] * sy) + m[10] * sz) + m[14] * 1.0f;
+        float hw = ((m[3] * sx + m[7] * sy) + m[11] * sz) + m[15] * 1.0f;
+        float inv_w = div_rn(1.0f, hw);
+        V3 near_p = mk3(hx * inv_w, hy * inv_w, hz * inv_w);
+        V3 dl = normalize(near_p);
+        const float* tw = sc.camera.to_world;
+        V3 d = mk3(((tw[0] * dl.x + tw[4] * dl.y) + tw[8] * dl.z) + tw[12] * 0.0f,
+                   ((tw[1] * dl.x + tw[5] * dl.y) + tw[9] * dl.z) + tw[13] * 0.0f,
+                   ((tw[2] * dl.x + tw[6] * dl.y) + tw[10] * dl.z) + tw[14] * 0.0f);
+        V3 o = mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]);
+        store3(pool, slot, F_OX, o);
+        store3(pool, slot, F_DX, d);
+        storec(pool, slot, F_BR, cone());
+        storec(pool, slot, F_TR, cone());
+        storec(pool, slot, F_WR, cone());     // sensor edge: weight 1, rr 1, PDF::SolidAngle(1)
+        PF(F_RR) = 1.0f;
+        PF(F_PDF) = 1.0f;
+        if (sc.medium.enabled) { PF(F_XI) = rng_next_f32(rng); n_draws++; }   // Edge::from_ray's medium.sample(ray, next())
+        store_rng(pool, slot, Q_R0, rng);
+        PU(U_DEPTH) = 1u;
+        PU(U_FLAGS) = ST_RAY | (PREV_SENSOR << ST_PREV_SHIFT) | ST_PDF_SA;
+    }
+    wave_add(&rc.counters->camera_samples, n_samples);
+    wave_add(&rc.counters->rng_draws, n_draws);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_extend / k_shadow — traversal kernels.  Dynamic LDS = [staged scene] + per-lane stack.
+template <bool LDS_SCENE>
+__global__ void __launch_bounds__(256) k_extend(RenderConst rc, DeviceScene sc, Pool pool) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    SceneRecs recs;
+    float4* stack_base = smem;
+    if (LDS_SCENE) {
+        stage_scene_lds(sc, smem, smem + 4 * sc.n_nodes);
+        recs.nodes = smem; recs.tris = smem + 4 * sc.n_nodes;
+        stack_base = smem + 4 * (sc.n_nodes + sc.n_prims);
+    } else {
+        recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
+        recs.tris = reinterpret_cast<const float4*>(sc.tris);
+    }
+    int* stack = reinterpret_cast<int*>(stack_base) + threadIdx.x;
+    unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned n = 0;
+    if (slot < pool.P && (PU(U_FLAGS) & ST_RAY)) {
+        V3 o = load3(pool, slot, F_OX), d = load3(pool, slot, F_DX);
+        Hit hit; hit.t = kF32Max; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
+        traverse<false>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
+                        o, d, kEps, kF32Max, hit, stack, (int)blockDim.x);
+        PF(F_T) = hit.t; PF(F_U) = hit.u; PF(F_V) = hit.v;
+        PU(U_PRIM) = (unsigned)hit.prim;
+        n = 1;
+    }
+    wave_add(&rc.counters->extension_rays, n);
+}
+
+template <bool LDS_SCENE>
+__global__ void __launch_bounds__(256) k_shadow(RenderConst rc, DeviceScene sc, Pool pool) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    SceneRecs recs;
+    float4* stack_base = smem;
+    if (LDS_SCENE) {
+        stage_scene_lds(sc, smem, smem + 4 * sc.n_nodes);
+        recs.nodes = smem; recs.tris = smem + 4 * sc.n_nodes;
+        stack_base = smem + 4 * (sc.n_nodes + sc.n_prims);
+    } else {
+        recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
+        recs.tris = reinterpret_cast<const float4*>(sc.tris);
+    }
+    int* stack = reinterpret_cast<int*>(stack_base) + threadIdx.x;
+    unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot < pool.P && (PU(U_FLAGS) & ST_SHADOW)) {
+        // Acceleration::visible(p0, p1) (accel.rs:316-343)
+        V3 p0 = load3(pool, slot, F_OX), p1 = load3(pool, slot, F_SX);
+        V3 d = p1 - p0;
+        float len = length(d);
+        d = d / len;
+        float tfar = len * (1.0f - 0.00001f);
+        Hit hit; hit.t = tfar; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
+        V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
+        float te;
+        bool vis;
+        if (!slab(mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]), p0, inv_d, kEps, tfar, &te))
+            vis = false;   // root box missed => "occluded" (accel.rs:338-340)
+        else
+            vis = !traverse<true>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
+                                  p0, d, kEps, tfar, hit, stack, (int)blockDim.x);
+        if (vis) storec(pool, slot, F_LR, loadc(pool, slot, F_LR) + loadc(pool, slot, F_CR));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_shade<MAT, MEDIUM> — one path vertex.  MAT >= 0: only slots whose hit material has that BSDF
+// type are processed, through `queue` (filled by k_sort) or directly when the scene has a single
+// BSDF type; MAT = -1: generic (run-time switch).  MEDIUM selects the volume code.
+template <int MAT, bool MEDIUM>
+__global__ void __launch_bounds__(256) k_shade(RenderConst rc, DeviceScene sc, Pool pool, const unsigned* queue, const unsigned* queue_count) {
+    unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned n_vertices = 0, n_draws = 0, n_shadow = 0;
+    bool live = false;
+    unsigned slot = idx;
+    if (queue) { if (idx < *queue_count) { slot = queue[idx]; live = true; } }
+    else if (idx < pool.P) live = true;
+    unsigned flags = 0;
+    if (live) { flags = PU(U_FLAGS); live = (flags & ST_RAY) != 0u; }
+    if (live) {
+        const unsigned prev = (flags >> ST_PREV_SHIFT) & 3u;
+        const unsigned depth = PU(U_DEPTH);          // generate()'s depth at which the edge's origin vertex was expanded
+        const int prim = (int)PU(U_PRIM);
+        const V3 ro = load3(pool, slot, F_OX), rd = load3(pool, slot, F_DX);
+        const float t_hit = PF(F_T);
+        Col w_edge = loadc(pool, slot, F_WR);
+        const float rr = PF(F_RR);
+        const float pdf_edge = PF(F_PDF);
+        Col beta = loadc(pool, slot, F_BR);
+        Col L = loadc(pool, slot, F_LR);
+        bool zeroed = (flags & ST_ZEROED) != 0u;
+        const bool hit = prim >= 0;
+        bool is_volume = false;
+        V3 vpos = mk3(0.0f, 0.0f, 0.0f);
+        if (MEDIUM) {
+            // Edge::from_ray (paths/edge.rs:93-162): distance sampling up to the surface (or infinity on a miss)
+            MediumSample ms = medium_sample(sc.medium, hit ? t_hit : kF32Max, PF(F_XI));
+            w_edge = w_edge * ms.w;
+            is_volume = !hit || !ms.exited;
+            if (is_volume) vpos = ro + rd * ms.t;
+        }
+        bool ended = false;
+        if (!MEDIUM && !hit) ended = true;           // edge without a next vertex; environment luminance is 0
+        unsigned new_flags = ST_REGEN;
+        if (!ended) {
+            const Col W = w_edge * rr;                // edge.weight * edge.rr_weight (Color * f32, guarded)
+            SurfacePoint sp;
+            const Material* mat = nullptr;
+            MeshRecord mr;
+            if (!is_volume) {
+                sp = fill_intersection(sc, prim, PF(F_U), PF(F_V), ro, rd, t_hit);
+                mr = sc.meshes[sp.mesh];
+                mat = &sc.materials[mr.material];
+            }
+            // ---- contribution carried by the arriving edge (Edge::contribution -> Vertex::contribution)
+            Col emit = czero();
+            if (!is_volume && (mr.flags & MESH_IS_LIGHT) && dot(sp.n_s, -rd) >= 0.0f) emit = mkc(mr.emission[0], mr.emission[1], mr.emission[2]);
+            Col contrib = W * emit;
+            const unsigned cur = depth - 1u;          // evaluate()'s curr_depth of the origin vertex
+            const bool add_contrib = rc.has_min ? cur >= rc.min_depth : true;
+            if (prev == PREV_SENSOR) {
+                if (!is_zero(contrib) && add_contrib) L = L + contrib;              // path.rs:152-166 (no MIS)
+            } else if (!zeroed) {
+                if (rc.strategy == RL_STRATEGY_EMITTER) contrib = czero();          // id_sampling 0 != 1
+                if (!is_zero(contrib) && add_contrib) {
+                    float wmis = 1.0f;
+                    if (rc.strategy == RL_STRATEGY_ALL && (flags & ST_PDF_SA)) {
+                        // LightSamplingStrategy::pdf -> pdf_emitter (strategies/emitters.rs:10-92,250-282)
+                        float p2 = 0.0f;
+                        if (!is_volume && (mr.flags & MESH_IS_LIGHT) && (prev == PREV_SURFACE || prev == PREV_VOLUME))
+                            p2 = light_direct_pdf(mr, ro, sp.p, sp.n_g, rd);
+                        float total = (0.0f + pdf_edge) + p2;
+                        wmis = div_rn(pdf_edge, total);                             // balance heuristic (path.rs:80-98)
+                    }
+                    L = L + beta * (contrib * wmis);
+                }
+            }
+            beta = beta * W;
+            if (rc.single_scattering && !is_volume) zeroed = true;                  // evaluate(): surface vertex => subtree is 0
+
+            // ---- expand the new vertex (generate(), strategies/mod.rs:35-80)
+            const unsigned gen = depth + 1u;
+            const bool expand = (rc.has_max ? gen < rc.max_depth : true) && gen < kDepthCap;
+            if (expand) {
+                n_vertices = 1;
+                Rng rng = load_rng(pool, slot, Q_R0);
+                Col thr = loadc(pool, slot, F_TR);
+                const V3 vp = is_volume ? vpos : sp.p;
+                const V3 d_in = -rd;
+                // strategy 0: DirectionalSamplingStrategy::bounce (strategies/directional.rs:44-153)
+                V2 s2; s2.x = rng_next_f32(rng); s2.y = rng_next_f32(rng);
+                n_draws += 2;
+                bool has_edge = false;
+                bool sampled = false;
+                Col sw = czero(); V3 sd_world = mk3(0.0f, 0.0f, 0.0f); float spdf = 0.0f; int spdf_kind = PDF_SOLID_ANGLE;
+                if (is_volume) {
+                    phase_sample(sc.medium, d_in, s2, &sd_world, &sw, &spdf);
+                    sampled = true;
+                } else {
+                    BsdfSample bs;
+                    if (bsdf_sample<MAT>(sc, *mat, sp.has_uv, sp.uv, sp.wi, s2, &bs)) {
+                        sampled = true;
+                        sw = bs.weight; spdf = bs.pdf; spdf_kind = bs.pdf_kind;
+                        sd_world = to_world(sp.frame, bs.d);
+                    }
+                }
+                float rr_new = 1.0f;
+                if (sampled) {
+                    thr = thr * sw;
+                    if (!is_zero(thr)) {
+                        const bool do_rr = rc.has_rr ? rc.rr_depth <= gen : true;
+                        bool alive = true;
+                        if (do_rr) {
+                            float q = rmin(channel_max(thr), 0.95f);
+                            float x = rng_next_f32(rng);
+                            n_draws++;
+                            if (q < x) alive = false; else rr_new = div_rn(1.0f, q);
+                        }
+                        if (alive) {
+                            thr = scale_unguarded(thr, rr_new);
+                            has_edge = true;
+                            if (MEDIUM) { PF(F_XI) = rng_next_f32(rng); n_draws++; }   // the new edge's medium.sample draw
+                        }
+                    }
+                }
+                // strategy 1: LightSamplingStrategy::sample (strategies/emitters.rs:95-248)
+                const bool use_light = rc.strategy != RL_STRATEGY_BSDF;
+                const bool smooth = !is_volume && mat->smooth;
+                bool shadow = false;
+                if (use_light && !smooth) {
+                    float a = rng_next_f32(rng);
+                    float b = rng_next_f32(rng);
+                    V2 c; c.x = rng_next_f32(rng); c.y = rng_next_f32(rng);
+                    n_draws += 4;
+                    n_shadow = 1;     // the reference always traces the shadow ray (emitters.rs:125-126)
+                    LightSample ls = sample_light(sc, vp, a, b, c);
+                    if (ls.pdf != 0.0f) {
+                        Col wl;
+                        float p_dir;
+                        if (is_volume) { wl = phase_eval(sc.medium, d_in, ls.d); p_dir = phase_pdf(sc.medium, d_in, ls.d); }
+                        else {
+                            V3 wo = to_local(sp.frame, ls.d);
+                            wl = bsdf_eval<MAT>(sc, *mat, sp.has_uv, sp.uv, sp.wi, wo, false);
+                            p_dir = bsdf_pdf<MAT>(sc, *mat, sp.has_uv, sp.uv, sp.wi, wo, false);
+                        }
+                        if (MEDIUM) {
+                            V3 dd = ls.p - vp;
+                            wl = wl * medium_transmittance(sc.medium, dot(dd, ls.d));
+                        }
+                        Col c_l = ls.weight * wl * 1.0f;                       // contrib * weight * rr_weight (edge.rs:204)
+                        const bool add_l = rc.has_min ? (gen - 1u) >= rc.min_depth : true;
+                        if (!zeroed && !is_zero(c_l) && add_l) {
+                            float wmis = 1.0f;
+                            if (rc.strategy == RL_STRATEGY_ALL) {              // ls.pdf is a solid-angle pdf for mesh lights
+                                float total = (0.0f + p_dir) + ls.pdf;
+                                wmis = div_rn(ls.pdf, total);
+                            }
+                            Col pending = beta * (c_l * wmis);
+                            // a zero contribution needs no visibility test: the image cannot change
+                            if (!is_zero(pending)) {
+                                shadow = true;
+                                store3(pool, slot, F_SX, ls.p);
+                                storec(pool, slot, F_CR, pending);
+                            }
+                        }
+                    }
+                }
+                store_rng(pool, slot, Q_R0, rng);
+                store3(pool, slot, F_OX, vp);
+                new_flags = shadow ? ST_SHADOW : 0u;
+                if (has_edge) {
+                    store3(pool, slot, F_DX, sd_world);
+                    storec(pool, slot, F_TR, thr);
+                    storec(pool, slot, F_WR, sw);
+                    PF(F_RR) = rr_new;
+                    PF(F_PDF) = spdf;
+                    PU(U_DEPTH) = gen;
+                    const unsigned kind = is_volume ? PREV_VOLUME : (smooth ? PREV_SURFACE_SMOOTH : PREV_SURFACE);
+                    new_flags |= ST_RAY | (kind << ST_PREV_SHIFT) | (spdf_kind == PDF_SOLID_ANGLE ? ST_PDF_SA : 0u) | (zeroed ? ST_ZEROED : 0u);
+                } else new_flags |= ST_REGEN;
+            }
+            storec(pool, slot, F_BR, beta);
+            storec(pool, slot, F_LR, L);
+        }
+        PU(U_FLAGS) = new_flags;
+    }
+    wave_add(&rc.counters->vertices, n_vertices);
+    wave_add(&rc.counters->rng_draws, n_draws);
+    wave_add(&rc.counters->shadow_rays, n_shadow);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sort — stream compaction + material binning after k_extend: every live slot is appended to the
+// queue of its hit material's BSDF type (misses and volume-only slots go to queue 0).  One
+// atomic per wave per bin: wave64 ballot + mbcnt prefix.
+static constexpr int kNumBins = 5;
+__global__ void __launch_bounds__(256) k_sort(DeviceScene sc, Pool pool, unsigned* queues, unsigned* counts) {
+    unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+    int bin = -1;
+    if (slot < pool.P && (PU(U_FLAGS) & ST_RAY)) {
+        int prim = (int)PU(U_PRIM);
+        bin = 0;
+        if (prim >= 0) {
+            int mesh_id = sc.tris[prim].mesh;
+            bin = sc.materials[sc.meshes[mesh_id].material].type;
+        }
+    }
+    for (int b = 0; b < kNumBins; b++) {
+        unsigned long long mask = __ballot(bin == b);
+        if (mask == 0ull) continue;
+        unsigned lane = threadIdx.x & 63u;
+        unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
+        unsigned base = 0;
+        int leader = __ffsll((long long)mask) - 1;
+        if ((int)lane == leader) base = atomicAdd(&counts[b], (unsigned)__popcll(mask));
+        base = __shfl(base, leader, 64);
+        if (bin == b) queues[(size_t)b * pool.P + base + rank] = slot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// operator-level kernels: batched Acceleration::trace / visible for the parity tests
+__global__ void __launch_bounds__(256) k_trace_batch(DeviceScene sc, unsigned n, const float* o, const float* d, float* t_out, float* u_out,
+                                                     float* v_out, int* mesh_out, int* tri_out) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    SceneRecs recs;
+    recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
+    recs.tris = reinterpret_cast<const float4*>(sc.tris);
+    int* stack = reinterpret_cast<int*>(smem) + threadIdx.x;
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    Hit hit; hit.t = kF32Max; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
+    traverse<false>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
+                    ro, rd, kEps, kF32Max, hit, stack, (int)blockDim.x);
+    t_out[i] = hit.t; u_out[i] = hit.u; v_out[i] = hit.v;
+    if (hit.prim >= 0) { mesh_out[i] = sc.tris[hit.prim].mesh; tri_out[i] = sc.tris[hit.prim].tri; }
+    else { mesh_out[i] = -1; tri_out[i] = -1; }
+}
+
+__global__ void __launch_bounds__(256) k_visible_batch(DeviceScene sc, unsigned n, const float* p0a, const float* p1a, unsigned char* out) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    SceneRecs recs;
+    recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
+    recs.tris = reinterpret_cast<const float4*>(sc.tris);
+    int* stack = reinterpret_cast<int*>(smem) + threadIdx.x;
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 p0 = mk3(p0a[3 * i], p0a[3 * i + 1], p0a[3 * i + 2]), p1 = mk3(p1a[3 * i], p1a[3 * i + 1], p1a[3 * i + 2]);
+    V3 d = p1 - p0;
+    float len = length(d);
+    d = d / len;
+    float tfar = len * (1.0f - 0.00001f);
+    Hit hit; hit.t = tfar; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
+    bool occluded = traverse<true>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
+                                   p0, d, kEps, tfar, hit, stack, (int)blockDim.x);
+    V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
+    float te;
+    bool root_hit = slab(mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]), p0, inv_d, kEps, tfar, &te);
+    out[i] = (root_hit && !occluded) ? 1 : 0;
+}
+
+// device self-test of the numerics contract: IEEE divide / sqrt, denormals, no contraction
+__global__ void k_numerics_probe(unsigned n, const float* a, const float* b, float* out_div, float* out_sqrt, float* out_mad, float* out_sin,
+                                 float* out_cos, float* out_exp, float* out_log, float* out_pow) {
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out_div[i] = div_rn(a[i], b[i]);
+    out_sqrt[i] = sqrt_rn(fabsf(a[i]));
+    out_mad[i] = a[i] * b[i] + a[i];
+    out_sin[i] = dm::sinf_det(a[i]);
+    out_cos[i] = dm::cosf_det(a[i]);
+    out_exp[i] = dm::expf_det(a[i]);
+    out_log[i] = dm::logf_det(fabsf(a[i]));
+    out_pow[i] = dm::powf_det(fabsf(a[i]), b[i]);
+}
+
+}  // namespace rl
+
+// ==========================================================================================
+// host side
+// ==========================================================================================
+using namespace rl;
+
+static thread_local std::string g_last_error;
+void rl_set_error(const std::string& s) { g_last_error = s; }
+extern "C" const char* rl_last_error(void) { return g_last_error.c_str(); }
+
+#define HIP_OK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            rl_set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                           \
+            return RL_ERR_HIP;                                                                         \
+        }                                                                                              \
+    } while (0)
+
+struct rl_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DeviceScene ds{};
+    std::vector<void*> allocs;
+    uint32_t width = 0, height = 0;
+    bool single_bsdf = true;
+    int bsdf_type = 0;
+    bool lds_scene = false;
+    size_t scene_lds_bytes = 0;
+    // render scratch (grown on demand)
+    Pool pool{};
+    size_t pool_capacity = 0;
+    unsigned* d_owned = nullptr; size_t owned_capacity = 0;
+    unsigned* d_item_base = nullptr; size_t item_base_capacity = 0;
+    unsigned long long* d_block_seeds = nullptr; size_t seeds_capacity = 0;
+    unsigned long long* d_item_seed = nullptr; size_t item_capacity = 0;
+    unsigned* d_item_pixel = nullptr; size_t item_pixel_capacity = 0;
+    unsigned* d_queues = nullptr; unsigned* d_qcounts = nullptr; size_t queue_capacity = 0;
+    float* d_out = nullptr; size_t out_capacity = 0;
+    Counters* d_counters = nullptr;
+    Counters* h_counters = nullptr;   // pinned
+    std::vector<hipEvent_t> events;
+    BvhBuild bvh_dump;                // kept for rl_debug_bvh
+};
+
+template <typename T>
+static int upload(rl_context* ctx, const std::vector<T>& v, const T** out) {
+    *out = nullptr;
+    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    void* p = nullptr;
+    HIP_OK(hipMalloc(&p, bytes));
+    ctx->allocs.push_back(p);
+    if (!v.empty()) HIP_OK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = reinterpret_cast<const T*>(p);
+    return RL_OK;
+}
+
+extern "C" int rl_context_create(const rl_scene* scene, int device, rl_context** out) {
+    if (!scene || !out) return RL_ERR_INVALID_ARGUMENT;
+    if (!scene->has_camera) return RL_ERR_INVALID_ARGUMENT;
+    if (!scene->emitters_built) return RL_ERR_NOT_BUILT;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        rl_set_error("no HIP device available (hipGetDeviceCount); the MI355X path has no CPU fallback");
+        return RL_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n_dev) { rl_set_error("device ordinal out of range"); return RL_ERR_NO_DEVICE; }
+    HIP_OK(hipSetDevice(device));
+    rl_context* ctx = new rl_context();
+    ctx->device = device;
+    ctx->width = scene->width; ctx->height = scene->height;
+    int rc = RL_OK;
+    do {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rl_set_error("hipStreamCreate failed"); rc = RL_ERR_HIP; break; }
+        BvhBuild& bvh = ctx->bvh_dump;
+        build_bvh(*scene, &bvh);                  // BVHAccel::new — untimed (mod.rs:280)
+        FlatScene flat;
+        flatten_scene(*scene, &flat);
+        DeviceScene& ds = ctx->ds;
+        if ((rc = upload(ctx, bvh.nodes, &ds.nodes)) != RL_OK) break;
+        if ((rc = upload(ctx, bvh.tris, &ds.tris)) != RL_OK) break;
+        for (int i = 0; i < 3; i++) { ds.root_min[i] = bvh.root_min[i]; ds.root_max[i] = bvh.root_max[i]; }
+        ds.root = bvh.root;
+        ds.n_nodes = (uint32_t)bvh.nodes.size();
+        ds.n_prims = (uint32_t)bvh.tris.size();
+        ds.stack_depth = bvh.stack_depth;
+        if ((rc = upload(ctx, flat.tri_indices, &ds.tri_indices)) != RL_OK) break;
+        if ((rc = upload(ctx, flat.positions, &ds.positions)) != RL_OK) break;
+        if ((rc = upload(ctx, flat.normals, &ds.normals)) != RL_OK) break;
+        if ((rc = upload(ctx, flat.uvs, &ds.uvs)) != RL_OK) break;
+        if ((rc = upload(ctx, flat.meshes, &ds.meshes)) != RL_OK) break;
+        if ((rc = upload(ctx, flat.materials, &ds.materials)) != RL_OK) break;
+        if ((rc = upload(ctx, flat.bitmaps, &ds.bitmaps)) != RL_OK) break;
+        if ((rc = upload(ctx, flat.bitmap_texels, &ds.bitmap_texels)) != RL_OK) break;
+        if ((rc = upload(ctx, scene->emitters, &ds.emitters)) != RL_OK) break;
+        if ((rc = upload(ctx, scene->emitters_cdf, &ds.emitters_cdf)) != RL_OK) break;
+        ds.n_emitters = (uint32_t)scene->emitters.size();
+        if ((rc = upload(ctx, flat.mesh_cdf, &ds.mesh_cdf)) != RL_OK) break;
+        ds.n_meshes = (uint32_t)flat.meshes.size();
+        scene->sample_to_camera.to_cols(ds.camera.sample_to_camera);
+        scene->to_world.to_cols(ds.camera.to_world);
+        ds.camera.position[0] = scene->cam_pos.x; ds.camera.position[1] = scene->cam_pos.y; ds.camera.position[2] = scene->cam_pos.z;
+        ds.camera.width = scene->width; ds.camera.height = scene->height;
+        ds.medium = scene->medium;
+        ctx->single_bsdf = true;
+        ctx->bsdf_type = flat.materials.empty() ? 0 : flat.materials[0].type;
+        for (const Material& m : flat.materials) if (m.type != ctx->bsdf_type) ctx->single_bsdf = false;
+        // stage the scene in LDS when nodes + triangles are small (<= 48 KiB leaves room for the stacks)
+        ctx->scene_lds_bytes = 64 * ((size_t)ds.n_nodes + ds.n_prims);
+        ctx->lds_scene = ctx->scene_lds_bytes <= 48 * 1024;
+        if (hipMalloc((void**)&ctx->d_counters, sizeof(Counters)) != hipSuccess) { rl_set_error("hipMalloc counters"); rc = RL_ERR_HIP; break; }
+        if (hipHostMalloc((void**)&ctx->h_counters, sizeof(Counters)) != hipSuccess) { rl_set_error("hipHostMalloc counters"); rc = RL_ERR_HIP; break; }
+    } while (0);
+    if (rc != RL_OK) { rl_context_destroy(ctx); return rc; }
+    *out = ctx;
+    return RL_OK;
+}
+
+extern "C" void rl_context_destroy(rl_context* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    for (void* p : ctx->allocs) hipFree(p);
+    void* scratch[] = {ctx->pool.f, ctx->pool.u, ctx->pool.q, ctx->d_owned, ctx->d_item_base, ctx->d_block_seeds, ctx->d_item_seed,
+                       ctx->d_item_pixel, ctx->d_queues, ctx->d_qcounts, ctx->d_out, ctx->d_counters};
+    for (void* p : scratch) if (p) hipFree(p);
+    if (ctx->h_counters) hipHostFree(ctx->h_counters);
+    for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+template <typename T>
+static int ensure(T** p, size_t* cap, size_t n) {
+    if (*cap >= n && *p) return RL_OK;
+    if (*p) hipFree(*p);
+    *p = nullptr;
+    HIP_OK(hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)));
+    *cap = n;
+    return RL_OK;
+}
+
+static size_t traversal_lds_bytes(const rl_context* ctx, bool lds_scene, unsigned block) {
+    size_t stack = (size_t)2 * ctx->ds.stack_depth * block * sizeof(int);
+    return (lds_scene ? ctx->scene_lds_bytes : 0) + stack;
+}
+
+template <int MAT>
+static void launch_shade(bool medium, dim3 grid, dim3 block, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const Pool& pool,
+                         const unsigned* queue, const unsigned* count) {
+    if (medium) hipLaunchKernelGGL((k_shade<MAT, true>), grid, block, 0, st, rc, ds, pool, queue, count);
+    else hipLaunchKernelGGL((k_shade<MAT, false>), grid, block, 0, st, rc, ds, pool, queue, count);
+}
+static void launch_shade_type(int type, bool medium, dim3 grid, dim3 block, hipStream_t st, const RenderConst& rc, const DeviceScene& ds,
+                              const Pool& pool, const unsigned* queue, const unsigned* count) {
+    switch (type) {
+        case BSDF_DIFFUSE: launch_shade<BSDF_DIFFUSE>(medium, grid, block, st, rc, ds, pool, queue, count); break;
+        case BSDF_PHONG: launch_shade<BSDF_PHONG>(medium, grid, block, st, rc, ds, pool, queue, count); break;
+        case BSDF_METAL: launch_shade<BSDF_METAL>(medium, grid, block, st, rc, ds, pool, queue, count); break;
+        case BSDF_GLASS: launch_shade<BSDF_GLASS>(medium, grid, block, st, rc, ds, pool, queue, count); break;
+        case BSDF_SUBSTRATE: launch_shade<BSDF_SUBSTRATE>(medium, grid, block, st, rc, ds, pool, queue, count); break;
+        default: launch_shade<-1>(medium, grid, block, st, rc, ds, pool, queue, count); break;
+    }
+}
+
+extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, const uint64_t* block_seeds, size_t n_blocks, float* out_rgb,
+                              int out_is_device, void* stream_arg, rl_render_stats* stats) {
+    if (!ctx || !params || !block_seeds || !out_rgb) return RL_ERR_INVALID_ARGUMENT;
+    const uint32_t W = ctx->width, H = ctx->height;
+    const size_t nbx = (W + 15) / 16, nby = (H + 15) / 16;
+    if (n_blocks != nbx * nby) { rl_set_error("n_blocks does not match the image size"); return RL_ERR_INVALID_ARGUMENT; }
+    if (params->spp == 0) { rl_set_error("spp must be > 0 (assert_ne!(scene.nb_samples, 0), mod.rs:410)"); return RL_ERR_INVALID_ARGUMENT; }
+    if (params->strategy < 0 || params->strategy > 2) return RL_ERR_INVALID_ARGUMENT;
+    if (params->stream_mode != RL_STREAM_REFERENCE_ORDER && params->stream_mode != RL_STREAM_PER_SAMPLE) return RL_ERR_INVALID_ARGUMENT;
+    const uint32_t shard_count = params->shard_count ? params->shard_count : 1;
+    if (params->shard_index >= shard_count) return RL_ERR_INVALID_ARGUMENT;
+    if (params->strategy != RL_STRATEGY_BSDF && ctx->ds.n_emitters == 0) { rl_set_error("light sampling requested but the scene has no emitter"); return RL_ERR_NO_EMITTER; }
+    HIP_OK(hipSetDevice(ctx->device));
+    hipStream_t st = stream_arg ? (hipStream_t)stream_arg : ctx->stream;
+    auto t_start = std::chrono::steady_clock::now();
+
+    // ---- work decomposition: this shard's blocks, in creation order
+    std::vector<unsigned> owned, item_base;
+    unsigned n_pixels = 0;
+    for (size_t b = 0; b < n_blocks; b++) {
+        if (b % shard_count != params->shard_index) continue;
+        unsigned bx = (unsigned)(b / nby) * 16u, by = (unsigned)(b % nby) * 16u;
+        unsigned bw = std::min(16u, W - bx), bh = std::min(16u, H - by);
+        owned.push_back((unsigned)b);
+        item_base.push_back(n_pixels);
+        n_pixels += bw * bh;
+    }
+    const bool per_sample = params->stream_mode == RL_STREAM_PER_SAMPLE;
+    const unsigned n_items = per_sample ? n_pixels : (unsigned)owned.size();
+    unsigned P = params->pool_slots ? params->pool_slots : std::min<unsigned>(n_items, 4u << 20);
+    P = std::max(256u, (P + 255u) / 256u * 256u);
+
+    int rcode;
+    if ((rcode = ensure(&ctx->d_owned, &ctx->owned_capacity, owned.size())) != RL_OK) return rcode;
+    if ((rcode = ensure(&ctx->d_item_base, &ctx->item_base_capacity, owned.size())) != RL_OK) return rcode;
+    if ((rcode = ensure(&ctx->d_block_seeds, &ctx->seeds_capacity, n_blocks)) != RL_OK) return rcode;
+    if (per_sample) {
+        if ((rcode = ensure(&ctx->d_item_seed, &ctx->item_capacity, n_pixels)) != RL_OK) return rcode;
+        if ((rcode = ensure(&ctx->d_item_pixel, &ctx->item_pixel_capacity, n_pixels)) != RL_OK) return rcode;
+    }
+    if (ctx->pool_capacity < P) {
+        if (ctx->pool.f) hipFree(ctx->pool.f);
+        if (ctx->pool.u) hipFree(ctx->pool.u);
+        if (ctx->pool.q) hipFree(ctx->pool.q);
+        ctx->pool = Pool{};
+        HIP_OK(hipMalloc((void**)&ctx->pool.f, (size_t)F_COUNT * P * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&ctx->pool.u, (size_t)U_COUNT * P * sizeof(unsigned)));
+        HIP_OK(hipMalloc((void**)&ctx->pool.q, (size_t)Q_COUNT * P * sizeof(unsigned long long)));
+        ctx->pool_capacity = P;
+    }
+    Pool pool = ctx->pool;
+    pool.P = P;
+    const bool use_sort = !ctx->single_bsdf;
+    if (use_sort) {
+        if ((rcode = ensure(&ctx->d_queues, &ctx->queue_capacity, (size_t)kNumBins * P)) != RL_OK) return rcode;
+        if (!ctx->d_qcounts) HIP_OK(hipMalloc((void**)&ctx->d_qcounts, kNumBins * sizeof(unsigned)));
+    }
+    float* d_out = out_rgb;
+    if (!out_is_device) {
+        if ((rcode = ensure(&ctx->d_out, &ctx->out_capacity, (size_t)3 * W * H)) != RL_OK) return rcode;
+        d_out = ctx->d_out;
+    }
+
+    HIP_OK(hipMemcpyAsync(ctx->d_owned, owned.data(), owned.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(ctx->d_item_base, item_base.data(), item_base.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(ctx->d_block_seeds, block_seeds, n_blocks * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemsetAsync(d_out, 0, (size_t)3 * W * H * sizeof(float), st));
+    Counters init{};
+    init.active = std::min(P, n_items);
+    init.next_item = P;
+    HIP_OK(hipMemcpyAsync(ctx->d_counters, &init, sizeof(init), hipMemcpyHostToDevice, st));
+
+    RenderConst rc{};
+    rc.spp = params->spp;
+    rc.has_min = params->has_min_depth; rc.min_depth = params->min_depth;
+    rc.has_max = params->has_max_depth; rc.max_depth = params->max_depth;
+    rc.has_rr = params->has_rr_depth; rc.rr_depth = params->rr_depth;
+    rc.strategy = params->strategy; rc.single_scattering = params->single_scattering;
+    rc.stream_mode = params->stream_mode; rc.seed_variant = params->seed_variant;
+    rc.inv_spp = 1.0f / (float)params->spp;
+    rc.W = W; rc.H = H; rc.nby = (unsigned)nby;
+    rc.n_items = n_items;
+    rc.owned_blocks = ctx->d_owned; rc.block_item_base = ctx->d_item_base; rc.n_owned = (unsigned)owned.size();
+    rc.block_seeds = ctx->d_block_seeds;
+    rc.item_seed = ctx->d_item_seed; rc.item_pixel = ctx->d_item_pixel;
+    rc.out = d_out;
+    rc.counters = ctx->d_counters;
+
+    const DeviceScene& ds = ctx->ds;
+    const dim3 block(256);
+    const dim3 grid_all((P + 255) / 256);
+    int n_cu = 256;
+    hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const dim3 grid_persistent(std::min<unsigned>((P + 255) / 256, (unsigned)n_cu * 8u));
+    const bool medium = ds.medium.enabled != 0;
+    const size_t lds_trav = traversal_lds_bytes(ctx, ctx->lds_scene, 256);
+
+    if (per_sample && !owned.empty()) hipLaunchKernelGGL(k_seed_pixels, dim3(((unsigned)owned.size() + 63) / 64), dim3(64), 0, st, rc);
+    hipLaunchKernelGGL(k_init, grid_all, block, 0, st, rc, pool);
+
+    // events: 4 timed kernel classes per iteration
+    const bool timing = stats != nullptr && !getenv("RL_NO_EVENTS");
+    const size_t kEventsPerIter = 8;
+    const unsigned poll_every = per_sample ? 8u : 32u;
+    if (timing && ctx->events.size() < kEventsPerIter * poll_every) {
+        size_t need = kEventsPerIter * poll_every;
+        while (ctx->events.size() < need) { hipEvent_t ev; HIP_OK(hipEventCreate(&ev)); ctx->events.push_back(ev); }
+    }
+    double ms[4] = {0, 0, 0, 0};
+    uint64_t iterations = 0, launches = 2, n_extend = 0;
+    unsigned in_batch = 0;
+    auto flush_events = [&](unsigned count) -> int {
+        for (unsigned i = 0; i < count; i++)
+            for (int k = 0; k < 4; k++) {
+                float t = 0.0f;
+                HIP_OK(hipEventElapsedTime(&t, ctx->events[kEventsPerIter * i + 2 * k], ctx->events[kEventsPerIter * i + 2 * k + 1]));
+                ms[k] += t;
+            }
+        return RL_OK;
+    };
+    for (;;) {
+        hipEvent_t* ev = timing ? &ctx->events[kEventsPerIter * in_batch] : nullptr;
+        if (timing) hipEventRecord(ev[0], st);
+        hipLaunchKernelGGL(k_raygen, grid_persistent, block, 0, st, rc, ds, pool);
+        if (timing) { hipEventRecord(ev[1], st); hipEventRecord(ev[2], st); }
+        if (ctx->lds_scene) hipLaunchKernelGGL((k_extend<true>), grid_all, block, lds_trav, st, rc, ds, pool);
+        else hipLaunchKernelGGL((k_extend<false>), grid_all, block, lds_trav, st, rc, ds, pool);
+        if (timing) { hipEventRecord(ev[3], st); hipEventRecord(ev[4], st); }
+        if (use_sort) {
+            hipMemsetAsync(ctx->d_qcounts, 0, kNumBins * sizeof(unsigned), st);
+            hipLaunchKernelGGL(k_sort, grid_all, block, 0, st, ds, pool, ctx->d_queues, ctx->d_qcounts);
+            for (int b = 0; b < kNumBins; b++)
+                launch_shade_type(b, medium, grid_all, block, st, rc, ds, pool, ctx->d_queues + (size_t)b * P, ctx->d_qcounts + b);
+            launches += kNumBins + 1;
+        } else {
+            launch_shade_type(ctx->bsdf_type, medium, grid_all, block, st, rc, ds, pool, nullptr, nullptr);
+            launches += 1;
+        }
+        if (timing) { hipEventRecord(ev[5], st); hipEventRecord(ev[6], st); }
+        if (ctx->lds_scene) hipLaunchKernelGGL((k_shadow<true>), grid_all, block, lds_trav, st, rc, ds, pool);
+        else hipLaunchKernelGGL((k_shadow<false>), grid_all, block, lds_trav, st, rc, ds, pool);
+        if (timing) hipEventRecord(ev[7], st);
+        launches += 3;
+        n_extend++;
+        iterations++;
+        in_batch++;
+        if (in_batch == poll_every) {
+            HIP_OK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
+            if (timing) { int r = flush_events(in_batch); if (r != RL_OK) return r; }
+            in_batch = 0;
+            if (ctx->h_counters->active == 0) break;
+        }
+        if (iterations > (uint64_t)1 << 28) { rl_set_error("render did not terminate"); return RL_ERR_HIP; }
+    }
+    // one more raygen pass is never needed: `active` reaches 0 inside k_raygen after the last fold.
+    if (!out_is_device) HIP_OK(hipMemcpyAsync(out_rgb, d_out, (size_t)3 * W * H * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    HIP_OK(hipGetLastError());
+    auto t_end = std::chrono::steady_clock::now();
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        const Counters& c = *ctx->h_counters;
+        stats->camera_samples = c.camera_samples;
+        stats->vertices = c.vertices;
+        stats->extension_rays = c.extension_rays;
+        stats->shadow_rays = c.shadow_rays;
+        stats->rng_draws = c.rng_draws;
+        stats->iterations = iterations;
+        stats->kernel_launches = launches;
+        stats->render_ms = std::chrono::duration<double, std::milli>(t_end - t_start).count();
+        stats->ms_raygen = ms[0]; stats->ms_extend = ms[1]; stats->ms_shade = ms[2]; stats->ms_shadow = ms[3];
+        stats->n_extend_launches = n_extend;
+    }
+    return RL_OK;
+}
+
+// ---- batched Acceleration::{trace, visible}
+extern "C" int rl_trace_batch(rl_context* ctx, size_t n, const float* origins, const float* directions, float* t_out, float* u_out,
+                              float* v_out, int32_t* mesh_out, int32_t* tri_out) {
+    if (!ctx || (n && (!origins || !directions || !t_out || !u_out || !v_out || !mesh_out || !tri_out))) return RL_ERR_INVALID_ARGUMENT;
+    if (n == 0) return RL_OK;
+    HIP_OK(hipSetDevice(ctx->device));
+    float *d_o, *d_d, *d_t, *d_u, *d_v; int *d_m, *d_tr;
+    HIP_OK(hipMalloc((void**)&d_o, 3 * n * 4)); HIP_OK(hipMalloc((void**)&d_d, 3 * n * 4));
+    HIP_OK(hipMalloc((void**)&d_t, n * 4)); HIP_OK(hipMalloc((void**)&d_u, n * 4)); HIP_OK(hipMalloc((void**)&d_v, n * 4));
+    HIP_OK(hipMalloc((void**)&d_m, n * 4)); HIP_OK(hipMalloc((void**)&d_tr, n * 4));
+    HIP_OK(hipMemcpy(d_o, origins, 3 * n * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_d, directions, 3 * n * 4, hipMemcpyHostToDevice));
+    size_t lds = traversal_lds_bytes(ctx, false, 256);
+    hipLaunchKernelGGL(k_trace_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, ctx->stream, ctx->ds, (unsigned)n, d_o, d_d, d_t, d_u, d_v, d_m, d_tr);
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpy(t_out, d_t, n * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(u_out, d_u, n * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(v_out, d_v, n * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(mesh_out, d_m, n * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(tri_out, d_tr, n * 4, hipMemcpyDeviceToHost));
+    hipFree(d_o); hipFree(d_d); hipFree(d_t); hipFree(d_u); hipFree(d_v); hipFree(d_m); hipFree(d_tr);
+    return RL_OK;
+}
+
+extern "C" int rl_visible_batch(rl_context* ctx, size_t n, const float* p0, const float* p1, uint8_t* visible_out) {
+    if (!ctx || (n && (!p0 || !p1 || !visible_out))) return RL_ERR_INVALID_ARGUMENT;
+    if (n == 0) return RL_OK;
+    HIP_OK(hipSetDevice(ctx->device));
+    float *d_a, *d_b; unsigned char* d_o;
+    HIP_OK(hipMalloc((void**)&d_a, 3 * n * 4)); HIP_OK(hipMalloc((void**)&d_b, 3 * n * 4)); HIP_OK(hipMalloc((void**)&d_o, n));
+    HIP_OK(hipMemcpy(d_a, p0, 3 * n * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_b, p1, 3 * n * 4, hipMemcpyHostToDevice));
+    size_t lds = traversal_lds_bytes(ctx, false, 256);
+    hipLaunchKernelGGL(k_visible_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, ctx->stream, ctx->ds, (unsigned)n, d_a, d_b, d_o);
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpy(visible_out, d_o, n, hipMemcpyDeviceToHost));
+    hipFree(d_a); hipFree(d_b); hipFree(d_o);
+    return RL_OK;
+}
+
+// ---- debug / test hooks (declared in wavefront.h, exported for the test-suite)
+extern "C" int rl_debug_numerics(int device, size_t n, const float* a, const float* b, float* out8) {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return RL_ERR_NO_DEVICE;
+    HIP_OK(hipSetDevice(device));
+    float *d_a, *d_b, *d_out;
+    HIP_OK(hipMalloc((void**)&d_a, n * 4)); HIP_OK(hipMalloc((void**)&d_b, n * 4)); HIP_OK(hipMalloc((void**)&d_out, 8 * n * 4));
+    HIP_OK(hipMemcpy(d_a, a, n * 4, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(d_b, b, n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_numerics_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (unsigned)n, d_a, d_b, d_out, d_out + n, d_out + 2 * n,
+                       d_out + 3 * n, d_out + 4 * n, d_out + 5 * n, d_out + 6 * n, d_out + 7 * n);
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(out8, d_out, 8 * n * 4, hipMemcpyDeviceToHost));
+    hipFree(d_a); hipFree(d_b); hipFree(d_out);
+    return RL_OK;
+}
+
+extern "C" int rl_debug_bvh_sizes(const rl_context* ctx, uint64_t* n_ref_nodes, uint64_t* n_prims, uint32_t* stack_depth, int* lds_scene) {
+    if (!ctx) return RL_ERR_INVALID_ARGUMENT;
+    *n_ref_nodes = ctx->bvh_dump.ref_info.size(); *n_prims = ctx->bvh_dump.ref_prim_mesh.size();
+    *stack_depth = ctx->bvh_dump.stack_depth; *lds_scene = ctx->lds_scene ? 1 : 0;
+    return RL_OK;
+}
+
+extern "C" const char* rl_build_info(void) { return "rustlight_amd wavefront path tracer; kernels: gfx950 (hipcc, -ffp-contract=off)"; }

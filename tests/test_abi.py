@@ -1,0 +1,100 @@
+"""C-ABI library: loads, exports every symbol include/rustlight_amd.h declares, host-side logic
+(Mesh::new, build_emitters, BVH build, camera, PBRT loader) equals the oracle's.  CPU only —
+no compute entry point is called (those need a GPU and fail loudly without one)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from rustlight_amd import api, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "rustlight_amd.h")).read()
+    declared = set(re.findall(r"\b(rl_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(api.PUBLIC_SYMBOLS), declared ^ set(api.PUBLIC_SYMBOLS)
+    L = ctypes.CDLL(api.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in api.lib().rl_build_info()
+
+
+def test_kernels_are_compiled_for_gfx950(built):
+    data = open(api.LIB_PATH, "rb").read()
+    assert b"gfx950" in data and b"k_extend" in data and b"k_shade" in data and b"k_shadow" in data and b"k_raygen" in data
+
+
+def test_no_gpu_means_loud_failure_not_fallback(built, cbox64):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(api.NoDeviceError):
+        api.Context(api.Scene(cbox64))
+
+
+def test_error_codes(built):
+    L = api.lib()
+    assert L.rl_scene_create(None) == -1
+    h = ctypes.c_void_p()
+    assert L.rl_scene_create(ctypes.byref(h)) == 0
+    assert L.rl_scene_build_emitters(h) == -1            # no camera yet
+    v = np.zeros((3, 3), np.float32)
+    idx = np.array([[0, 1, 7]], np.uint32)                # out-of-range index
+    bd = api.abi.bsdf_desc(scenes.matte((0.5, 0.5, 0.5)))
+    assert L.rl_scene_add_mesh(h, api.abi.fptr(v), 3, api.abi.u32ptr(idx), 1, None, None, ctypes.byref(bd), None) == -1
+    assert L.rl_scene_add_mesh(h, api.abi.fptr(v), 3, api.abi.u32ptr(idx), 0, None, None, ctypes.byref(bd), None) == -1   # empty mesh
+    L.rl_scene_destroy(h)
+    with pytest.raises(api.RustlightError):
+        api.Scene.load_pbrt("/nonexistent.pbrt")
+
+
+@pytest.mark.parametrize("maker", [lambda: scenes.cbox(96, 64), lambda: scenes.living_room(64, 64, n_spheres=12, tess=8), scenes.single_triangle])
+def test_host_bvh_and_camera_equal_oracle(built, maker):
+    sd = maker()
+    ps, os_ = api.Scene(sd), orc.Scene(sd)
+    for a, b in zip(ps.debug_bvh(), os_.bvh()):
+        np.testing.assert_array_equal(a, b)
+    for px, py in [(0.0, 0.0), (10.25, 3.5), (sd.width - 0.001, sd.height - 0.5)]:
+        o1, d1 = ps.camera_ray(px, py)
+        o2, d2 = os_.camera_generate(px, py)
+        np.testing.assert_array_equal(o1, o2)
+        np.testing.assert_array_equal(d1, d2)
+        assert abs(float(np.dot(d1, d1)) - 1.0) < 1e-4     # Ray::new's assert_approx_eq (structure.rs:707)
+    assert ps.counts()["emitters"] == os_.info()["emitters"]
+
+
+def test_pbrt_loader_round_trip(built, tmp_path):
+    sd = scenes.cbox(128, 96)
+    p = str(tmp_path / "cbox.pbrt")
+    scenes.write_pbrt(sd, p)
+    loaded = api.Scene.load_pbrt(p)
+    direct = api.Scene(sd)
+    assert loaded.size == (128, 96)
+    assert loaded.counts() == direct.counts() == {"meshes": 8, "triangles": 36, "emitters": 1}
+    for a, b in zip(loaded.debug_bvh(), direct.debug_bvh()):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(loaded.camera_ray(5.5, 7.25)[1], direct.camera_ray(5.5, 7.25)[1])
+
+
+def test_repo_cbox_scene_file_matches_fixture(built):
+    loaded = api.Scene.load_pbrt(os.path.join(ROOT, "data", "cbox.pbrt"))
+    direct = api.Scene(scenes.cbox(512, 512))
+    assert loaded.size == (512, 512)
+    for a, b in zip(loaded.debug_bvh(), direct.debug_bvh()):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_save_pfm(built, tmp_path):
+    img = np.arange(2 * 3 * 3, dtype=np.float32).reshape(2, 3, 3) - 4.0
+    p = str(tmp_path / "x.pfm")
+    api.save_pfm(p, img)
+    raw = open(p, "rb").read()
+    assert raw.startswith(b"PF\n3 2\n-1.0\n")
+    data = np.frombuffer(raw[len(b"PF\n3 2\n-1.0\n"):], dtype="<f4").reshape(2, 3, 3)
+    np.testing.assert_array_equal(data, np.abs(img[::-1]))      # bottom-up rows, abs() (structure.rs:547-560)
