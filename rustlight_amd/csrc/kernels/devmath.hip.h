@@ -30,8 +30,8 @@ RL_DEV bool finite_f(float x) { return x - x == 0.0f; }
 RL_DEV float rmax(float a, float b) { return fmaxf(a, b); }     // Rust f32::max (non-NaN operand wins)
 RL_DEV float rmin(float a, float b) { return fminf(a, b); }
 RL_DEV float signum_f(float x) { return x != x ? x : copysignf(1.0f, x); }   // Rust f32::signum
-RL_DEV float sqrt_rn(float x) { return __fsqrt_rn(x); }
-RL_DEV float div_rn(float a, float b) { return __fdiv_rn(a, b); }
+RL_DEV float sqrt_rn(float x) { return __builtin_sqrtf(x); }   // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt, the default); __fsqrt_rn is the 1-ulp native sqrt
+RL_DEV float div_rn(float a, float b) { return a / b; }             // correctly rounded under the same default
 
 // ------------------------------------------------------------------------------------------
 struct V2 { float x, y; };

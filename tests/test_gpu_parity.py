@@ -85,7 +85,7 @@ def _render_pair(sd, ctx=None, osc=None, seed=0, **kw):
     ctx = ctx or api.Context(api.Scene(sd), 0)
     osc = osc or orc.Scene(sd)
     okw = {k: v for k, v in kw.items() if k != "pool_slots"}
-    img, st = ctx.render(api.IndependentSampler(seed).block_seeds(sd.width, sd.height), api.path_params(**kw))
+    img, st = ctx.render(api.IndependentSampler(seed, kw.get("seed_variant", 0)).block_seeds(sd.width, sd.height), api.path_params(**kw))
     ref_fwd, ost = osc.render(master_seed=seed, eval_order=1, **okw)
     ref_rec, _ = osc.render(master_seed=seed, eval_order=0, **okw)
     return img, st, ref_fwd, ref_rec, ost
