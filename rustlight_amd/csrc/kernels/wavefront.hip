@@ -78,7 +78,6 @@ struct Pool {
 };
 
 struct Counters {
-    unsigned long long camera_samples, vertices, extension_rays, shadow_rays, rng_draws;
     unsigned int active;        // slots that still own work
     unsigned int next_item;     // work-item dispenser
     unsigned int pad[2];
@@ -103,6 +102,7 @@ struct RenderConst {
     unsigned* item_pixel;               // per pixel item: y * W + x
     float* out;                         // W*H*3 framebuffer
     Counters* counters;
+    unsigned long long* partials;       // [max grid blocks][STAT_COUNT] statistics rows
 };
 
 #define PF(field) pool.f[(size_t)(field) * pool.P + slot]
@@ -116,10 +116,27 @@ RL_DEV void storec(const Pool& pool, unsigned slot, int f0, Col c) { PF(f0) = c.
 RL_DEV Rng load_rng(const Pool& pool, unsigned slot, int q0) { Rng r; r.s0 = PQ(q0); r.s1 = PQ(q0 + 1); r.s2 = PQ(q0 + 2); r.s3 = PQ(q0 + 3); return r; }
 RL_DEV void store_rng(const Pool& pool, unsigned slot, int q0, const Rng& r) { PQ(q0) = r.s0; PQ(q0 + 1) = r.s1; PQ(q0 + 2) = r.s2; PQ(q0 + 3) = r.s3; }
 
-// wave64 sum; lane 0 of each wave publishes with one atomic
-RL_DEV void wave_add(unsigned long long* dst, unsigned v) {
+// Statistics without atomics on shared words (a device-scope atomic on one word costs ~10 ns and
+// serialises: MI355X_MICROARCH "fanin"): wave64 shuffle sum -> LDS per block -> one plain
+// read-modify-write of this block's own row of `partials` (rows are private to a block index;
+// launches on one stream are ordered).  The host sums the rows after the render.
+enum { STAT_SAMPLES, STAT_VERTICES, STAT_EXT_RAYS, STAT_SHADOW_RAYS, STAT_DRAWS, STAT_COUNT = 8 };
+RL_DEV unsigned wave_sum(unsigned v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if ((threadIdx.x & 63u) == 0u && v) atomicAdd(dst, (unsigned long long)v);
+    return v;
+}
+template <int N>
+RL_DEV void block_stats(unsigned long long* partials, const int (&which)[N], const unsigned (&vals)[N]) {
+    __shared__ unsigned s_acc[N];
+    if (threadIdx.x < N) s_acc[threadIdx.x] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        unsigned v = wave_sum(vals[k]);
+        if ((threadIdx.x & 63u) == 0u && v) atomicAdd(&s_acc[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < N && s_acc[threadIdx.x]) partials[(size_t)blockIdx.x * STAT_COUNT + which[threadIdx.x]] += s_acc[threadIdx.x];
 }
 
 RL_DEV void block_geometry(const RenderConst& rc, unsigned b, unsigned* bx, unsigned* by, unsigned* bw, unsigned* bh) {
@@ -260,8 +277,7 @@ __global__ void __launch_bounds__(256) k_raygen(RenderConst rc, DeviceScene sc, 
         PU(U_DEPTH) = 1u;
         PU(U_FLAGS) = ST_RAY | (PREV_SENSOR << ST_PREV_SHIFT) | ST_PDF_SA;
     }
-    wave_add(&rc.counters->camera_samples, n_samples);
-    wave_add(&rc.counters->rng_draws, n_draws);
+    { const int which[2] = {STAT_SAMPLES, STAT_DRAWS}; const unsigned vals[2] = {n_samples, n_draws}; block_stats<2>(rc.partials, which, vals); }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -281,7 +297,6 @@ __global__ void __launch_bounds__(256) k_extend(RenderConst rc, DeviceScene sc, 
     }
     int* stack = reinterpret_cast<int*>(stack_base) + threadIdx.x;
     unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned n = 0;
     if (slot < pool.P && (PU(U_FLAGS) & ST_RAY)) {
         V3 o = load3(pool, slot, F_OX), d = load3(pool, slot, F_DX);
         Hit hit; hit.t = kF32Max; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
@@ -289,9 +304,7 @@ __global__ void __launch_bounds__(256) k_extend(RenderConst rc, DeviceScene sc, 
                         o, d, kEps, kF32Max, hit, stack, (int)blockDim.x);
         PF(F_T) = hit.t; PF(F_U) = hit.u; PF(F_V) = hit.v;
         PU(U_PRIM) = (unsigned)hit.prim;
-        n = 1;
     }
-    wave_add(&rc.counters->extension_rays, n);
 }
 
 template <bool LDS_SCENE>
@@ -336,7 +349,7 @@ __global__ void __launch_bounds__(256) k_shadow(RenderConst rc, DeviceScene sc, 
 template <int MAT, bool MEDIUM>
 __global__ void __launch_bounds__(256) k_shade(RenderConst rc, DeviceScene sc, Pool pool, const unsigned* queue, const unsigned* queue_count) {
     unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned n_vertices = 0, n_draws = 0, n_shadow = 0;
+    unsigned n_vertices = 0, n_draws = 0, n_shadow = 0, n_ext = 0;
     bool live = false;
     unsigned slot = idx;
     if (queue) { if (idx < *queue_count) { slot = queue[idx]; live = true; } }
@@ -344,6 +357,7 @@ __global__ void __launch_bounds__(256) k_shade(RenderConst rc, DeviceScene sc, P
     unsigned flags = 0;
     if (live) { flags = PU(U_FLAGS); live = (flags & ST_RAY) != 0u; }
     if (live) {
+        n_ext = 1;      // every shaded slot carried exactly one extension ray through k_extend
         const unsigned prev = (flags >> ST_PREV_SHIFT) & 3u;
         const unsigned depth = PU(U_DEPTH);          // generate()'s depth at which the edge's origin vertex was expanded
         const int prim = (int)PU(U_PRIM);
@@ -510,9 +524,11 @@ __global__ void __launch_bounds__(256) k_shade(RenderConst rc, DeviceScene sc, P
         }
         PU(U_FLAGS) = new_flags;
     }
-    wave_add(&rc.counters->vertices, n_vertices);
-    wave_add(&rc.counters->rng_draws, n_draws);
-    wave_add(&rc.counters->shadow_rays, n_shadow);
+    {
+        const int which[4] = {STAT_VERTICES, STAT_DRAWS, STAT_SHADOW_RAYS, STAT_EXT_RAYS};
+        const unsigned vals[4] = {n_vertices, n_draws, n_shadow, n_ext};
+        block_stats<4>(rc.partials, which, vals);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -643,6 +659,7 @@ struct rl_context {
     float* d_out = nullptr; size_t out_capacity = 0;
     Counters* d_counters = nullptr;
     Counters* h_counters = nullptr;   // pinned
+    unsigned long long* d_partials = nullptr; size_t partials_capacity = 0;
     std::vector<hipEvent_t> events;
     BvhBuild bvh_dump;                // kept for rl_debug_bvh
 };
@@ -726,7 +743,7 @@ extern "C" void rl_context_destroy(rl_context* ctx) {
     hipSetDevice(ctx->device);
     for (void* p : ctx->allocs) hipFree(p);
     void* scratch[] = {ctx->pool.f, ctx->pool.u, ctx->pool.q, ctx->d_owned, ctx->d_item_base, ctx->d_block_seeds, ctx->d_item_seed,
-                       ctx->d_item_pixel, ctx->d_queues, ctx->d_qcounts, ctx->d_out, ctx->d_counters};
+                       ctx->d_item_pixel, ctx->d_queues, ctx->d_qcounts, ctx->d_out, ctx->d_counters, ctx->d_partials};
     for (void* p : scratch) if (p) hipFree(p);
     if (ctx->h_counters) hipHostFree(ctx->h_counters);
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
@@ -838,6 +855,9 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     init.active = std::min(P, n_items);
     init.next_item = P;
     HIP_OK(hipMemcpyAsync(ctx->d_counters, &init, sizeof(init), hipMemcpyHostToDevice, st));
+    const size_t n_partial_rows = (P + 255) / 256;
+    if ((rcode = ensure(&ctx->d_partials, &ctx->partials_capacity, n_partial_rows * STAT_COUNT)) != RL_OK) return rcode;
+    HIP_OK(hipMemsetAsync(ctx->d_partials, 0, n_partial_rows * STAT_COUNT * sizeof(unsigned long long), st));
 
     RenderConst rc{};
     rc.spp = params->spp;
@@ -854,6 +874,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     rc.item_seed = ctx->d_item_seed; rc.item_pixel = ctx->d_item_pixel;
     rc.out = d_out;
     rc.counters = ctx->d_counters;
+    rc.partials = ctx->d_partials;
 
     const DeviceScene& ds = ctx->ds;
     const dim3 block(256);
@@ -924,17 +945,20 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     }
     // one more raygen pass is never needed: `active` reaches 0 inside k_raygen after the last fold.
     if (!out_is_device) HIP_OK(hipMemcpyAsync(out_rgb, d_out, (size_t)3 * W * H * sizeof(float), hipMemcpyDeviceToHost, st));
+    std::vector<unsigned long long> partials(n_partial_rows * STAT_COUNT);
+    HIP_OK(hipMemcpyAsync(partials.data(), ctx->d_partials, partials.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
+    unsigned long long totals[STAT_COUNT] = {0};
+    for (size_t r = 0; r < n_partial_rows; r++) for (int k = 0; k < STAT_COUNT; k++) totals[k] += partials[r * STAT_COUNT + k];
     HIP_OK(hipGetLastError());
     auto t_end = std::chrono::steady_clock::now();
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
-        const Counters& c = *ctx->h_counters;
-        stats->camera_samples = c.camera_samples;
-        stats->vertices = c.vertices;
-        stats->extension_rays = c.extension_rays;
-        stats->shadow_rays = c.shadow_rays;
-        stats->rng_draws = c.rng_draws;
+        stats->camera_samples = totals[STAT_SAMPLES];
+        stats->vertices = totals[STAT_VERTICES];
+        stats->extension_rays = totals[STAT_EXT_RAYS];
+        stats->shadow_rays = totals[STAT_SHADOW_RAYS];
+        stats->rng_draws = totals[STAT_DRAWS];
         stats->iterations = iterations;
         stats->kernel_launches = launches;
         stats->render_ms = std::chrono::duration<double, std::milli>(t_end - t_start).count();
