@@ -47,7 +47,10 @@ RL_DEV bool slab(V3 lo, V3 hi, V3 o, V3 inv_d, float tnear, float tfar, float* t
     return true;
 }
 
-// Mesh::intersection_tri; returns true and updates `hit` if the triangle is the new closest hit
+// Mesh::intersection_tri; returns true and updates `hit` if the triangle is the new closest hit.
+// The reference evaluates u, v (two sqrt + two divides) before it looks at `t < its.t && t > 1e-5`
+// (geometry.rs:391-398).  All conditions are pure and must hold together, so testing the cheap
+// distance window first accepts exactly the same set of hits with the same (t, u, v) bits.
 RL_DEV bool tri_test(const float4 q0, const float4 q1, const float4 q2, const float4 q3, V3 o, V3 d, Hit& hit, int prim) {
     V3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z);
     V3 n = mk3(q0.w, q1.w, q2.w);
@@ -56,6 +59,7 @@ RL_DEV bool tri_test(const float4 q0, const float4 q1, const float4 q2, const fl
     if (denom == 0.0f) return false;
     float t = div_rn(-dot(o - v0, n), denom);
     if (t < 0.0f) return false;
+    if (!(t < hit.t && t > 0.00001f)) return false;
     V3 p = o + t * d;
     V3 pv = p - v0;
     V3 u0 = cross(e1, pv);
@@ -64,9 +68,7 @@ RL_DEV bool tri_test(const float4 q0, const float4 q1, const float4 q2, const fl
     float v = div_rn(length(u0), det);
     float u = div_rn(length(w0), det);
     if (u < 0.0f || v < 0.0f || u > 1.0f || v > 1.0f) return false;
-    if (u + v <= 1.0f) {
-        if (t < hit.t && t > 0.00001f) { hit.t = t; hit.u = u; hit.v = v; hit.prim = prim; return true; }
-    }
+    if (u + v <= 1.0f) { hit.t = t; hit.u = u; hit.v = v; hit.prim = prim; return true; }
     return false;
 }
 

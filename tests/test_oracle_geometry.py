@@ -1,0 +1,136 @@
+"""Oracle unit tests for the geometric core and the quirks of SURVEY.md App. D.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from rustlight_amd import scenes
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def tri(built):
+    return orc.Scene(scenes.single_triangle())
+
+
+def test_single_triangle_known_answer(tri):
+    # triangle (0,0,0) (1,0,0) (0,1,0); ray from z=-1 straight up +z through (0.25, 0.5)
+    t, u, v, m, k = tri.trace([[0.25, 0.5, -1.0]], [[0.0, 0.0, 1.0]])
+    assert m[0] == 0 and k[0] == 0
+    assert t[0] == np.float32(1.0)
+    assert u[0] == np.float32(0.25) and v[0] == np.float32(0.5)          # u <-> vertex 1, v <-> vertex 2
+    # u + v <= 1 is inclusive, outside is a miss
+    assert tri.trace([[0.5, 0.5, -1.0]], [[0, 0, 1.0]])[3][0] == 0
+    assert tri.trace([[0.6, 0.6, -1.0]], [[0, 0, 1.0]])[3][0] == 1        # passes the triangle, hits the light quad behind
+    # double sided: the same hit from the other side
+    t2, *_ , m2, _ = tri.trace([[0.25, 0.5, 1.0]], [[0.0, 0.0, -1.0]])
+    assert m2[0] == 0 and t2[0] == np.float32(1.0)
+    # parallel ray: denom == 0 exactly -> no hit on the triangle
+    assert tri.trace([[0.25, 0.5, -1.0]], [[1.0, 0.0, 0.0]])[3][0] == -1
+
+
+def test_self_intersection_epsilon(tri):
+    # t > 1e-5 is required (geometry.rs:395): a ray starting on the triangle does not re-hit it
+    t, *_, m, _ = tri.trace([[0.25, 0.25, 0.0]], [[0.0, 0.0, 1.0]])
+    assert m[0] == 1 and t[0] == np.float32(5.0)
+    t, *_, m, _ = tri.trace([[0.25, 0.25, -2e-5]], [[0.0, 0.0, 1.0]])
+    assert m[0] == 0 and 1.9e-5 < t[0] < 2.1e-5
+
+
+def test_visible_quirks(tri):
+    assert tri.visible([[0.25, 0.25, -1.0]], [[0.25, 0.25, 4.0]])[0] == 0        # blocked by the triangle
+    assert tri.visible([[0.8, 0.8, -1.0]], [[0.8, 0.8, 4.0]])[0] == 1
+    # segment is shortened by (1 - 1e-5): an occluder exactly at the end point does not count
+    assert tri.visible([[0.25, 0.25, -1.0]], [[0.25, 0.25, 0.0]])[0] == 1
+    # a segment that never touches the root box is reported as NOT visible (accel.rs:338-340)
+    assert tri.visible([[10.0, 10.0, 10.0]], [[11.0, 10.0, 10.0]])[0] == 0
+
+
+def test_bvh_equals_brute_force(built):
+    for sd in (scenes.cbox(32, 32), scenes.living_room(32, 32, n_spheres=8, tess=8)):
+        sc = orc.Scene(sd)
+        rng = np.random.default_rng(3)
+        n = 100000
+        o = rng.uniform(-0.9, 0.9, (n, 3)).astype(np.float32)
+        o[:, 1] += 1.0
+        if sd.n_triangles > 100:
+            o = o * 3.5
+        d = rng.normal(size=(n, 3))
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        a, b = sc.trace(o, d), sc.trace(o, d, brute=True)
+        np.testing.assert_array_equal(a[0], b[0])                      # identical t everywhere
+        same = (a[3] == b[3]) & (a[4] == b[4])
+        # the primitive may differ only on exact-t ties (e.g. the tall box's bottom face is coplanar with the
+        # floor): strict `t < its.t` keeps whichever triangle is tested first
+        assert same.mean() > 0.998
+        assert (a[3] >= 0).mean() > 0.3
+
+
+def test_bvh_shape(built):
+    sc = orc.Scene(scenes.cbox(32, 32))
+    boxes, info, count, pm, pt = sc.bvh()
+    assert len(pm) == 36 and 35 <= len(count) <= 71
+    assert count[0] == 0 and (count <= 2).all()                       # leaves hold <= 2 triangles
+    assert count.sum() == 36
+    inner = np.where(count == 0)[0]
+    assert (info[inner] + 1 < len(count)).all()                        # children are contiguous (info, info + 1)
+    assert sorted(zip(pm.tolist(), pt.tolist())) == sorted((m, t) for m, mesh in enumerate(scenes.cbox_meshes()) for t in range(len(mesh.indices)))
+
+
+def test_two_sided_flip_and_emitter_orientation(built):
+    sc = orc.Scene(scenes.cbox(32, 32))
+    # floor seen from below (outside the box): diffuse is two-sided -> normals flipped towards the ray origin
+    up = sc.trace_full([0.0, -1.0, 0.0], [0.0, 1.0, 0.0])
+    assert up["mesh"] == 0 and up["n_s"][1] < 0 and up["wi"][2] > 0
+    down = sc.trace_full([0.0, 1.0, 0.0], [0.0, -1.0, 0.0])
+    assert down["mesh"] == 0 and down["n_s"][1] > 0 and down["wi"][2] > 0
+    # the light is NOT flipped: from behind wi.z < 0 (structure.rs:1006-1013)
+    behind = sc.trace_full([0.0, 1.99, 0.0], [0.0, -1.0, 0.0])
+    assert behind["mesh"] == 7 and behind["n_s"][1] < 0 and behind["wi"][2] < 0
+    front = sc.trace_full([0.0, 1.0, 0.0], [0.0, 1.0, 0.0])
+    assert front["mesh"] == 7 and front["wi"][2] > 0
+
+
+def test_light_sampling_record(built):
+    sc = orc.Scene(scenes.cbox(32, 32))
+    p = np.float32([0.1, 0.5, 0.2])
+    ls = sc.sample_light(p, 0.3, 0.7, 0.25, 0.6)
+    assert ls["emitter"] == 7 and abs(ls["p"][1] - 1.98) < 1e-6
+    assert -0.24 <= ls["p"][0] <= 0.23 and -0.22 <= ls["p"][2] <= 0.16
+    d = ls["p"] - p
+    dist = np.linalg.norm(d)
+    np.testing.assert_allclose(ls["d"], d / dist, rtol=1e-6)
+    area = 0.47 * 0.38
+    cos_l = max(0.0, float(np.dot(ls["n"], -ls["d"])))
+    np.testing.assert_allclose(ls["pdf"], (1 / area) * dist * dist / cos_l, rtol=1e-5)     # area pdf -> solid angle
+    np.testing.assert_allclose(ls["weight"], np.float32([17, 12, 4]) * (cos_l / dist ** 2) * area, rtol=1e-5)
+    # from above the light: geometry term 0 -> pdf 0, weight 0 (LightSampling::is_valid false)
+    ls2 = sc.sample_light(np.float32([0.0, 1.99, 0.0]), 0.3, 0.7, 0.25, 0.6)
+    assert ls2["pdf"] == 0 and not ls2["weight"].any()
+    # cdf.sample_discrete: r < 0.5 -> triangle 0, r >= 0.5 -> triangle 1 of the quad
+    a = sc.sample_light(p, 0.0, 0.49, 0.9, 0.5)["p"]
+    b = sc.sample_light(p, 0.0, 0.5, 0.9, 0.5)["p"]
+    assert not np.allclose(a, b)
+
+
+def test_diffuse_bsdf(built):
+    sc = orc.Scene(scenes.cbox(32, 32))
+    wi = np.float32([0.3, 0.1, 0.9])
+    wi /= np.linalg.norm(wi)
+    s = sc.bsdf_sample(3, wi, [0.3, 0.8])
+    assert s["pdf_kind"] == 0 and s["d"][2] > 0
+    np.testing.assert_allclose(s["weight"], [0.14, 0.45, 0.091], rtol=1e-6)
+    np.testing.assert_allclose(s["pdf"], s["d"][2] / np.pi, rtol=1e-6)
+    np.testing.assert_allclose(sc.bsdf_eval(3, wi, s["d"]), np.float32([0.14, 0.45, 0.091]) * s["d"][2] / np.pi, rtol=1e-6)
+    assert sc.bsdf_sample(3, -wi, [0.3, 0.8]) is None                   # wi.z <= 0 -> None
+    assert sc.bsdf_pdf(3, wi, [0.0, 0.0, -1.0]) == 0.0
+
+
+def test_golden_trace_vectors(built):
+    k = np.load(os.path.join(GOLD, "trace_cbox_kat.npz"))
+    sc = orc.Scene(scenes.cbox(64, 64))
+    got = sc.trace(k["o"], k["d"])
+    for g, name in zip(got, ["t", "u", "v", "mesh", "tri"]):
+        np.testing.assert_array_equal(g, k[name])
