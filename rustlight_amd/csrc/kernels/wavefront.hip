@@ -139,6 +139,25 @@ RL_DEV void block_stats(unsigned long long* partials, const int (&which)[N], con
     if (threadIdx.x < N && s_acc[threadIdx.x]) partials[(size_t)blockIdx.x * STAT_COUNT + which[threadIdx.x]] += s_acc[threadIdx.x];
 }
 
+// Block-local stream compaction with wave64 ballot + prefix popcount (no global atomics): the threads of a
+// workgroup whose slot satisfies `pred` are packed to the front, so the traversal / shading loops run on
+// full waves and the remaining waves exit at once.  `list` = 256 + 4 words of LDS.  Returns the number of
+// packed entries; thread `t < n` then works on slot `list[t]`.
+RL_DEV unsigned block_compact(bool pred, unsigned slot, unsigned* list) {
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long mask = __ballot(pred);
+    const unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
+    unsigned* wave_cnt = list + 256;
+    if (lane == 0u) wave_cnt[wave] = (unsigned)__popcll(mask);
+    __syncthreads();
+    unsigned base = 0, total = 0;
+#pragma unroll
+    for (unsigned w = 0; w < 4u; w++) { unsigned c = wave_cnt[w]; if (w < wave) base += c; total += c; }
+    if (pred) list[base + rank] = slot;
+    __syncthreads();
+    return total;
+}
+
 RL_DEV void block_geometry(const RenderConst& rc, unsigned b, unsigned* bx, unsigned* by, unsigned* bw, unsigned* bh) {
     *bx = (b / rc.nby) * 16u;            // block index b = (ix/16) * ceil(H/16) + iy/16 (mod.rs:357-358)
     *by = (b % rc.nby) * 16u;
@@ -241,11 +260,11 @@ __global__ void __launch_bounds__(256) k_raygen(RenderConst rc, DeviceScene sc, 
         n_draws += 2;
         n_samples++;
         storec(pool, slot, F_AR, acc);
-        storec(pool, slot, F_LR, czero());
         PU(U_SAMPLE) = s;
         PU(U_CURSOR) = cursor;
         const bool expand = (!rc.has_max || 1u < rc.max_depth);   // TechniquePathTracing::expand at depth 1
         if (!expand) {   // sensor not expanded: the sample is 0 (next raygen pass folds it)
+            storec(pool, slot, F_LR, czero());
             store_rng(pool, slot, Q_R0, rng);
             PU(U_FLAGS) = ST_REGEN;
             continue;
@@ -264,14 +283,9 @@ __global__ void __launch_bounds__(256) k_raygen(RenderConst rc, DeviceScene sc, 
         V3 d = mk3(((tw[0] * dl.x + tw[4] * dl.y) + tw[8] * dl.z) + tw[12] * 0.0f,
                    ((tw[1] * dl.x + tw[5] * dl.y) + tw[9] * dl.z) + tw[13] * 0.0f,
                    ((tw[2] * dl.x + tw[6] * dl.y) + tw[10] * dl.z) + tw[14] * 0.0f);
-        V3 o = mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]);
-        store3(pool, slot, F_OX, o);
+        // the sensor edge's state is implied by PREV_SENSOR and never stored: origin = Camera::position(),
+        // weight 1, rr_weight 1, PDF::SolidAngle(1), beta = thr = 1 (strategies/directional.rs:27-41)
         store3(pool, slot, F_DX, d);
-        storec(pool, slot, F_BR, cone());
-        storec(pool, slot, F_TR, cone());
-        storec(pool, slot, F_WR, cone());     // sensor edge: weight 1, rr 1, PDF::SolidAngle(1)
-        PF(F_RR) = 1.0f;
-        PF(F_PDF) = 1.0f;
         if (sc.medium.enabled) { PF(F_XI) = rng_next_f32(rng); n_draws++; }   // Edge::from_ray's medium.sample(ray, next())
         store_rng(pool, slot, Q_R0, rng);
         PU(U_DEPTH) = 1u;
@@ -295,10 +309,17 @@ __global__ void __launch_bounds__(256) k_extend(RenderConst rc, DeviceScene sc, 
         recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
         recs.tris = reinterpret_cast<const float4*>(sc.tris);
     }
-    int* stack = reinterpret_cast<int*>(stack_base) + threadIdx.x;
+    unsigned* list = reinterpret_cast<unsigned*>(stack_base);
+    int* stack = reinterpret_cast<int*>(list + 272) + threadIdx.x;
     unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot < pool.P && (PU(U_FLAGS) & ST_RAY)) {
-        V3 o = load3(pool, slot, F_OX), d = load3(pool, slot, F_DX);
+    unsigned flags = slot < pool.P ? PU(U_FLAGS) : 0u;
+    const unsigned n_live = block_compact((flags & ST_RAY) != 0u, slot, list);
+    if (threadIdx.x < n_live) {
+        slot = list[threadIdx.x];
+        flags = PU(U_FLAGS);
+        const bool primary = ((flags >> ST_PREV_SHIFT) & 3u) == PREV_SENSOR;    // camera rays start at Camera::position()
+        V3 o = primary ? mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]) : load3(pool, slot, F_OX);
+        V3 d = load3(pool, slot, F_DX);
         Hit hit; hit.t = kF32Max; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
         traverse<false>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
                         o, d, kEps, kF32Max, hit, stack, (int)blockDim.x);
@@ -320,9 +341,13 @@ __global__ void __launch_bounds__(256) k_shadow(RenderConst rc, DeviceScene sc, 
         recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
         recs.tris = reinterpret_cast<const float4*>(sc.tris);
     }
-    int* stack = reinterpret_cast<int*>(stack_base) + threadIdx.x;
+    unsigned* list = reinterpret_cast<unsigned*>(stack_base);
+    int* stack = reinterpret_cast<int*>(list + 272) + threadIdx.x;
     unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot < pool.P && (PU(U_FLAGS) & ST_SHADOW)) {
+    const unsigned flags = slot < pool.P ? PU(U_FLAGS) : 0u;
+    const unsigned n_live = block_compact((flags & ST_SHADOW) != 0u, slot, list);
+    if (threadIdx.x < n_live) {
+        slot = list[threadIdx.x];
         // Acceleration::visible(p0, p1) (accel.rs:316-343)
         V3 p0 = load3(pool, slot, F_OX), p1 = load3(pool, slot, F_SX);
         V3 d = p1 - p0;
@@ -330,6 +355,8 @@ __global__ void __launch_bounds__(256) k_shadow(RenderConst rc, DeviceScene sc, 
         d = d / len;
         float tfar = len * (1.0f - 0.00001f);
         Hit hit; hit.t = tfar; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
+        // traverse() starts with the root-box test: a segment that misses it is reported occluded
+        // only in the sense of "no hit found" => the caller below must treat a root miss as NOT visible
         V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
         float te;
         bool vis;
@@ -361,13 +388,15 @@ __global__ void __launch_bounds__(256) k_shade(RenderConst rc, DeviceScene sc, P
         const unsigned prev = (flags >> ST_PREV_SHIFT) & 3u;
         const unsigned depth = PU(U_DEPTH);          // generate()'s depth at which the edge's origin vertex was expanded
         const int prim = (int)PU(U_PRIM);
-        const V3 ro = load3(pool, slot, F_OX), rd = load3(pool, slot, F_DX);
+        const bool primary = prev == PREV_SENSOR;     // sensor edge: implied state, see k_raygen
+        const V3 ro = primary ? mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]) : load3(pool, slot, F_OX);
+        const V3 rd = load3(pool, slot, F_DX);
         const float t_hit = PF(F_T);
-        Col w_edge = loadc(pool, slot, F_WR);
-        const float rr = PF(F_RR);
-        const float pdf_edge = PF(F_PDF);
-        Col beta = loadc(pool, slot, F_BR);
-        Col L = loadc(pool, slot, F_LR);
+        Col w_edge = primary ? cone() : loadc(pool, slot, F_WR);
+        const float rr = primary ? 1.0f : PF(F_RR);
+        const float pdf_edge = primary ? 1.0f : PF(F_PDF);
+        Col beta = primary ? cone() : loadc(pool, slot, F_BR);
+        Col L = primary ? czero() : loadc(pool, slot, F_LR);
         bool zeroed = (flags & ST_ZEROED) != 0u;
         const bool hit = prim >= 0;
         bool is_volume = false;
@@ -424,7 +453,7 @@ __global__ void __launch_bounds__(256) k_shade(RenderConst rc, DeviceScene sc, P
             if (expand) {
                 n_vertices = 1;
                 Rng rng = load_rng(pool, slot, Q_R0);
-                Col thr = loadc(pool, slot, F_TR);
+                Col thr = primary ? cone() : loadc(pool, slot, F_TR);
                 const V3 vp = is_volume ? vpos : sp.p;
                 const V3 d_in = -rd;
                 // strategy 0: DirectionalSamplingStrategy::bounce (strategies/directional.rs:44-153)
@@ -521,7 +550,7 @@ __global__ void __launch_bounds__(256) k_shade(RenderConst rc, DeviceScene sc, P
             }
             storec(pool, slot, F_BR, beta);
             storec(pool, slot, F_LR, L);
-        }
+        } else if (primary) storec(pool, slot, F_LR, L);   // camera ray left the scene: the sample is 0
         PU(U_FLAGS) = new_flags;
     }
     {
@@ -763,7 +792,7 @@ static int ensure(T** p, size_t* cap, size_t n) {
 
 static size_t traversal_lds_bytes(const rl_context* ctx, bool lds_scene, unsigned block) {
     size_t stack = (size_t)2 * ctx->ds.stack_depth * block * sizeof(int);
-    return (lds_scene ? ctx->scene_lds_bytes : 0) + stack;
+    return (lds_scene ? ctx->scene_lds_bytes : 0) + 272 * sizeof(unsigned) + stack;   // [scene][compaction list][stacks]
 }
 
 template <int MAT>
