@@ -17,8 +17,8 @@
 //              its MIS weight (strategies/directional.rs, strategies/emitters.rs, path.rs:37-111)
 //   k_shadow   any-hit traversal for the NEE shadow rays (Acceleration::visible; accel.rs:316-343),
 //              adds the pre-weighted contribution to the path's radiance
-// plus k_sort (stream compaction / material binning with wave64 ballot + prefix) when the scene
-// mixes BSDF types.  Radiance is accumulated front-to-back (DESIGN.md §Radiance order).
+// (k_shade_sorted when the scene mixes BSDF types: block-local stream compaction + material sort with
+// wave64 ballot + prefix popcounts, then one packed pass per BSDF).  Radiance is accumulated front-to-back (DESIGN.md §Radiance order).
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -82,6 +82,19 @@ struct Counters {
     unsigned int next_item;     // work-item dispenser
     unsigned int pad[2];
 };
+
+// traversal stack configuration (see TravStack)
+struct StackConf { int lds_levels; int* overflow; size_t overflow_stride; };
+
+RL_DEV TravStack make_stack(const StackConf& sc_, unsigned* lds_after_list, size_t global_thread) {
+    TravStack st;
+    st.lds = reinterpret_cast<int*>(lds_after_list) + threadIdx.x;
+    st.lds_stride = (int)blockDim.x;
+    st.lds_levels = sc_.lds_levels;
+    st.glob = sc_.overflow ? sc_.overflow + global_thread : nullptr;
+    st.glob_stride = sc_.overflow_stride;
+    return st;
+}
 
 struct RenderConst {
     // IntegratorPathTracing fields (explicit/path.rs:14-20)
@@ -297,23 +310,24 @@ __global__ void __launch_bounds__(256) k_raygen(RenderConst rc, DeviceScene sc, 
 // ------------------------------------------------------------------------------------------
 // k_extend / k_shadow — traversal kernels.  Dynamic LDS = [staged scene] + per-lane stack.
 template <bool LDS_SCENE>
-__global__ void __launch_bounds__(256) k_extend(RenderConst rc, DeviceScene sc, Pool pool) {
+__global__ void __launch_bounds__(256) k_extend(RenderConst rc, DeviceScene sc, Pool pool, StackConf stc) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    // LDS layout: [staged scene (LDS_SCENE)] [compaction list 272 words] [per-lane stacks]
+    float4* after_scene = LDS_SCENE ? smem + 4 * (sc.n_nodes + sc.n_prims) : smem;
+    unsigned* list = reinterpret_cast<unsigned*>(after_scene);
+    unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const TravStack stack = make_stack(stc, list + 272, slot);
+    unsigned flags = slot < pool.P ? PU(U_FLAGS) : 0u;
+    const unsigned n_live = block_compact((flags & ST_RAY) != 0u, slot, list);
+    if (n_live == 0u) return;          // whole tile idle (finished pixels): skip the scene staging too
     SceneRecs recs;
-    float4* stack_base = smem;
     if (LDS_SCENE) {
         stage_scene_lds(sc, smem, smem + 4 * sc.n_nodes);
         recs.nodes = smem; recs.tris = smem + 4 * sc.n_nodes;
-        stack_base = smem + 4 * (sc.n_nodes + sc.n_prims);
     } else {
         recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
         recs.tris = reinterpret_cast<const float4*>(sc.tris);
     }
-    unsigned* list = reinterpret_cast<unsigned*>(stack_base);
-    int* stack = reinterpret_cast<int*>(list + 272) + threadIdx.x;
-    unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned flags = slot < pool.P ? PU(U_FLAGS) : 0u;
-    const unsigned n_live = block_compact((flags & ST_RAY) != 0u, slot, list);
     if (threadIdx.x < n_live) {
         slot = list[threadIdx.x];
         flags = PU(U_FLAGS);
@@ -322,30 +336,31 @@ __global__ void __launch_bounds__(256) k_extend(RenderConst rc, DeviceScene sc, 
         V3 d = load3(pool, slot, F_DX);
         Hit hit; hit.t = kF32Max; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
         traverse<false>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
-                        o, d, kEps, kF32Max, hit, stack, (int)blockDim.x);
+                        o, d, kEps, kF32Max, hit, stack);
         PF(F_T) = hit.t; PF(F_U) = hit.u; PF(F_V) = hit.v;
         PU(U_PRIM) = (unsigned)hit.prim;
     }
 }
 
 template <bool LDS_SCENE>
-__global__ void __launch_bounds__(256) k_shadow(RenderConst rc, DeviceScene sc, Pool pool) {
+__global__ void __launch_bounds__(256) k_shadow(RenderConst rc, DeviceScene sc, Pool pool, StackConf stc) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    // LDS layout: [staged scene (LDS_SCENE)] [compaction list 272 words] [per-lane stacks]
+    float4* after_scene = LDS_SCENE ? smem + 4 * (sc.n_nodes + sc.n_prims) : smem;
+    unsigned* list = reinterpret_cast<unsigned*>(after_scene);
+    unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const TravStack stack = make_stack(stc, list + 272, slot);
+    const unsigned flags = slot < pool.P ? PU(U_FLAGS) : 0u;
+    const unsigned n_live = block_compact((flags & ST_SHADOW) != 0u, slot, list);
+    if (n_live == 0u) return;          // whole tile idle (finished pixels): skip the scene staging too
     SceneRecs recs;
-    float4* stack_base = smem;
     if (LDS_SCENE) {
         stage_scene_lds(sc, smem, smem + 4 * sc.n_nodes);
         recs.nodes = smem; recs.tris = smem + 4 * sc.n_nodes;
-        stack_base = smem + 4 * (sc.n_nodes + sc.n_prims);
     } else {
         recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
         recs.tris = reinterpret_cast<const float4*>(sc.tris);
     }
-    unsigned* list = reinterpret_cast<unsigned*>(stack_base);
-    int* stack = reinterpret_cast<int*>(list + 272) + threadIdx.x;
-    unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned flags = slot < pool.P ? PU(U_FLAGS) : 0u;
-    const unsigned n_live = block_compact((flags & ST_SHADOW) != 0u, slot, list);
     if (threadIdx.x < n_live) {
         slot = list[threadIdx.x];
         // Acceleration::visible(p0, p1) (accel.rs:316-343)
@@ -364,195 +379,245 @@ __global__ void __launch_bounds__(256) k_shadow(RenderConst rc, DeviceScene sc, 
             vis = false;   // root box missed => "occluded" (accel.rs:338-340)
         else
             vis = !traverse<true>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
-                                  p0, d, kEps, tfar, hit, stack, (int)blockDim.x);
+                                  p0, d, kEps, tfar, hit, stack);
         if (vis) storec(pool, slot, F_LR, loadc(pool, slot, F_LR) + loadc(pool, slot, F_CR));
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// k_shade<MAT, MEDIUM> — one path vertex.  MAT >= 0: only slots whose hit material has that BSDF
-// type are processed, through `queue` (filled by k_sort) or directly when the scene has a single
-// BSDF type; MAT = -1: generic (run-time switch).  MEDIUM selects the volume code.
+// shade_slot<MAT, MEDIUM> — one path vertex of one slot.  MAT >= 0: the hit material is known to have that
+// BSDF type (per-BSDF code path, uniform over the calling lanes); MAT = -1: generic (run-time switch).
 template <int MAT, bool MEDIUM>
-__global__ void __launch_bounds__(256) k_shade(RenderConst rc, DeviceScene sc, Pool pool, const unsigned* queue, const unsigned* queue_count) {
-    unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned n_vertices = 0, n_draws = 0, n_shadow = 0, n_ext = 0;
-    bool live = false;
-    unsigned slot = idx;
-    if (queue) { if (idx < *queue_count) { slot = queue[idx]; live = true; } }
-    else if (idx < pool.P) live = true;
-    unsigned flags = 0;
-    if (live) { flags = PU(U_FLAGS); live = (flags & ST_RAY) != 0u; }
-    if (live) {
-        n_ext = 1;      // every shaded slot carried exactly one extension ray through k_extend
-        const unsigned prev = (flags >> ST_PREV_SHIFT) & 3u;
-        const unsigned depth = PU(U_DEPTH);          // generate()'s depth at which the edge's origin vertex was expanded
-        const int prim = (int)PU(U_PRIM);
-        const bool primary = prev == PREV_SENSOR;     // sensor edge: implied state, see k_raygen
-        const V3 ro = primary ? mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]) : load3(pool, slot, F_OX);
-        const V3 rd = load3(pool, slot, F_DX);
-        const float t_hit = PF(F_T);
-        Col w_edge = primary ? cone() : loadc(pool, slot, F_WR);
-        const float rr = primary ? 1.0f : PF(F_RR);
-        const float pdf_edge = primary ? 1.0f : PF(F_PDF);
-        Col beta = primary ? cone() : loadc(pool, slot, F_BR);
-        Col L = primary ? czero() : loadc(pool, slot, F_LR);
-        bool zeroed = (flags & ST_ZEROED) != 0u;
-        const bool hit = prim >= 0;
-        bool is_volume = false;
-        V3 vpos = mk3(0.0f, 0.0f, 0.0f);
-        if (MEDIUM) {
-            // Edge::from_ray (paths/edge.rs:93-162): distance sampling up to the surface (or infinity on a miss)
-            MediumSample ms = medium_sample(sc.medium, hit ? t_hit : kF32Max, PF(F_XI));
-            w_edge = w_edge * ms.w;
-            is_volume = !hit || !ms.exited;
-            if (is_volume) vpos = ro + rd * ms.t;
-        }
-        bool ended = false;
-        if (!MEDIUM && !hit) ended = true;           // edge without a next vertex; environment luminance is 0
-        unsigned new_flags = ST_REGEN;
-        if (!ended) {
-            const Col W = w_edge * rr;                // edge.weight * edge.rr_weight (Color * f32, guarded)
-            SurfacePoint sp;
-            const Material* mat = nullptr;
-            MeshRecord mr;
-            if (!is_volume) {
-                sp = fill_intersection(sc, prim, PF(F_U), PF(F_V), ro, rd, t_hit);
-                mr = sc.meshes[sp.mesh];
-                mat = &sc.materials[mr.material];
-            }
-            // ---- contribution carried by the arriving edge (Edge::contribution -> Vertex::contribution)
-            Col emit = czero();
-            if (!is_volume && (mr.flags & MESH_IS_LIGHT) && dot(sp.n_s, -rd) >= 0.0f) emit = mkc(mr.emission[0], mr.emission[1], mr.emission[2]);
-            Col contrib = W * emit;
-            const unsigned cur = depth - 1u;          // evaluate()'s curr_depth of the origin vertex
-            const bool add_contrib = rc.has_min ? cur >= rc.min_depth : true;
-            if (prev == PREV_SENSOR) {
-                if (!is_zero(contrib) && add_contrib) L = L + contrib;              // path.rs:152-166 (no MIS)
-            } else if (!zeroed) {
-                if (rc.strategy == RL_STRATEGY_EMITTER) contrib = czero();          // id_sampling 0 != 1
-                if (!is_zero(contrib) && add_contrib) {
-                    float wmis = 1.0f;
-                    if (rc.strategy == RL_STRATEGY_ALL && (flags & ST_PDF_SA)) {
-                        // LightSamplingStrategy::pdf -> pdf_emitter (strategies/emitters.rs:10-92,250-282)
-                        float p2 = 0.0f;
-                        if (!is_volume && (mr.flags & MESH_IS_LIGHT) && (prev == PREV_SURFACE || prev == PREV_VOLUME))
-                            p2 = light_direct_pdf(mr, ro, sp.p, sp.n_g, rd);
-                        float total = (0.0f + pdf_edge) + p2;
-                        wmis = div_rn(pdf_edge, total);                             // balance heuristic (path.rs:80-98)
-                    }
-                    L = L + beta * (contrib * wmis);
-                }
-            }
-            beta = beta * W;
-            if (rc.single_scattering && !is_volume) zeroed = true;                  // evaluate(): surface vertex => subtree is 0
-
-            // ---- expand the new vertex (generate(), strategies/mod.rs:35-80)
-            const unsigned gen = depth + 1u;
-            const bool expand = (rc.has_max ? gen < rc.max_depth : true) && gen < kDepthCap;
-            if (expand) {
-                n_vertices = 1;
-                Rng rng = load_rng(pool, slot, Q_R0);
-                Col thr = primary ? cone() : loadc(pool, slot, F_TR);
-                const V3 vp = is_volume ? vpos : sp.p;
-                const V3 d_in = -rd;
-                // strategy 0: DirectionalSamplingStrategy::bounce (strategies/directional.rs:44-153)
-                V2 s2; s2.x = rng_next_f32(rng); s2.y = rng_next_f32(rng);
-                n_draws += 2;
-                bool has_edge = false;
-                bool sampled = false;
-                Col sw = czero(); V3 sd_world = mk3(0.0f, 0.0f, 0.0f); float spdf = 0.0f; int spdf_kind = PDF_SOLID_ANGLE;
-                if (is_volume) {
-                    phase_sample(sc.medium, d_in, s2, &sd_world, &sw, &spdf);
-                    sampled = true;
-                } else {
-                    BsdfSample bs;
-                    if (bsdf_sample<MAT>(sc, *mat, sp.has_uv, sp.uv, sp.wi, s2, &bs)) {
-                        sampled = true;
-                        sw = bs.weight; spdf = bs.pdf; spdf_kind = bs.pdf_kind;
-                        sd_world = to_world(sp.frame, bs.d);
-                    }
-                }
-                float rr_new = 1.0f;
-                if (sampled) {
-                    thr = thr * sw;
-                    if (!is_zero(thr)) {
-                        const bool do_rr = rc.has_rr ? rc.rr_depth <= gen : true;
-                        bool alive = true;
-                        if (do_rr) {
-                            float q = rmin(channel_max(thr), 0.95f);
-                            float x = rng_next_f32(rng);
-                            n_draws++;
-                            if (q < x) alive = false; else rr_new = div_rn(1.0f, q);
-                        }
-                        if (alive) {
-                            thr = scale_unguarded(thr, rr_new);
-                            has_edge = true;
-                            if (MEDIUM) { PF(F_XI) = rng_next_f32(rng); n_draws++; }   // the new edge's medium.sample draw
-                        }
-                    }
-                }
-                // strategy 1: LightSamplingStrategy::sample (strategies/emitters.rs:95-248)
-                const bool use_light = rc.strategy != RL_STRATEGY_BSDF;
-                const bool smooth = !is_volume && mat->smooth;
-                bool shadow = false;
-                if (use_light && !smooth) {
-                    float a = rng_next_f32(rng);
-                    float b = rng_next_f32(rng);
-                    V2 c; c.x = rng_next_f32(rng); c.y = rng_next_f32(rng);
-                    n_draws += 4;
-                    n_shadow = 1;     // the reference always traces the shadow ray (emitters.rs:125-126)
-                    LightSample ls = sample_light(sc, vp, a, b, c);
-                    if (ls.pdf != 0.0f) {
-                        Col wl;
-                        float p_dir;
-                        if (is_volume) { wl = phase_eval(sc.medium, d_in, ls.d); p_dir = phase_pdf(sc.medium, d_in, ls.d); }
-                        else {
-                            V3 wo = to_local(sp.frame, ls.d);
-                            wl = bsdf_eval<MAT>(sc, *mat, sp.has_uv, sp.uv, sp.wi, wo, false);
-                            p_dir = bsdf_pdf<MAT>(sc, *mat, sp.has_uv, sp.uv, sp.wi, wo, false);
-                        }
-                        if (MEDIUM) {
-                            V3 dd = ls.p - vp;
-                            wl = wl * medium_transmittance(sc.medium, dot(dd, ls.d));
-                        }
-                        Col c_l = ls.weight * wl * 1.0f;                       // contrib * weight * rr_weight (edge.rs:204)
-                        const bool add_l = rc.has_min ? (gen - 1u) >= rc.min_depth : true;
-                        if (!zeroed && !is_zero(c_l) && add_l) {
-                            float wmis = 1.0f;
-                            if (rc.strategy == RL_STRATEGY_ALL) {              // ls.pdf is a solid-angle pdf for mesh lights
-                                float total = (0.0f + p_dir) + ls.pdf;
-                                wmis = div_rn(ls.pdf, total);
-                            }
-                            Col pending = beta * (c_l * wmis);
-                            // a zero contribution needs no visibility test: the image cannot change
-                            if (!is_zero(pending)) {
-                                shadow = true;
-                                store3(pool, slot, F_SX, ls.p);
-                                storec(pool, slot, F_CR, pending);
-                            }
-                        }
-                    }
-                }
-                store_rng(pool, slot, Q_R0, rng);
-                store3(pool, slot, F_OX, vp);
-                new_flags = shadow ? ST_SHADOW : 0u;
-                if (has_edge) {
-                    store3(pool, slot, F_DX, sd_world);
-                    storec(pool, slot, F_TR, thr);
-                    storec(pool, slot, F_WR, sw);
-                    PF(F_RR) = rr_new;
-                    PF(F_PDF) = spdf;
-                    PU(U_DEPTH) = gen;
-                    const unsigned kind = is_volume ? PREV_VOLUME : (smooth ? PREV_SURFACE_SMOOTH : PREV_SURFACE);
-                    new_flags |= ST_RAY | (kind << ST_PREV_SHIFT) | (spdf_kind == PDF_SOLID_ANGLE ? ST_PDF_SA : 0u) | (zeroed ? ST_ZEROED : 0u);
-                } else new_flags |= ST_REGEN;
-            }
-            storec(pool, slot, F_BR, beta);
-            storec(pool, slot, F_LR, L);
-        } else if (primary) storec(pool, slot, F_LR, L);   // camera ray left the scene: the sample is 0
-        PU(U_FLAGS) = new_flags;
+RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, const Pool& pool, unsigned slot, unsigned flags,
+                       unsigned& n_vertices, unsigned& n_draws, unsigned& n_shadow, unsigned& n_ext) {
+    n_ext += 1;      // every shaded slot carried exactly one extension ray through k_extend
+    const unsigned prev = (flags >> ST_PREV_SHIFT) & 3u;
+    const unsigned depth = PU(U_DEPTH);          // generate()'s depth at which the edge's origin vertex was expanded
+    const int prim = (int)PU(U_PRIM);
+    const bool primary = prev == PREV_SENSOR;     // sensor edge: implied state, see k_raygen
+    const V3 ro = primary ? mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]) : load3(pool, slot, F_OX);
+    const V3 rd = load3(pool, slot, F_DX);
+    const float t_hit = PF(F_T);
+    Col w_edge = primary ? cone() : loadc(pool, slot, F_WR);
+    const float rr = primary ? 1.0f : PF(F_RR);
+    const float pdf_edge = primary ? 1.0f : PF(F_PDF);
+    Col beta = primary ? cone() : loadc(pool, slot, F_BR);
+    Col L = primary ? czero() : loadc(pool, slot, F_LR);
+    bool zeroed = (flags & ST_ZEROED) != 0u;
+    const bool hit = prim >= 0;
+    bool is_volume = false;
+    V3 vpos = mk3(0.0f, 0.0f, 0.0f);
+    if (MEDIUM) {
+        // Edge::from_ray (paths/edge.rs:93-162): distance sampling up to the surface (or infinity on a miss)
+        MediumSample ms = medium_sample(sc.medium, hit ? t_hit : kF32Max, PF(F_XI));
+        w_edge = w_edge * ms.w;
+        is_volume = !hit || !ms.exited;
+        if (is_volume) vpos = ro + rd * ms.t;
     }
+    bool ended = false;
+    if (!MEDIUM && !hit) ended = true;           // edge without a next vertex; environment luminance is 0
+    unsigned new_flags = ST_REGEN;
+    if (!ended) {
+        const Col W = w_edge * rr;                // edge.weight * edge.rr_weight (Color * f32, guarded)
+        SurfacePoint sp;
+        const Material* mat = nullptr;
+        MeshRecord mr;
+        if (!is_volume) {
+            sp = fill_intersection(sc, prim, PF(F_U), PF(F_V), ro, rd, t_hit);
+            mr = sc.meshes[sp.mesh];
+            mat = &sc.materials[mr.material];
+        }
+        // ---- contribution carried by the arriving edge (Edge::contribution -> Vertex::contribution)
+        Col emit = czero();
+        if (!is_volume && (mr.flags & MESH_IS_LIGHT) && dot(sp.n_s, -rd) >= 0.0f) emit = mkc(mr.emission[0], mr.emission[1], mr.emission[2]);
+        Col contrib = W * emit;
+        const unsigned cur = depth - 1u;          // evaluate()'s curr_depth of the origin vertex
+        const bool add_contrib = rc.has_min ? cur >= rc.min_depth : true;
+        if (prev == PREV_SENSOR) {
+            if (!is_zero(contrib) && add_contrib) L = L + contrib;              // path.rs:152-166 (no MIS)
+        } else if (!zeroed) {
+            if (rc.strategy == RL_STRATEGY_EMITTER) contrib = czero();          // id_sampling 0 != 1
+            if (!is_zero(contrib) && add_contrib) {
+                float wmis = 1.0f;
+                if (rc.strategy == RL_STRATEGY_ALL && (flags & ST_PDF_SA)) {
+                    // LightSamplingStrategy::pdf -> pdf_emitter (strategies/emitters.rs:10-92,250-282)
+                    float p2 = 0.0f;
+                    if (!is_volume && (mr.flags & MESH_IS_LIGHT) && (prev == PREV_SURFACE || prev == PREV_VOLUME))
+                        p2 = light_direct_pdf(mr, ro, sp.p, sp.n_g, rd);
+                    float total = (0.0f + pdf_edge) + p2;
+                    wmis = div_rn(pdf_edge, total);                             // balance heuristic (path.rs:80-98)
+                }
+                L = L + beta * (contrib * wmis);
+            }
+        }
+        beta = beta * W;
+        if (rc.single_scattering && !is_volume) zeroed = true;                  // evaluate(): surface vertex => subtree is 0
+
+        // ---- expand the new vertex (generate(), strategies/mod.rs:35-80)
+        const unsigned gen = depth + 1u;
+        const bool expand = (rc.has_max ? gen < rc.max_depth : true) && gen < kDepthCap;
+        if (expand) {
+            n_vertices += 1;
+            Rng rng = load_rng(pool, slot, Q_R0);
+            Col thr = primary ? cone() : loadc(pool, slot, F_TR);
+            const V3 vp = is_volume ? vpos : sp.p;
+            const V3 d_in = -rd;
+            // strategy 0: DirectionalSamplingStrategy::bounce (strategies/directional.rs:44-153)
+            V2 s2; s2.x = rng_next_f32(rng); s2.y = rng_next_f32(rng);
+            n_draws += 2;
+            bool has_edge = false;
+            bool sampled = false;
+            Col sw = czero(); V3 sd_world = mk3(0.0f, 0.0f, 0.0f); float spdf = 0.0f; int spdf_kind = PDF_SOLID_ANGLE;
+            if (is_volume) {
+                phase_sample(sc.medium, d_in, s2, &sd_world, &sw, &spdf);
+                sampled = true;
+            } else {
+                BsdfSample bs;
+                if (bsdf_sample<MAT>(sc, *mat, sp.has_uv, sp.uv, sp.wi, s2, &bs)) {
+                    sampled = true;
+                    sw = bs.weight; spdf = bs.pdf; spdf_kind = bs.pdf_kind;
+                    sd_world = to_world(sp.frame, bs.d);
+                }
+            }
+            float rr_new = 1.0f;
+            if (sampled) {
+                thr = thr * sw;
+                if (!is_zero(thr)) {
+                    const bool do_rr = rc.has_rr ? rc.rr_depth <= gen : true;
+                    bool alive = true;
+                    if (do_rr) {
+                        float q = rmin(channel_max(thr), 0.95f);
+                        float x = rng_next_f32(rng);
+                        n_draws++;
+                        if (q < x) alive = false; else rr_new = div_rn(1.0f, q);
+                    }
+                    if (alive) {
+                        thr = scale_unguarded(thr, rr_new);
+                        has_edge = true;
+                        if (MEDIUM) { PF(F_XI) = rng_next_f32(rng); n_draws++; }   // the new edge's medium.sample draw
+                    }
+                }
+            }
+            // strategy 1: LightSamplingStrategy::sample (strategies/emitters.rs:95-248)
+            const bool use_light = rc.strategy != RL_STRATEGY_BSDF;
+            const bool smooth = !is_volume && mat->smooth;
+            bool shadow = false;
+            if (use_light && !smooth) {
+                float a = rng_next_f32(rng);
+                float b = rng_next_f32(rng);
+                V2 c; c.x = rng_next_f32(rng); c.y = rng_next_f32(rng);
+                n_draws += 4;
+                n_shadow += 1;     // the reference always traces the shadow ray (emitters.rs:125-126)
+                LightSample ls = sample_light(sc, vp, a, b, c);
+                if (ls.pdf != 0.0f) {
+                    Col wl;
+                    float p_dir;
+                    if (is_volume) { wl = phase_eval(sc.medium, d_in, ls.d); p_dir = phase_pdf(sc.medium, d_in, ls.d); }
+                    else {
+                        V3 wo = to_local(sp.frame, ls.d);
+                        wl = bsdf_eval<MAT>(sc, *mat, sp.has_uv, sp.uv, sp.wi, wo, false);
+                        p_dir = bsdf_pdf<MAT>(sc, *mat, sp.has_uv, sp.uv, sp.wi, wo, false);
+                    }
+                    if (MEDIUM) {
+                        V3 dd = ls.p - vp;
+                        wl = wl * medium_transmittance(sc.medium, dot(dd, ls.d));
+                    }
+                    Col c_l = ls.weight * wl * 1.0f;                       // contrib * weight * rr_weight (edge.rs:204)
+                    const bool add_l = rc.has_min ? (gen - 1u) >= rc.min_depth : true;
+                    if (!zeroed && !is_zero(c_l) && add_l) {
+                        float wmis = 1.0f;
+                        if (rc.strategy == RL_STRATEGY_ALL) {              // ls.pdf is a solid-angle pdf for mesh lights
+                            float total = (0.0f + p_dir) + ls.pdf;
+                            wmis = div_rn(ls.pdf, total);
+                        }
+                        Col pending = beta * (c_l * wmis);
+                        // a zero contribution needs no visibility test: the image cannot change
+                        if (!is_zero(pending)) {
+                            shadow = true;
+                            store3(pool, slot, F_SX, ls.p);
+                            storec(pool, slot, F_CR, pending);
+                        }
+                    }
+                }
+            }
+            store_rng(pool, slot, Q_R0, rng);
+            store3(pool, slot, F_OX, vp);
+            new_flags = shadow ? ST_SHADOW : 0u;
+            if (has_edge) {
+                store3(pool, slot, F_DX, sd_world);
+                storec(pool, slot, F_TR, thr);
+                storec(pool, slot, F_WR, sw);
+                PF(F_RR) = rr_new;
+                PF(F_PDF) = spdf;
+                PU(U_DEPTH) = gen;
+                const unsigned kind = is_volume ? PREV_VOLUME : (smooth ? PREV_SURFACE_SMOOTH : PREV_SURFACE);
+                new_flags |= ST_RAY | (kind << ST_PREV_SHIFT) | (spdf_kind == PDF_SOLID_ANGLE ? ST_PDF_SA : 0u) | (zeroed ? ST_ZEROED : 0u);
+            } else new_flags |= ST_REGEN;
+        }
+        storec(pool, slot, F_BR, beta);
+        storec(pool, slot, F_LR, L);
+    } else if (primary) storec(pool, slot, F_LR, L);   // camera ray left the scene: the sample is 0
+    PU(U_FLAGS) = new_flags;
+}
+
+// k_shade<MAT, MEDIUM>: scenes with a single BSDF type — every live slot goes straight to that BSDF's code.
+template <int MAT, bool MEDIUM>
+__global__ void __launch_bounds__(256) k_shade(RenderConst rc, DeviceScene sc, Pool pool) {
+    unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned n_vertices = 0, n_draws = 0, n_shadow = 0, n_ext = 0;
+    unsigned flags = slot < pool.P ? PU(U_FLAGS) : 0u;
+    if (flags & ST_RAY) shade_slot<MAT, MEDIUM>(rc, sc, pool, slot, flags, n_vertices, n_draws, n_shadow, n_ext);
+    {
+        const int which[4] = {STAT_VERTICES, STAT_DRAWS, STAT_SHADOW_RAYS, STAT_EXT_RAYS};
+        const unsigned vals[4] = {n_vertices, n_draws, n_shadow, n_ext};
+        block_stats<4>(rc.partials, which, vals);
+    }
+}
+
+// k_shade_sorted<MEDIUM>: mixed-material scenes.  Stream compaction + material sort with wave64 ballot and
+// prefix popcounts, local to the workgroup's 256 slots (no global atomics, no queue in HBM): live slots are
+// binned by the BSDF type of the surface they hit, then each BSDF's code runs once over its packed bin, so
+// a wave never mixes two BSDFs.
+static constexpr int kNumBins = 5;
+template <bool MEDIUM>
+__global__ void __launch_bounds__(256) k_shade_sorted(RenderConst rc, DeviceScene sc, Pool pool) {
+    __shared__ unsigned s_list[256];
+    __shared__ unsigned s_wave_cnt[kNumBins][4];
+    unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned n_vertices = 0, n_draws = 0, n_shadow = 0, n_ext = 0;
+    const unsigned flags = slot < pool.P ? PU(U_FLAGS) : 0u;
+    int bin = -1;
+    if (flags & ST_RAY) {
+        const int prim = (int)PU(U_PRIM);
+        bin = 0;
+        if (prim >= 0) bin = sc.materials[sc.meshes[sc.tris[prim].mesh].material].type;
+    }
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned rank = 0;
+#pragma unroll
+    for (int b = 0; b < kNumBins; b++) {
+        const unsigned long long mask = __ballot(bin == b);
+        if (bin == b) rank = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0u) s_wave_cnt[b][wave] = (unsigned)__popcll(mask);
+    }
+    __syncthreads();
+    unsigned bin_begin[kNumBins + 1];
+    unsigned my_off = 0, run = 0;
+#pragma unroll
+    for (int b = 0; b < kNumBins; b++) {
+        bin_begin[b] = run;
+#pragma unroll
+        for (unsigned w = 0; w < 4u; w++) { if (b == bin && w == wave) my_off = run; run += s_wave_cnt[b][w]; }
+    }
+    bin_begin[kNumBins] = run;
+    if (bin >= 0) s_list[my_off + rank] = slot;
+    __syncthreads();
+#define RL_SHADE_BIN(B)                                                                                       \
+    { const unsigned n = bin_begin[(B) + 1] - bin_begin[B];                                                   \
+      if (threadIdx.x < n) { const unsigned sl = s_list[bin_begin[B] + threadIdx.x];                           \
+          shade_slot<B, MEDIUM>(rc, sc, pool, sl, pool.u[(size_t)U_FLAGS * pool.P + sl], n_vertices, n_draws, n_shadow, n_ext); } }
+    RL_SHADE_BIN(0) RL_SHADE_BIN(1) RL_SHADE_BIN(2) RL_SHADE_BIN(3) RL_SHADE_BIN(4)
+#undef RL_SHADE_BIN
     {
         const int which[4] = {STAT_VERTICES, STAT_DRAWS, STAT_SHADOW_RAYS, STAT_EXT_RAYS};
         const unsigned vals[4] = {n_vertices, n_draws, n_shadow, n_ext};
@@ -561,61 +626,32 @@ __global__ void __launch_bounds__(256) k_shade(RenderConst rc, DeviceScene sc, P
 }
 
 // ------------------------------------------------------------------------------------------
-// k_sort — stream compaction + material binning after k_extend: every live slot is appended to the
-// queue of its hit material's BSDF type (misses and volume-only slots go to queue 0).  One
-// atomic per wave per bin: wave64 ballot + mbcnt prefix.
-static constexpr int kNumBins = 5;
-__global__ void __launch_bounds__(256) k_sort(DeviceScene sc, Pool pool, unsigned* queues, unsigned* counts) {
-    unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
-    int bin = -1;
-    if (slot < pool.P && (PU(U_FLAGS) & ST_RAY)) {
-        int prim = (int)PU(U_PRIM);
-        bin = 0;
-        if (prim >= 0) {
-            int mesh_id = sc.tris[prim].mesh;
-            bin = sc.materials[sc.meshes[mesh_id].material].type;
-        }
-    }
-    for (int b = 0; b < kNumBins; b++) {
-        unsigned long long mask = __ballot(bin == b);
-        if (mask == 0ull) continue;
-        unsigned lane = threadIdx.x & 63u;
-        unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
-        unsigned base = 0;
-        int leader = __ffsll((long long)mask) - 1;
-        if ((int)lane == leader) base = atomicAdd(&counts[b], (unsigned)__popcll(mask));
-        base = __shfl(base, leader, 64);
-        if (bin == b) queues[(size_t)b * pool.P + base + rank] = slot;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // operator-level kernels: batched Acceleration::trace / visible for the parity tests
-__global__ void __launch_bounds__(256) k_trace_batch(DeviceScene sc, unsigned n, const float* o, const float* d, float* t_out, float* u_out,
+__global__ void __launch_bounds__(256) k_trace_batch(DeviceScene sc, StackConf stc, unsigned n, const float* o, const float* d, float* t_out, float* u_out,
                                                      float* v_out, int* mesh_out, int* tri_out) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneRecs recs;
     recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
     recs.tris = reinterpret_cast<const float4*>(sc.tris);
-    int* stack = reinterpret_cast<int*>(smem) + threadIdx.x;
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    const TravStack stack = make_stack(stc, reinterpret_cast<unsigned*>(smem), i);
     if (i >= n) return;
     V3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     Hit hit; hit.t = kF32Max; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
     traverse<false>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
-                    ro, rd, kEps, kF32Max, hit, stack, (int)blockDim.x);
+                    ro, rd, kEps, kF32Max, hit, stack);
     t_out[i] = hit.t; u_out[i] = hit.u; v_out[i] = hit.v;
     if (hit.prim >= 0) { mesh_out[i] = sc.tris[hit.prim].mesh; tri_out[i] = sc.tris[hit.prim].tri; }
     else { mesh_out[i] = -1; tri_out[i] = -1; }
 }
 
-__global__ void __launch_bounds__(256) k_visible_batch(DeviceScene sc, unsigned n, const float* p0a, const float* p1a, unsigned char* out) {
+__global__ void __launch_bounds__(256) k_visible_batch(DeviceScene sc, StackConf stc, unsigned n, const float* p0a, const float* p1a, unsigned char* out) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneRecs recs;
     recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
     recs.tris = reinterpret_cast<const float4*>(sc.tris);
-    int* stack = reinterpret_cast<int*>(smem) + threadIdx.x;
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    const TravStack stack = make_stack(stc, reinterpret_cast<unsigned*>(smem), i);
     if (i >= n) return;
     V3 p0 = mk3(p0a[3 * i], p0a[3 * i + 1], p0a[3 * i + 2]), p1 = mk3(p1a[3 * i], p1a[3 * i + 1], p1a[3 * i + 2]);
     V3 d = p1 - p0;
@@ -624,7 +660,7 @@ __global__ void __launch_bounds__(256) k_visible_batch(DeviceScene sc, unsigned 
     float tfar = len * (1.0f - 0.00001f);
     Hit hit; hit.t = tfar; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
     bool occluded = traverse<true>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
-                                   p0, d, kEps, tfar, hit, stack, (int)blockDim.x);
+                                   p0, d, kEps, tfar, hit, stack);
     V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
     float te;
     bool root_hit = slab(mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]), p0, inv_d, kEps, tfar, &te);
@@ -689,6 +725,7 @@ struct rl_context {
     Counters* d_counters = nullptr;
     Counters* h_counters = nullptr;   // pinned
     unsigned long long* d_partials = nullptr; size_t partials_capacity = 0;
+    int* d_overflow = nullptr; size_t overflow_capacity = 0;
     std::vector<hipEvent_t> events;
     BvhBuild bvh_dump;                // kept for rl_debug_bvh
 };
@@ -772,7 +809,7 @@ extern "C" void rl_context_destroy(rl_context* ctx) {
     hipSetDevice(ctx->device);
     for (void* p : ctx->allocs) hipFree(p);
     void* scratch[] = {ctx->pool.f, ctx->pool.u, ctx->pool.q, ctx->d_owned, ctx->d_item_base, ctx->d_block_seeds, ctx->d_item_seed,
-                       ctx->d_item_pixel, ctx->d_queues, ctx->d_qcounts, ctx->d_out, ctx->d_counters, ctx->d_partials};
+                       ctx->d_item_pixel, ctx->d_queues, ctx->d_qcounts, ctx->d_out, ctx->d_counters, ctx->d_partials, ctx->d_overflow};
     for (void* p : scratch) if (p) hipFree(p);
     if (ctx->h_counters) hipHostFree(ctx->h_counters);
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
@@ -790,26 +827,43 @@ static int ensure(T** p, size_t* cap, size_t n) {
     return RL_OK;
 }
 
-static size_t traversal_lds_bytes(const rl_context* ctx, bool lds_scene, unsigned block) {
-    size_t stack = (size_t)2 * ctx->ds.stack_depth * block * sizeof(int);
-    return (lds_scene ? ctx->scene_lds_bytes : 0) + 272 * sizeof(unsigned) + stack;   // [scene][compaction list][stacks]
+static constexpr int kLdsStackLevels = 12;
+static int lds_levels_of(const rl_context* ctx) { return std::min<int>((int)ctx->ds.stack_depth, kLdsStackLevels); }
+static size_t traversal_lds_bytes(const rl_context* ctx, bool lds_scene, unsigned block, bool with_list) {
+    size_t stack = (size_t)2 * lds_levels_of(ctx) * block * sizeof(int);
+    return (lds_scene ? ctx->scene_lds_bytes : 0) + (with_list ? 272 * sizeof(unsigned) : 0) + stack;   // [scene][compaction list][stacks]
+}
+// overflow levels beyond the LDS part, [2 * levels][n_threads] ints
+static int stack_conf(rl_context* ctx, size_t n_threads, StackConf* out) {
+    out->lds_levels = lds_levels_of(ctx);
+    out->overflow = nullptr;
+    out->overflow_stride = n_threads;
+    int extra = (int)ctx->ds.stack_depth - out->lds_levels;
+    if (extra > 0) {
+        size_t need = (size_t)2 * extra * n_threads;
+        if (ctx->overflow_capacity < need) {
+            if (ctx->d_overflow) hipFree(ctx->d_overflow);
+            ctx->d_overflow = nullptr;
+            HIP_OK(hipMalloc((void**)&ctx->d_overflow, need * sizeof(int)));
+            ctx->overflow_capacity = need;
+        }
+        out->overflow = ctx->d_overflow;
+    }
+    return RL_OK;
 }
 
 template <int MAT>
-static void launch_shade(bool medium, dim3 grid, dim3 block, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const Pool& pool,
-                         const unsigned* queue, const unsigned* count) {
-    if (medium) hipLaunchKernelGGL((k_shade<MAT, true>), grid, block, 0, st, rc, ds, pool, queue, count);
-    else hipLaunchKernelGGL((k_shade<MAT, false>), grid, block, 0, st, rc, ds, pool, queue, count);
+static void launch_shade(bool medium, dim3 grid, dim3 block, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const Pool& pool) {
+    if (medium) hipLaunchKernelGGL((k_shade<MAT, true>), grid, block, 0, st, rc, ds, pool);
+    else hipLaunchKernelGGL((k_shade<MAT, false>), grid, block, 0, st, rc, ds, pool);
 }
-static void launch_shade_type(int type, bool medium, dim3 grid, dim3 block, hipStream_t st, const RenderConst& rc, const DeviceScene& ds,
-                              const Pool& pool, const unsigned* queue, const unsigned* count) {
+static void launch_shade_type(int type, bool medium, dim3 grid, dim3 block, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const Pool& pool) {
     switch (type) {
-        case BSDF_DIFFUSE: launch_shade<BSDF_DIFFUSE>(medium, grid, block, st, rc, ds, pool, queue, count); break;
-        case BSDF_PHONG: launch_shade<BSDF_PHONG>(medium, grid, block, st, rc, ds, pool, queue, count); break;
-        case BSDF_METAL: launch_shade<BSDF_METAL>(medium, grid, block, st, rc, ds, pool, queue, count); break;
-        case BSDF_GLASS: launch_shade<BSDF_GLASS>(medium, grid, block, st, rc, ds, pool, queue, count); break;
-        case BSDF_SUBSTRATE: launch_shade<BSDF_SUBSTRATE>(medium, grid, block, st, rc, ds, pool, queue, count); break;
-        default: launch_shade<-1>(medium, grid, block, st, rc, ds, pool, queue, count); break;
+        case BSDF_DIFFUSE: launch_shade<BSDF_DIFFUSE>(medium, grid, block, st, rc, ds, pool); break;
+        case BSDF_PHONG: launch_shade<BSDF_PHONG>(medium, grid, block, st, rc, ds, pool); break;
+        case BSDF_METAL: launch_shade<BSDF_METAL>(medium, grid, block, st, rc, ds, pool); break;
+        case BSDF_GLASS: launch_shade<BSDF_GLASS>(medium, grid, block, st, rc, ds, pool); break;
+        default: launch_shade<BSDF_SUBSTRATE>(medium, grid, block, st, rc, ds, pool); break;
     }
 }
 
@@ -866,10 +920,6 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     Pool pool = ctx->pool;
     pool.P = P;
     const bool use_sort = !ctx->single_bsdf;
-    if (use_sort) {
-        if ((rcode = ensure(&ctx->d_queues, &ctx->queue_capacity, (size_t)kNumBins * P)) != RL_OK) return rcode;
-        if (!ctx->d_qcounts) HIP_OK(hipMalloc((void**)&ctx->d_qcounts, kNumBins * sizeof(unsigned)));
-    }
     float* d_out = out_rgb;
     if (!out_is_device) {
         if ((rcode = ensure(&ctx->d_out, &ctx->out_capacity, (size_t)3 * W * H)) != RL_OK) return rcode;
@@ -912,7 +962,9 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
     const dim3 grid_persistent(std::min<unsigned>((P + 255) / 256, (unsigned)n_cu * 8u));
     const bool medium = ds.medium.enabled != 0;
-    const size_t lds_trav = traversal_lds_bytes(ctx, ctx->lds_scene, 256);
+    const size_t lds_trav = traversal_lds_bytes(ctx, ctx->lds_scene, 256, true);
+    StackConf stc;
+    if ((rcode = stack_conf(ctx, (size_t)grid_all.x * 256, &stc)) != RL_OK) return rcode;
 
     if (per_sample && !owned.empty()) hipLaunchKernelGGL(k_seed_pixels, dim3(((unsigned)owned.size() + 63) / 64), dim3(64), 0, st, rc);
     hipLaunchKernelGGL(k_init, grid_all, block, 0, st, rc, pool);
@@ -942,22 +994,17 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         if (timing) hipEventRecord(ev[0], st);
         hipLaunchKernelGGL(k_raygen, grid_persistent, block, 0, st, rc, ds, pool);
         if (timing) { hipEventRecord(ev[1], st); hipEventRecord(ev[2], st); }
-        if (ctx->lds_scene) hipLaunchKernelGGL((k_extend<true>), grid_all, block, lds_trav, st, rc, ds, pool);
-        else hipLaunchKernelGGL((k_extend<false>), grid_all, block, lds_trav, st, rc, ds, pool);
+        if (ctx->lds_scene) hipLaunchKernelGGL((k_extend<true>), grid_all, block, lds_trav, st, rc, ds, pool, stc);
+        else hipLaunchKernelGGL((k_extend<false>), grid_all, block, lds_trav, st, rc, ds, pool, stc);
         if (timing) { hipEventRecord(ev[3], st); hipEventRecord(ev[4], st); }
         if (use_sort) {
-            hipMemsetAsync(ctx->d_qcounts, 0, kNumBins * sizeof(unsigned), st);
-            hipLaunchKernelGGL(k_sort, grid_all, block, 0, st, ds, pool, ctx->d_queues, ctx->d_qcounts);
-            for (int b = 0; b < kNumBins; b++)
-                launch_shade_type(b, medium, grid_all, block, st, rc, ds, pool, ctx->d_queues + (size_t)b * P, ctx->d_qcounts + b);
-            launches += kNumBins + 1;
-        } else {
-            launch_shade_type(ctx->bsdf_type, medium, grid_all, block, st, rc, ds, pool, nullptr, nullptr);
-            launches += 1;
-        }
+            if (medium) hipLaunchKernelGGL((k_shade_sorted<true>), grid_all, block, 0, st, rc, ds, pool);
+            else hipLaunchKernelGGL((k_shade_sorted<false>), grid_all, block, 0, st, rc, ds, pool);
+        } else launch_shade_type(ctx->bsdf_type, medium, grid_all, block, st, rc, ds, pool);
+        launches += 1;
         if (timing) { hipEventRecord(ev[5], st); hipEventRecord(ev[6], st); }
-        if (ctx->lds_scene) hipLaunchKernelGGL((k_shadow<true>), grid_all, block, lds_trav, st, rc, ds, pool);
-        else hipLaunchKernelGGL((k_shadow<false>), grid_all, block, lds_trav, st, rc, ds, pool);
+        if (ctx->lds_scene) hipLaunchKernelGGL((k_shadow<true>), grid_all, block, lds_trav, st, rc, ds, pool, stc);
+        else hipLaunchKernelGGL((k_shadow<false>), grid_all, block, lds_trav, st, rc, ds, pool, stc);
         if (timing) hipEventRecord(ev[7], st);
         launches += 3;
         n_extend++;
@@ -1009,8 +1056,10 @@ extern "C" int rl_trace_batch(rl_context* ctx, size_t n, const float* origins, c
     HIP_OK(hipMalloc((void**)&d_m, n * 4)); HIP_OK(hipMalloc((void**)&d_tr, n * 4));
     HIP_OK(hipMemcpy(d_o, origins, 3 * n * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_d, directions, 3 * n * 4, hipMemcpyHostToDevice));
-    size_t lds = traversal_lds_bytes(ctx, false, 256);
-    hipLaunchKernelGGL(k_trace_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, ctx->stream, ctx->ds, (unsigned)n, d_o, d_d, d_t, d_u, d_v, d_m, d_tr);
+    size_t lds = traversal_lds_bytes(ctx, false, 256, false);
+    StackConf stc;
+    { int r = stack_conf(ctx, (n + 255) / 256 * 256, &stc); if (r != RL_OK) return r; }
+    hipLaunchKernelGGL(k_trace_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, ctx->stream, ctx->ds, stc, (unsigned)n, d_o, d_d, d_t, d_u, d_v, d_m, d_tr);
     HIP_OK(hipStreamSynchronize(ctx->stream));
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpy(t_out, d_t, n * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(u_out, d_u, n * 4, hipMemcpyDeviceToHost));
@@ -1028,8 +1077,10 @@ extern "C" int rl_visible_batch(rl_context* ctx, size_t n, const float* p0, cons
     HIP_OK(hipMalloc((void**)&d_a, 3 * n * 4)); HIP_OK(hipMalloc((void**)&d_b, 3 * n * 4)); HIP_OK(hipMalloc((void**)&d_o, n));
     HIP_OK(hipMemcpy(d_a, p0, 3 * n * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_b, p1, 3 * n * 4, hipMemcpyHostToDevice));
-    size_t lds = traversal_lds_bytes(ctx, false, 256);
-    hipLaunchKernelGGL(k_visible_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, ctx->stream, ctx->ds, (unsigned)n, d_a, d_b, d_o);
+    size_t lds = traversal_lds_bytes(ctx, false, 256, false);
+    StackConf stc;
+    { int r = stack_conf(ctx, (n + 255) / 256 * 256, &stc); if (r != RL_OK) return r; }
+    hipLaunchKernelGGL(k_visible_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, ctx->stream, ctx->ds, stc, (unsigned)n, d_a, d_b, d_o);
     HIP_OK(hipStreamSynchronize(ctx->stream));
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpy(visible_out, d_o, n, hipMemcpyDeviceToHost));
