@@ -122,6 +122,16 @@ int rl_scene_add_bitmap(rl_scene* scene, uint32_t width, uint32_t height, const 
 int rl_scene_set_medium(rl_scene* scene, const float sigma_a[3], const float sigma_s[3],
                         int phase_type, float g);
 
+/* Non-mesh emitters (`EmittersState::Unbuild`, src/scene_loader.rs:177-204): PointEmitter { intensity, position }
+ * (src/emitter.rs:183-250) and DirectionalLight { direction, intensity } (src/emitter.rs:96-181), kept in
+ * insertion order after the emissive meshes and the environment. */
+int rl_scene_add_point_light(rl_scene* scene, const float position[3], const float intensity[3]);
+int rl_scene_add_directional_light(rl_scene* scene, const float direction[3], const float intensity[3]);
+/* scene.emitter_environment = EnvironmentLight { luminance: EnvironmentLightColor::Constant(rgb) }
+ * (src/emitter.rs:300-568, src/scene_loader.rs:205-224).  Not combinable with a medium (the reference
+ * asserts, src/paths/edge.rs:94); lat-long texture environments are not supported yet. */
+int rl_scene_set_environment(rl_scene* scene, const float rgb[3]);
+
 /* Scene::build_emitters(false) (src/scene.rs:53-123): scene bounding sphere, emitter list
  * (emissive meshes in mesh order), CDF over flux().channel_max().  The ATS light tree
  * (`-x ats`) is out of scope. */

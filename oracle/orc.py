@@ -61,6 +61,9 @@ def lib():
                                          C.POINTER(abi.BsdfDesc), C.POINTER(C.c_float)]
         L.orc_scene_set_medium.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_float]
         L.orc_scene_build.argtypes = [C.c_void_p]
+        L.orc_scene_add_point_light.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_scene_add_directional_light.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_scene_set_environment.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.orc_rng_seed.argtypes = [C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
         L.orc_rng_next_u64.argtypes = [C.POINTER(C.c_uint64)]
         L.orc_rng_next_u64.restype = C.c_uint64
@@ -154,6 +157,12 @@ class Scene:
             sa = np.asarray(sd.medium.sigma_a, dtype=np.float32)
             ss = np.asarray(sd.medium.sigma_s, dtype=np.float32)
             L.orc_scene_set_medium(self.h, abi.fptr(sa), abi.fptr(ss), sd.medium.phase, sd.medium.g)
+        for lt in sd.lights:
+            a = np.asarray(lt["a"], np.float32); b = np.asarray(lt["intensity"], np.float32)
+            (L.orc_scene_add_point_light if lt["type"] == "point" else L.orc_scene_add_directional_light)(self.h, abi.fptr(a), abi.fptr(b))
+        if sd.environment is not None:
+            e = np.asarray(sd.environment, np.float32)
+            L.orc_scene_set_environment(self.h, abi.fptr(e))
         L.orc_scene_build(self.h)
 
     def __del__(self):
@@ -229,9 +238,9 @@ class Scene:
         return float(out[0])
 
     def sample_light(self, p, r_sel, r, ux, uy):
-        pp = np.asarray(p, np.float32); out = np.zeros(14, np.float32)
+        pp = np.asarray(p, np.float32); out = np.zeros(15, np.float32)
         lib().orc_sample_light(self.h, abi.fptr(pp), r_sel, r, ux, uy, abi.fptr(out))
-        return {"pdf": out[0], "p": out[1:4], "n": out[4:7], "d": out[7:10], "weight": out[10:13], "emitter": int(out[13])}
+        return {"pdf": out[0], "p": out[1:4], "n": out[4:7], "d": out[7:10], "weight": out[10:13], "emitter": int(out[13]), "pdf_kind": int(out[14])}
 
     def compute_pixel(self, ix, iy, rng: Rng, **kw):
         p = path_params(**kw)

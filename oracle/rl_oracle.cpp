@@ -810,6 +810,39 @@ static LightSampling mesh_direct_sample(const Mesh& m, V3 p, float r, V2 uv) {  
 }
 static Color mesh_flux(const Mesh& m) { return m.cdf.total() * m.emit() * PI_F; }  // emitter.rs:591-599
 
+// solve_quadratic (src/math.rs:324-352) and BoundingSphere::intersect (src/structure.rs:894-917)
+static bool solve_quadratic(float a, float b, float c, float* x0, float* x1) {
+    if (a == 0.0f) { if (b != 0.0f) { float v = -c / b; *x0 = v; *x1 = v; return true; } return false; }
+    float d = b * b - 4.0f * a * c;
+    if (d < 0.0f) return false;
+    float d_sqrt = std::sqrt(d);
+    float tmp = b < 0.0f ? -0.5f * (b - d_sqrt) : -0.5f * (b + d_sqrt);
+    float r0 = tmp / a, r1 = c / tmp;
+    if (r0 > r1) { *x0 = r1; *x1 = r0; } else { *x0 = r0; *x1 = r1; }
+    return true;
+}
+static bool bsphere_intersect(const BoundingSphere& s, const Ray& r, float* t) {
+    V3 d_p = s.center - r.o;
+    float a = magnitude2(r.d);
+    float b = 2.0f * dot(d_p, r.d);
+    float c = magnitude2(d_p) - s.radius * s.radius;
+    float t0, t1;
+    if (!solve_quadratic(a, b, c, &t0, &t1)) return false;
+    if (t0 < r.tnear) { if (t1 < r.tfar) { *t = t1; return true; } return false; }
+    if (t0 < r.tfar) { *t = t0; return true; }
+    return false;
+}
+
+// the non-mesh emitters (src/emitter.rs:96-250, 300-568); EnvironmentLightColor::Constant only
+enum EmitterKind { EM_MESH = 0, EM_ENV = 1, EM_POINT = 2, EM_DIRECTIONAL = 3 };
+struct EmitterRec {
+    int kind = EM_MESH;
+    int mesh = -1;
+    V3 v{0, 0, 0};            // point position / light direction
+    Color c = Color::zero();  // intensity / environment luminance
+    BoundingSphere bsphere;   // preprocess(): scene.bsphere with radius * 1.1
+};
+
 // ------------------------------------------------------------------------------------------
 // cgmath Matrix4 (column-major) — restated from memory of cgmath 0.18 (third party, unpinned)
 struct V4 { float x, y, z, w; };
@@ -959,7 +992,10 @@ struct Scene {
     Volume volume;
     // EmitterSampler (non-ATS): emitters = mesh indices in mesh order
     bool emitters_built = false;
-    std::vector<int> emitters;
+    std::vector<EmitterRec> emitters;
+    std::vector<EmitterRec> other_emitters;   // EmittersState::Unbuild(..): point / directional lights in insertion order
+    bool has_env = false; Color env_color = Color::zero();
+    int env_emitter = -1;
     std::vector<int> mesh_to_emitter;
     Distribution1D emitters_cdf;
     BoundingSphere bsphere;
@@ -979,23 +1015,62 @@ struct Scene {
         bsphere.center = c;
         bsphere.radius = magnitude(c - aabb.p_max);
         emitters.clear();
+        env_emitter = -1;
         mesh_to_emitter.assign(meshes.size(), -1);
-        for (size_t i = 0; i < meshes.size(); i++) if (meshes[i].is_light) { mesh_to_emitter[i] = (int)emitters.size(); emitters.push_back((int)i); }
+        for (size_t i = 0; i < meshes.size(); i++) if (meshes[i].is_light) {
+            mesh_to_emitter[i] = (int)emitters.size();
+            EmitterRec e; e.kind = EM_MESH; e.mesh = (int)i; emitters.push_back(e);
+        }
+        BoundingSphere big = bsphere; big.radius *= 1.1f;       // Emitter::preprocess
+        if (has_env) { EmitterRec e; e.kind = EM_ENV; e.c = env_color; e.bsphere = big; env_emitter = (int)emitters.size(); emitters.push_back(e); }
+        for (EmitterRec e : other_emitters) { e.bsphere = big; emitters.push_back(e); }
         emitters_built = true;
         if (emitters.empty()) return;
         std::vector<float> flux;
-        for (int e : emitters) flux.push_back(mesh_flux(meshes[e]).channel_max());
+        for (const EmitterRec& e : emitters) {
+            Color f;
+            switch (e.kind) {
+                case EM_MESH: f = mesh_flux(meshes[e.mesh]); break;
+                case EM_POINT: f = e.c * 4.0f * PI_F; break;                                  // emitter.rs:238-240
+                case EM_DIRECTIONAL: f = (PI_F * powi(e.bsphere.radius, 2)) * e.c; break;      // emitter.rs:163-167
+                default: f = PI_F * powi(e.bsphere.radius, 2) * e.c; break;                    // emitter.rs:520-523
+            }
+            flux.push_back(f.channel_max());
+        }
         emitters_cdf = Distribution1D::normalize(flux);
     }
     float emitter_pdf(int mesh_id) const { return emitters_cdf.pdf((size_t)mesh_to_emitter[mesh_id]); }  // emitter.rs:1510-1526
     // EmitterSampler::direct_pdf (emitter.rs:1566-1575)
     PDF direct_pdf(int mesh_id, const LightSamplingPDF& ls) const { return mesh_direct_pdf(meshes[mesh_id], ls).mul(emitter_pdf(mesh_id)); }
-    // EmitterSampler::sample_light (emitter.rs:1604-1620)
+    PDF direct_pdf_env() const { return PDF::solid_angle(1.0f / (PI_F * 4.0f)).mul(emitters_cdf.pdf((size_t)env_emitter)); }
+    Color environment_luminance() const { return has_env ? env_color : Color::zero(); }   // scene.rs:125-130
+    // EmitterSampler::sample_light (emitter.rs:1604-1620); LightSampling.emitter = index into `emitters`
     LightSampling sample_light(V3 p, float r_sel, float r, V2 uv) const {
         size_t id = emitters_cdf.sample_discrete(r_sel);
         float pdf_sel = emitters_cdf.pdf(id);
-        LightSampling res = mesh_direct_sample(meshes[emitters[id]], p, r, uv);
-        res.emitter = emitters[id];
+        const EmitterRec& e = emitters[id];
+        LightSampling res;
+        if (e.kind == EM_MESH) res = mesh_direct_sample(meshes[e.mesh], p, r, uv);
+        else if (e.kind == EM_POINT) {                                     // emitter.rs:194-213
+            V3 d = e.v - p;
+            float dist = magnitude(d);
+            d = d / dist;
+            res = {-1, PDF::discrete(1.0f), e.v, {0, 0, 0}, d, e.c / powi(dist, 2)};
+        } else if (e.kind == EM_DIRECTIONAL) {                             // emitter.rs:116-134
+            V3 lp = p - e.bsphere.radius * e.v;
+            res = {-1, PDF::discrete(1.0f), lp, e.v, -e.v, e.c};
+        } else {                                                           // emitter.rs:482-518 (Constant)
+            V3 d = sample_uniform_sphere(uv);
+            float pdf = 1.0f / (PI_F * 4.0f);
+            float t;
+            if (!bsphere_intersect(e.bsphere, Ray::make(p, d), &t)) res = {-1, PDF::solid_angle(pdf), {0, 0, 0}, {0, 0, 0}, d, Color::zero()};
+            else {
+                V3 lp = p + d * t;
+                V3 n = normalize(e.bsphere.center - lp);
+                res = {-1, PDF::solid_angle(pdf), lp, n, d, e.c / pdf};
+            }
+        }
+        res.emitter = (int)id;
         div_assign(res.weight, pdf_sel);
         res.pdf = res.pdf.mul(pdf_sel);
         return res;
@@ -1199,16 +1274,16 @@ struct PathTracer {
             if (dot(vx.its.n_s, -e.d) >= 0.0f) return scene.meshes[vx.its.mesh].emit();
             return Color::zero();
         }
-        if (vx.kind == Vertex::Light) return scene.meshes[vx.emitter].emit();  // emitter.eval(-d, uv) = emit(uv)
+        if (vx.kind == Vertex::Light) { const EmitterRec& em = scene.emitters[vx.emitter]; return em.kind == EM_MESH ? scene.meshes[em.mesh].emit() : em.c; }  // emitter.eval(-d, uv)
         return Color::zero();
     }
-    bool next_on_light_source(const Edge& e) const { return e.v1 >= 0 ? on_light_source(e.v1) : false; }  // edge.rs:191-197 (no envmap)
+    bool next_on_light_source(const Edge& e) const { return e.v1 >= 0 ? on_light_source(e.v1) : scene.has_env; }  // edge.rs:191-197
     Color edge_contribution(const Edge& e) const {  // edge.rs:201-210
         if (e.v1 >= 0) {
             if (e.has_contrib) return e.contrib * e.weight * e.rr_weight;
             return e.weight * e.rr_weight * vertex_contribution(e.v1, e);
         }
-        return e.weight * e.rr_weight * Color::zero();  // scene.enviroment_luminance (no envmap)
+        return e.weight * e.rr_weight * scene.environment_luminance();  // scene.enviroment_luminance(self.d)
     }
 
     // Edge::from_ray (edge.rs:65-189)
@@ -1371,15 +1446,21 @@ struct PathTracer {
         if (v.kind == Vertex::Surface) { if (scene.meshes[v.its.mesh].bsdf.is_smooth()) return false; }
         else if (v.kind != Vertex::Volume) return false;
         V3 o = v.position();
-        if (e.v1 < 0) return false;
+        if (e.v1 < 0) {   // pdf_emitter with no next vertex: the environment (emitters.rs:18-46)
+            if (!scene.has_env) return false;
+            *out = scene.direct_pdf_env().value();
+            return true;
+        }
         const Vertex& nx = path.vertices[e.v1];
         if (nx.kind == Vertex::Surface) {
             PDF p = scene.direct_pdf(nx.its.mesh, {o, nx.its.p, nx.its.n_g, e.d});
             *out = p.value();
             return true;
         }
-        if (nx.kind == Vertex::Light) {
-            PDF p = scene.direct_pdf(nx.emitter, {o, nx.pos, nx.n, e.d});
+        if (nx.kind == Vertex::Light) {   // (not reached by the path integrator: NEE edges never ask for the light pdf)
+            const EmitterRec& em = scene.emitters[nx.emitter];
+            if (em.kind != EM_MESH) return false;
+            PDF p = scene.direct_pdf(em.mesh, {o, nx.pos, nx.n, e.d});
             *out = p.value();
             return true;
         }
@@ -1579,6 +1660,21 @@ int orc_scene_set_medium(orc_scene* sc, const float* sigma_a, const float* sigma
     return 0;
 }
 
+int orc_scene_add_point_light(orc_scene* sc, const float* position, const float* intensity) {
+    EmitterRec e; e.kind = EM_POINT; e.v = {position[0], position[1], position[2]}; e.c = {intensity[0], intensity[1], intensity[2]};
+    sc->s.other_emitters.push_back(e);
+    return 0;
+}
+int orc_scene_add_directional_light(orc_scene* sc, const float* direction, const float* intensity) {
+    EmitterRec e; e.kind = EM_DIRECTIONAL; e.v = {direction[0], direction[1], direction[2]}; e.c = {intensity[0], intensity[1], intensity[2]};
+    sc->s.other_emitters.push_back(e);
+    return 0;
+}
+int orc_scene_set_environment(orc_scene* sc, const float* rgb) {
+    sc->s.has_env = true; sc->s.env_color = {rgb[0], rgb[1], rgb[2]};
+    return 0;
+}
+
 int orc_scene_build(orc_scene* sc) {
     sc->s.build_emitters();
     sc->s.build_bvh();
@@ -1694,10 +1790,12 @@ int orc_bsdf_probe(const orc_scene* sc, int mesh, int op, const float* wi, const
     PDF p = b.pdf(false, {0, 0}, w, o, DomSolidAngle); out[0] = p.v; out[1] = (float)p.kind;
     return 0;
 }
-// EmitterSampler::sample_light probe: out = [pdf, p3, n3, d3, weight3, emitter]
+// EmitterSampler::sample_light probe: out = [pdf, p3, n3, d3, weight3, mesh id (or -kind), pdf kind]
 int orc_sample_light(const orc_scene* sc, const float* p, float r_sel, float r, float ux, float uy, float* out) {
     LightSampling l = sc->s.sample_light({p[0], p[1], p[2]}, r_sel, r, {ux, uy});
-    float v[] = {l.pdf.v, l.p.x, l.p.y, l.p.z, l.n.x, l.n.y, l.n.z, l.d.x, l.d.y, l.d.z, l.weight.r, l.weight.g, l.weight.b, (float)l.emitter};
+    const EmitterRec& em = sc->s.emitters[l.emitter];
+    float v[] = {l.pdf.v, l.p.x, l.p.y, l.p.z, l.n.x, l.n.y, l.n.z, l.d.x, l.d.y, l.d.z, l.weight.r, l.weight.g, l.weight.b,
+                 (float)(em.kind == EM_MESH ? em.mesh : -em.kind), (float)l.pdf.kind};
     std::memcpy(out, v, sizeof(v));
     return 0;
 }

@@ -35,6 +35,9 @@ int orc_scene_add_bitmap(orc_scene* sc, uint32_t w, uint32_t h, const float* rgb
 int orc_scene_add_mesh(orc_scene* sc, const float* vertices, size_t nv, const uint32_t* indices, size_t ntri,
                        const float* normals, const float* uv, const rl_bsdf_desc* bsdf, const float* emission);
 int orc_scene_set_medium(orc_scene* sc, const float* sigma_a, const float* sigma_s, int phase, float g);
+int orc_scene_add_point_light(orc_scene* sc, const float* position, const float* intensity);
+int orc_scene_add_directional_light(orc_scene* sc, const float* direction, const float* intensity);
+int orc_scene_set_environment(orc_scene* sc, const float* rgb);
 int orc_scene_build(orc_scene* sc);
 
 void orc_rng_seed(uint64_t seed, int variant, uint64_t* state_out);

@@ -27,7 +27,8 @@ STREAM_REFERENCE_ORDER, STREAM_PER_SAMPLE = 0, 1
 # every symbol include/rustlight_amd.h declares (tests check the .so exports all of them)
 PUBLIC_SYMBOLS = [
     "rl_scene_create", "rl_scene_destroy", "rl_scene_set_camera", "rl_scene_scale_image", "rl_scene_add_mesh",
-    "rl_scene_add_bitmap", "rl_scene_set_medium", "rl_scene_build_emitters", "rl_scene_load_pbrt",
+    "rl_scene_add_bitmap", "rl_scene_set_medium", "rl_scene_add_point_light", "rl_scene_add_directional_light",
+    "rl_scene_set_environment", "rl_scene_build_emitters", "rl_scene_load_pbrt",
     "rl_scene_image_size", "rl_scene_counts", "rl_sampler_seed", "rl_sampler_next_u64", "rl_sampler_next_f32",
     "rl_path_params_default", "rl_context_create", "rl_context_destroy", "rl_last_error", "rl_block_count",
     "rl_generate_block_seeds", "rl_render_path", "rl_trace_batch", "rl_visible_batch", "rl_save_pfm", "rl_build_info",
@@ -65,6 +66,9 @@ def lib():
     L.rl_scene_add_bitmap.argtypes = [vp, C.c_uint32, C.c_uint32, f32p]
     L.rl_scene_set_medium.argtypes = [vp, f32p, f32p, C.c_int, C.c_float]
     L.rl_scene_build_emitters.argtypes = [vp]
+    L.rl_scene_add_point_light.argtypes = [vp, f32p, f32p]
+    L.rl_scene_add_directional_light.argtypes = [vp, f32p, f32p]
+    L.rl_scene_set_environment.argtypes = [vp, f32p]
     L.rl_scene_load_pbrt.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
     L.rl_scene_image_size.argtypes = [vp, u32p, u32p]
     L.rl_scene_counts.argtypes = [vp, u64p, u64p, u64p]
@@ -152,6 +156,14 @@ class Scene:
                 sa = np.asarray(sd.medium.sigma_a, dtype=np.float32)
                 ss = np.asarray(sd.medium.sigma_s, dtype=np.float32)
                 _check(L.rl_scene_set_medium(self.h, abi.fptr(sa), abi.fptr(ss), sd.medium.phase, sd.medium.g))
+            for lt in sd.lights:
+                a = np.asarray(lt["a"], np.float32)
+                b = np.asarray(lt["intensity"], np.float32)
+                fn = L.rl_scene_add_point_light if lt["type"] == "point" else L.rl_scene_add_directional_light
+                _check(fn(self.h, abi.fptr(a), abi.fptr(b)))
+            if sd.environment is not None:
+                e = np.asarray(sd.environment, np.float32)
+                _check(L.rl_scene_set_environment(self.h, abi.fptr(e)))
         _check(L.rl_scene_build_emitters(self.h))
 
     @classmethod

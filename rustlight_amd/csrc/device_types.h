@@ -77,6 +77,19 @@ struct MeshRecord {
 };
 enum { MESH_HAS_NORMALS = 1, MESH_HAS_UV = 2, MESH_IS_LIGHT = 4 };
 
+// one entry of EmitterSampler::emitters (src/emitter.rs:1491-1496)
+enum { EMITTER_MESH = 0, EMITTER_ENV = 1, EMITTER_POINT = 2, EMITTER_DIRECTIONAL = 3 };
+struct EmitterRecord {
+    int32_t kind;
+    int32_t mesh;            // EMITTER_MESH
+    float v[3];              // point position / light direction
+    float c[3];              // intensity / constant environment luminance
+    float center[3];         // bounding sphere after Emitter::preprocess (radius * 1.1)
+    float radius;
+    float pad[4];
+};
+static_assert(sizeof(EmitterRecord) == 64, "EmitterRecord must be 64 bytes");
+
 struct CameraRecord {   // struct Camera (src/camera.rs:5-15)
     float sample_to_camera[16];  // column-major
     float to_world[16];
@@ -109,9 +122,12 @@ struct DeviceScene {
     const BitmapDesc* bitmaps;
     const float* bitmap_texels;
     // EmitterSampler (non-ATS): emitters in mesh order + cdf over flux.channel_max()
-    const int32_t* emitters;       // mesh ids
+    const EmitterRecord* emitters;
     const float* emitters_cdf;     // n_emitters + 1
     uint32_t n_emitters;
+    int32_t env_emitter;           // index of the environment emitter or -1
+    float env_color[3];
+    float env_pdf;                 // direct_pdf of the constant environment: 1/(4 pi) * p_sel
     const float* mesh_cdf;         // concatenated per-mesh area cdfs
     uint32_t n_meshes;
     CameraRecord camera;

@@ -277,6 +277,33 @@ int load_pbrt(const char* path, bool use_shading_normals, rl_scene** out, std::s
             const Param* L = find(ps, "L");
             gs.has_emission = true;
             for (int i = 0; i < 3; i++) gs.emission[i] = (L && L->nums.size() >= 3) ? (float)L->nums[i] : 1.0f;
+        } else if (d == "LightSource") {   // scene_loader.rs:177-224
+            Token ty = lx.next();
+            if (!read_params(lx, &ps)) return fail(RL_ERR_PARSE, "LightSource: bad parameters");
+            rl_color_desc sc = color_param(ps, "scale", 1, 1, 1);
+            if (ty.text == "point") {
+                rl_color_desc I = color_param(ps, "I", 1, 1, 1);
+                const Param* from = find(ps, "from");
+                Vec3 pos = gs.ctm.xform_point({from && from->nums.size() >= 3 ? (float)from->nums[0] : 0.0f, from && from->nums.size() >= 3 ? (float)from->nums[1] : 0.0f,
+                                               from && from->nums.size() >= 3 ? (float)from->nums[2] : 0.0f});
+                float p3[3] = {pos.x, pos.y, pos.z}, i3[3] = {I.color0[0] * sc.color0[0], I.color0[1] * sc.color0[1], I.color0[2] * sc.color0[2]};
+                rl_scene_add_point_light(scene, p3, i3);
+            } else if (ty.text == "distant") {
+                rl_color_desc Lc = color_param(ps, "L", 1, 1, 1);
+                const Param* from = find(ps, "from");
+                const Param* to = find(ps, "to");
+                Vec3 f{0, 0, 0}, t{0, 0, 1};
+                if (from && from->nums.size() >= 3) f = {(float)from->nums[0], (float)from->nums[1], (float)from->nums[2]};
+                if (to && to->nums.size() >= 3) t = {(float)to->nums[0], (float)to->nums[1], (float)to->nums[2]};
+                Vec3 dir = vnormalize(vsub(t, f));   // (to - from).normalize()
+                float d3[3] = {dir.x, dir.y, dir.z}, i3[3] = {Lc.color0[0] * sc.color0[0], Lc.color0[1] * sc.color0[1], Lc.color0[2] * sc.color0[2]};
+                rl_scene_add_directional_light(scene, d3, i3);
+            } else if (ty.text == "infinite") {
+                if (find(ps, "mapname")) return fail(RL_ERR_UNSUPPORTED, "LightSource infinite with a mapname (texture environment) is not supported");
+                rl_color_desc Lc = color_param(ps, "L", 1, 1, 1);
+                float e3[3] = {Lc.color0[0] * sc.color0[0], Lc.color0[1] * sc.color0[1], Lc.color0[2] * sc.color0[2]};
+                rl_scene_set_environment(scene, e3);
+            } else return fail(RL_ERR_UNSUPPORTED, "LightSource \"" + ty.text + "\" is not supported");
         } else if (d == "Shape") {
             Token ty = lx.next();
             if (!read_params(lx, &ps)) return fail(RL_ERR_PARSE, "Shape: bad parameters");

@@ -96,7 +96,8 @@ void flatten_scene(const rl_scene& scene, FlatScene* out) {
     }
     // EmitterSampler::pdf(emitter) = emitters_cdf.pdf(i) (src/emitter.rs:1510-1526)
     for (size_t e = 0; e < scene.emitters.size(); e++)
-        out->meshes[scene.emitters[e]].emitter_pdf = scene.emitters_cdf[e + 1] - scene.emitters_cdf[e];
+        if (scene.emitters[e].kind == EMITTER_MESH)
+            out->meshes[scene.emitters[e].mesh].emitter_pdf = scene.emitters_cdf[e + 1] - scene.emitters_cdf[e];
     uint64_t off = 0;
     for (const HostBitmap& b : scene.bitmaps) {
         out->bitmaps.push_back({b.w, b.h, off});
@@ -232,23 +233,74 @@ int rl_scene_build_emitters(rl_scene* scene) {
     scene->bsphere_radius = vlen(vsub(c, box.hi));
     scene->emitters.clear();
     std::vector<float> flux;
+    auto channel_max = [](const float* c) { return std::fmax(c[0], std::fmax(c[1], c[2])); };
     for (size_t i = 0; i < scene->meshes.size(); i++) {
         const HostMesh& m = scene->meshes[i];
         if (!m.is_light) continue;
-        scene->emitters.push_back((int32_t)i);
-        // Mesh::flux = cdf.total() * e * PI (emitter.rs:591-599); f32 * Color is unguarded, Color * f32 is guarded
+        EmitterRecord e;
+        std::memset(&e, 0, sizeof(e));
+        e.kind = EMITTER_MESH; e.mesh = (int32_t)i;
+        scene->emitters.push_back(e);
+        // Mesh::flux = cdf.total() * e * PI (emitter.rs:591-599)
         float total = m.area_total();
         float ch[3];
-        for (int k = 0; k < 3; k++) ch[k] = m.emission[k] * total;
-        for (int k = 0; k < 3; k++) ch[k] = ch[k] * kPi;   // (PI is finite: the guard never fires)
-        flux.push_back(std::fmax(ch[0], std::fmax(ch[1], ch[2])));   // Color::channel_max
+        for (int k = 0; k < 3; k++) ch[k] = (m.emission[k] * total) * kPi;
+        flux.push_back(channel_max(ch));
     }
+    const float big_radius = scene->bsphere_radius * 1.1f;      // Emitter::preprocess: bsphere.radius *= 1.1
+    auto finish = [&](EmitterRecord e) {
+        for (int k = 0; k < 3; k++) e.center[k] = scene->bsphere_center[k];
+        e.radius = big_radius;
+        scene->emitters.push_back(e);
+        float ch[3];
+        float r2 = big_radius * big_radius;                      // radius.powi(2)
+        if (e.kind == EMITTER_POINT) for (int k = 0; k < 3; k++) ch[k] = (e.c[k] * 4.0f) * kPi;            // intensity * 4 * PI
+        else if (e.kind == EMITTER_DIRECTIONAL) for (int k = 0; k < 3; k++) ch[k] = e.c[k] * (kPi * r2);    // area * intensity
+        else for (int k = 0; k < 3; k++) ch[k] = e.c[k] * (kPi * r2);                                      // PI * r^2 * c
+        flux.push_back(channel_max(ch));
+    };
+    if (scene->has_env) {
+        EmitterRecord e;
+        std::memset(&e, 0, sizeof(e));
+        e.kind = EMITTER_ENV; e.mesh = -1;
+        for (int k = 0; k < 3; k++) e.c[k] = scene->env_color[k];
+        finish(e);
+    }
+    for (const EmitterRecord& o : scene->other_emitters) finish(o);
     scene->emitters_cdf.clear();
     if (!flux.empty()) {
         float fi;
         build_cdf(flux, &scene->emitters_cdf, &fi);
     }
     scene->emitters_built = true;
+    return RL_OK;
+}
+
+int rl_scene_add_point_light(rl_scene* scene, const float position[3], const float intensity[3]) {
+    if (!scene || !position || !intensity) return RL_ERR_INVALID_ARGUMENT;
+    EmitterRecord e;
+    std::memset(&e, 0, sizeof(e));
+    e.kind = EMITTER_POINT; e.mesh = -1;
+    for (int k = 0; k < 3; k++) { e.v[k] = position[k]; e.c[k] = intensity[k]; }
+    scene->other_emitters.push_back(e);
+    scene->emitters_built = false;
+    return RL_OK;
+}
+int rl_scene_add_directional_light(rl_scene* scene, const float direction[3], const float intensity[3]) {
+    if (!scene || !direction || !intensity) return RL_ERR_INVALID_ARGUMENT;
+    EmitterRecord e;
+    std::memset(&e, 0, sizeof(e));
+    e.kind = EMITTER_DIRECTIONAL; e.mesh = -1;
+    for (int k = 0; k < 3; k++) { e.v[k] = direction[k]; e.c[k] = intensity[k]; }
+    scene->other_emitters.push_back(e);
+    scene->emitters_built = false;
+    return RL_OK;
+}
+int rl_scene_set_environment(rl_scene* scene, const float rgb[3]) {
+    if (!scene || !rgb) return RL_ERR_INVALID_ARGUMENT;
+    scene->has_env = true;
+    for (int k = 0; k < 3; k++) scene->env_color[k] = rgb[k];
+    scene->emitters_built = false;
     return RL_OK;
 }
 

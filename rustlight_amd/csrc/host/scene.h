@@ -48,7 +48,9 @@ struct rl_scene {
     rl::MediumRecord medium{};
     // emitters (Scene::build_emitters)
     bool emitters_built = false;
-    std::vector<int32_t> emitters;          // mesh ids in mesh order
+    std::vector<rl::EmitterRecord> other_emitters;   // point / directional lights, insertion order
+    bool has_env = false; float env_color[3] = {0, 0, 0};
+    std::vector<rl::EmitterRecord> emitters;          // emissive meshes (mesh order), environment, others
     std::vector<float> emitters_cdf;        // n + 1
     float bsphere_center[3] = {0, 0, 0};
     float bsphere_radius = 0;

@@ -390,47 +390,100 @@ RL_DEV unsigned int cdf_sample(const float* cdf, unsigned int n_entries, float v
     return lo - 1;
 }
 
-struct LightSample { float pdf; V3 p, n, d; Col weight; int mesh; };
+struct LightSample { float pdf; int pdf_kind; V3 p, n, d; Col weight; int kind; };
 
-// EmitterSampler::sample_light (non-ATS) -> Mesh::direct_sample -> Mesh::sample -> sample_tri
+// solve_quadratic (src/math.rs:324-352) + BoundingSphere::intersect (src/structure.rs:894-917)
+RL_DEV bool bsphere_intersect(V3 center, float radius, V3 o, V3 d, float tnear, float tfar, float* t_out) {
+    V3 d_p = center - o;
+    float a = length2(d);
+    float b = 2.0f * dot(d_p, d);
+    float c = length2(d_p) - radius * radius;
+    float x0, x1;
+    if (a == 0.0f) {
+        if (b == 0.0f) return false;
+        float v = div_rn(-c, b);
+        x0 = v; x1 = v;
+    } else {
+        float disc = b * b - 4.0f * a * c;
+        if (disc < 0.0f) return false;
+        float d_sqrt = sqrt_rn(disc);
+        float tmp = b < 0.0f ? -0.5f * (b - d_sqrt) : -0.5f * (b + d_sqrt);
+        float r0 = div_rn(tmp, a), r1 = div_rn(c, tmp);
+        if (r0 > r1) { x0 = r1; x1 = r0; } else { x0 = r0; x1 = r1; }
+    }
+    if (x0 < tnear) { if (x1 < tfar) { *t_out = x1; return true; } return false; }
+    if (x0 < tfar) { *t_out = x0; return true; }
+    return false;
+}
+
+// EmitterSampler::sample_light (non-ATS, src/emitter.rs:1604-1620) -> Emitter::direct_sample of the picked emitter
 RL_DEV LightSample sample_light(const DeviceScene& sc, V3 p, float r_sel, float r, V2 uv) {
     unsigned int id = cdf_sample(sc.emitters_cdf, sc.n_emitters + 1, r_sel);
     float pdf_sel = sc.emitters_cdf[id + 1] - sc.emitters_cdf[id];
-    int mesh_id = sc.emitters[id];
-    MeshRecord mr = sc.meshes[mesh_id];
-    unsigned int prim = cdf_sample(sc.mesh_cdf + mr.cdf_base, mr.n_tris + 1, r);
-    unsigned int gtri = mr.tri_base + prim;
-    unsigned int i0 = sc.tri_indices[3 * gtri], i1 = sc.tri_indices[3 * gtri + 1], i2 = sc.tri_indices[3 * gtri + 2];
-    V3 v0 = mk3(sc.positions[3 * i0], sc.positions[3 * i0 + 1], sc.positions[3 * i0 + 2]);
-    V3 v1 = mk3(sc.positions[3 * i1], sc.positions[3 * i1 + 1], sc.positions[3 * i1 + 2]);
-    V3 v2 = mk3(sc.positions[3 * i2], sc.positions[3 * i2 + 1], sc.positions[3 * i2 + 2]);
-    V2 b = uniform_sample_triangle(uv);
-    float w2 = 1.0f - b.x - b.y;
-    V3 pos = v0 * b.x + v1 * b.y + v2 * w2;
-    V3 n_g = normalize(cross(v2 - v0, v1 - v0));     // (v2-v0) x (v1-v0): geometry.rs:272-276
-    if (mr.flags & MESH_HAS_NORMALS) {
-        V3 n0 = mk3(sc.normals[3 * i0], sc.normals[3 * i0 + 1], sc.normals[3 * i0 + 2]);
-        V3 n1 = mk3(sc.normals[3 * i1], sc.normals[3 * i1 + 1], sc.normals[3 * i1 + 2]);
-        V3 n2 = mk3(sc.normals[3 * i2], sc.normals[3 * i2 + 1], sc.normals[3 * i2 + 2]);
-        V3 n = n0 * b.x + n1 * b.y + n2 * w2;
-        float nl = length2(n);
-        if (nl == 0.0f) n = n_g;
-        else if (nl != 1.0f) n = n / sqrt_rn(nl);
-        if (dot(n_g, n) < 0.0f) n_g = -n_g;
-    }
-    float pdf_area = mr.inv_area;                      // res.pdf = Area(1 / cdf.total())
+    const EmitterRecord em = sc.emitters[id];
     LightSample ls;
-    ls.mesh = mesh_id;
-    V3 d = pos - p;
-    float dist = length(d);
-    if (dist != 0.0f) d = d / dist;
-    float geom = dist != 0.0f ? div_rn(rmax(dot(n_g, -d), 0.0f), dist * dist) : 0.0f;
-    float pdf = geom == 0.0f ? 0.0f : div_rn(pdf_area, geom);   // PDF::as_solid_angle_geom
-    Col emit = mkc(mr.emission[0], mr.emission[1], mr.emission[2]);
-    Col weight = pdf == 0.0f ? czero() : emit * geom / pdf_area;
-    weight = div_unguarded(weight, pdf_sel);           // res.weight /= pdf_sel
-    ls.pdf = pdf * pdf_sel;                            // res.pdf = res.pdf * pdf_sel
-    ls.p = pos; ls.n = n_g; ls.d = d; ls.weight = weight;
+    ls.kind = em.kind;
+    if (em.kind == EMITTER_MESH) {
+        // Mesh::direct_sample -> Mesh::sample -> sample_tri (emitter.rs:652-688, geometry.rs:261-348)
+        MeshRecord mr = sc.meshes[em.mesh];
+        unsigned int prim = cdf_sample(sc.mesh_cdf + mr.cdf_base, mr.n_tris + 1, r);
+        unsigned int gtri = mr.tri_base + prim;
+        unsigned int i0 = sc.tri_indices[3 * gtri], i1 = sc.tri_indices[3 * gtri + 1], i2 = sc.tri_indices[3 * gtri + 2];
+        V3 v0 = mk3(sc.positions[3 * i0], sc.positions[3 * i0 + 1], sc.positions[3 * i0 + 2]);
+        V3 v1 = mk3(sc.positions[3 * i1], sc.positions[3 * i1 + 1], sc.positions[3 * i1 + 2]);
+        V3 v2 = mk3(sc.positions[3 * i2], sc.positions[3 * i2 + 1], sc.positions[3 * i2 + 2]);
+        V2 b = uniform_sample_triangle(uv);
+        float w2 = 1.0f - b.x - b.y;
+        V3 pos = v0 * b.x + v1 * b.y + v2 * w2;
+        V3 n_g = normalize(cross(v2 - v0, v1 - v0));     // (v2-v0) x (v1-v0): geometry.rs:272-276
+        if (mr.flags & MESH_HAS_NORMALS) {
+            V3 n0 = mk3(sc.normals[3 * i0], sc.normals[3 * i0 + 1], sc.normals[3 * i0 + 2]);
+            V3 n1 = mk3(sc.normals[3 * i1], sc.normals[3 * i1 + 1], sc.normals[3 * i1 + 2]);
+            V3 n2 = mk3(sc.normals[3 * i2], sc.normals[3 * i2 + 1], sc.normals[3 * i2 + 2]);
+            V3 n = n0 * b.x + n1 * b.y + n2 * w2;
+            float nl = length2(n);
+            if (nl == 0.0f) n = n_g;
+            else if (nl != 1.0f) n = n / sqrt_rn(nl);
+            if (dot(n_g, n) < 0.0f) n_g = -n_g;
+        }
+        float pdf_area = mr.inv_area;                      // res.pdf = Area(1 / cdf.total())
+        V3 d = pos - p;
+        float dist = length(d);
+        if (dist != 0.0f) d = d / dist;
+        float geom = dist != 0.0f ? div_rn(rmax(dot(n_g, -d), 0.0f), dist * dist) : 0.0f;
+        float pdf = geom == 0.0f ? 0.0f : div_rn(pdf_area, geom);   // PDF::as_solid_angle_geom
+        Col emit = mkc(mr.emission[0], mr.emission[1], mr.emission[2]);
+        ls.weight = pdf == 0.0f ? czero() : emit * geom / pdf_area;
+        ls.pdf = pdf; ls.pdf_kind = PDF_SOLID_ANGLE;
+        ls.p = pos; ls.n = n_g; ls.d = d;
+    } else if (em.kind == EMITTER_POINT) {                 // PointEmitter::direct_sample (emitter.rs:194-213)
+        V3 lp = mk3(em.v[0], em.v[1], em.v[2]);
+        V3 d = lp - p;
+        float dist = length(d);
+        d = d / dist;
+        ls.pdf = 1.0f; ls.pdf_kind = PDF_DISCRETE;
+        ls.p = lp; ls.n = mk3(0.0f, 0.0f, 0.0f); ls.d = d;
+        ls.weight = mkc(em.c[0], em.c[1], em.c[2]) / powi_f(dist, 2);
+    } else if (em.kind == EMITTER_DIRECTIONAL) {           // DirectionalLight::direct_sample (emitter.rs:116-134)
+        V3 dir = mk3(em.v[0], em.v[1], em.v[2]);
+        ls.pdf = 1.0f; ls.pdf_kind = PDF_DISCRETE;
+        ls.p = p - em.radius * dir; ls.n = dir; ls.d = -dir;
+        ls.weight = mkc(em.c[0], em.c[1], em.c[2]);
+    } else {                                               // EnvironmentLight::direct_sample, Constant (emitter.rs:482-518)
+        V3 d = sample_uniform_sphere(uv);
+        float pdf = div_rn(1.0f, kPi * 4.0f);
+        float t;
+        ls.pdf = pdf; ls.pdf_kind = PDF_SOLID_ANGLE; ls.d = d;
+        if (!bsphere_intersect(mk3(em.center[0], em.center[1], em.center[2]), em.radius, p, d, kEps, kF32Max, &t)) {
+            ls.p = mk3(0.0f, 0.0f, 0.0f); ls.n = mk3(0.0f, 0.0f, 0.0f); ls.weight = czero();
+        } else {
+            ls.p = p + d * t;
+            ls.n = normalize(mk3(em.center[0], em.center[1], em.center[2]) - ls.p);
+            ls.weight = mkc(em.c[0], em.c[1], em.c[2]) / pdf;
+        }
+    }
+    ls.weight = div_unguarded(ls.weight, pdf_sel);         // res.weight /= pdf_sel
+    ls.pdf = ls.pdf * pdf_sel;                             // res.pdf = res.pdf * pdf_sel
     return ls;
 }
 

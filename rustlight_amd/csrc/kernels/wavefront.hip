@@ -415,8 +415,31 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, const Pool&
         if (is_volume) vpos = ro + rd * ms.t;
     }
     bool ended = false;
-    if (!MEDIUM && !hit) ended = true;           // edge without a next vertex; environment luminance is 0
     unsigned new_flags = ST_REGEN;
+    if (!MEDIUM && !hit) {
+        // edge without a next vertex: Edge::contribution = weight * rr * scene.enviroment_luminance(d) (edge.rs:201-210)
+        ended = true;
+        if (sc.env_emitter >= 0) {
+            Col contrib = (w_edge * rr) * mkc(sc.env_color[0], sc.env_color[1], sc.env_color[2]);
+            const bool add_contrib = rc.has_min ? (depth - 1u) >= rc.min_depth : true;
+            if (prev == PREV_SENSOR) {
+                if (!is_zero(contrib) && add_contrib) L = L + contrib;
+            } else if (!zeroed) {
+                if (rc.strategy == RL_STRATEGY_EMITTER) contrib = czero();
+                if (!is_zero(contrib) && add_contrib) {
+                    float wmis = 1.0f;
+                    if (rc.strategy == RL_STRATEGY_ALL && (flags & ST_PDF_SA)) {
+                        // pdf_emitter, `None` next vertex: direct_pdf of the environment (emitters.rs:18-46)
+                        float p2 = (prev == PREV_SURFACE || prev == PREV_VOLUME) ? sc.env_pdf : 0.0f;
+                        float total = (0.0f + pdf_edge) + p2;
+                        wmis = div_rn(pdf_edge, total);
+                    }
+                    L = L + beta * (contrib * wmis);
+                }
+            }
+            storec(pool, slot, F_LR, L);
+        }
+    }
     if (!ended) {
         const Col W = w_edge * rr;                // edge.weight * edge.rr_weight (Color * f32, guarded)
         SurfacePoint sp;
@@ -512,11 +535,15 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, const Pool&
                 if (ls.pdf != 0.0f) {
                     Col wl;
                     float p_dir;
-                    if (is_volume) { wl = phase_eval(sc.medium, d_in, ls.d); p_dir = phase_pdf(sc.medium, d_in, ls.d); }
+                    if (is_volume) { wl = phase_eval(sc.medium, d_in, ls.d); p_dir = phase_pdf(sc.medium, d_in, ls.d); }   // (no environment with a medium)
                     else {
                         V3 wo = to_local(sp.frame, ls.d);
                         wl = bsdf_eval<MAT>(sc, *mat, sp.has_uv, sp.uv, sp.wi, wo, false);
-                        p_dir = bsdf_pdf<MAT>(sc, *mat, sp.has_uv, sp.uv, sp.wi, wo, false);
+                        // the MIS pdf is asked along Edge::from_vertex's own direction (p_light - p) / |..| (edge.rs:37-39):
+                        // bitwise equal to ls.d for mesh lights, recomputed for the environment
+                        V3 wo_edge = wo;
+                        if (ls.kind == EMITTER_ENV) { V3 ed = ls.p - vp; ed = ed / length(ed); wo_edge = to_local(sp.frame, ed); }
+                        p_dir = bsdf_pdf<MAT>(sc, *mat, sp.has_uv, sp.uv, sp.wi, wo_edge, false);
                     }
                     if (MEDIUM) {
                         V3 dd = ls.p - vp;
@@ -526,7 +553,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, const Pool&
                     const bool add_l = rc.has_min ? (gen - 1u) >= rc.min_depth : true;
                     if (!zeroed && !is_zero(c_l) && add_l) {
                         float wmis = 1.0f;
-                        if (rc.strategy == RL_STRATEGY_ALL) {              // ls.pdf is a solid-angle pdf for mesh lights
+                        if (rc.strategy == RL_STRATEGY_ALL && ls.pdf_kind == PDF_SOLID_ANGLE) {   // Discrete (point / directional): no MIS
                             float total = (0.0f + p_dir) + ls.pdf;
                             wmis = div_rn(ls.pdf, total);
                         }
@@ -556,7 +583,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, const Pool&
         }
         storec(pool, slot, F_BR, beta);
         storec(pool, slot, F_LR, L);
-    } else if (primary) storec(pool, slot, F_LR, L);   // camera ray left the scene: the sample is 0
+    } else if (primary && sc.env_emitter < 0) storec(pool, slot, F_LR, L);   // camera ray left the scene: the sample is 0
     PU(U_FLAGS) = new_flags;
 }
 
@@ -783,6 +810,15 @@ extern "C" int rl_context_create(const rl_scene* scene, int device, rl_context**
         if ((rc = upload(ctx, scene->emitters, &ds.emitters)) != RL_OK) break;
         if ((rc = upload(ctx, scene->emitters_cdf, &ds.emitters_cdf)) != RL_OK) break;
         ds.n_emitters = (uint32_t)scene->emitters.size();
+        ds.env_emitter = -1;
+        for (size_t e = 0; e < scene->emitters.size(); e++)
+            if (scene->emitters[e].kind == EMITTER_ENV) {
+                ds.env_emitter = (int32_t)e;
+                for (int k = 0; k < 3; k++) ds.env_color[k] = scene->emitters[e].c[k];
+                // EnvironmentLight::direct_pdf = SolidAngle(1 / (4 pi)) * EmitterSampler::pdf(env)
+                ds.env_pdf = (1.0f / (3.14159265358979323846f * 4.0f)) * (scene->emitters_cdf[e + 1] - scene->emitters_cdf[e]);
+            }
+        if (ds.env_emitter >= 0 && scene->medium.enabled) { rl_set_error("an environment emitter cannot be combined with a medium (paths/edge.rs:94)"); rc = RL_ERR_UNSUPPORTED; break; }
         if ((rc = upload(ctx, flat.mesh_cdf, &ds.mesh_cdf)) != RL_OK) break;
         ds.n_meshes = (uint32_t)flat.meshes.size();
         scene->sample_to_camera.to_cols(ds.camera.sample_to_camera);

@@ -82,6 +82,8 @@ class SceneData:
     meshes: List[MeshData]
     medium: Optional[Medium] = None
     bitmaps: list = field(default_factory=list)
+    lights: list = field(default_factory=list)           # [{"type": "point"|"directional", "a": position|direction, "intensity": rgb}]
+    environment: Optional[tuple] = None                  # EnvironmentLightColor::Constant(rgb)
 
     @property
     def n_triangles(self) -> int:
@@ -176,6 +178,22 @@ def single_triangle() -> SceneData:
     light = _quad_mesh("light", [-1, -1, 5, 1, -1, 5, 1, 1, 5, -1, 1, 5], [0, 0, -1], matte((0, 0, 0)), emission=(1, 1, 1))
     to_world = np.asarray([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0.25, 0.25, -3, 1], dtype=np.float32)
     return SceneData(32, 32, 40.0, 0, to_world, False, [m, light])
+
+
+def cbox_other_lights(width: int = 64, height: int = 64, point=True, directional=True, environment=True, keep_area_light=True) -> SceneData:
+    """Cornell box lit by the non-mesh emitters of SURVEY.md a24 (point, directional, constant environment)."""
+    sd = cbox(width, height)
+    if not keep_area_light:
+        sd.meshes[-1].emission = None
+    if point:
+        sd.lights.append({"type": "point", "a": (0.3, 1.5, 0.4), "intensity": (2.0, 1.5, 1.0)})
+    if directional:
+        d = np.asarray((0.3, -0.8, -0.52), dtype=np.float64)
+        d = d / np.linalg.norm(d)
+        sd.lights.append({"type": "directional", "a": tuple(float(np.float32(x)) for x in d), "intensity": (1.0, 1.0, 1.2)})
+    if environment:
+        sd.environment = (0.3, 0.4, 0.6)
+    return sd
 
 
 def furnace(albedo: float = 0.5, le: float = 1.0, width: int = 32, height: int = 32) -> SceneData:

@@ -163,6 +163,14 @@ def test_phong_beckmann_textures_parity(built):
     _assert_parity(*_render_pair(sd, spp=4, max_depth=8))
 
 
+@pytest.mark.parametrize("combo", [dict(), dict(keep_area_light=False), dict(point=False, directional=False), dict(environment=False, keep_area_light=False)])
+def test_point_directional_environment_emitters_parity(built, combo):
+    """SURVEY.md a24: PointEmitter, DirectionalLight, EnvironmentLight::Constant next to / instead of the mesh light."""
+    sd = scenes.cbox_other_lights(48, 48, **combo)
+    for kw in (dict(spp=4), dict(spp=2, strategy=api.STRATEGY_EMITTER), dict(spp=2, strategy=api.STRATEGY_BSDF, max_depth=6), dict(spp=2, min_depth=1)):
+        _assert_parity(*_render_pair(sd, **kw))
+
+
 def test_furnace_invariant_on_gpu(built):
     sd = scenes.furnace(albedo=0.5, le=1.0, width=16, height=16)
     ctx = api.Context(api.Scene(sd), 0)
