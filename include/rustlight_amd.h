@@ -192,7 +192,11 @@ typedef struct rl_path_params {
     uint32_t shard_count;
     /* tuning: number of path slots resident on the device (0 = auto). Does not change results. */
     uint32_t pool_slots;
-    uint32_t reserved[3];
+    /* 0 = auto, 1 = wavefront stage kernels (raygen / extend / shade / shadow per iteration, state in HBM),
+     * 2 = persistent fused kernel (same stages in one launch, state in registers; single-BSDF scenes).
+     * Does not change results. */
+    uint32_t pipeline;
+    uint32_t reserved[2];
 } rl_path_params;
 
 void rl_path_params_default(rl_path_params* params);   /* CLI defaults: examples/cli.rs:53-61,167-168 */
@@ -208,7 +212,7 @@ typedef struct rl_render_stats {
     uint64_t kernel_launches;
     double render_ms;             /* wall time of the call (the reference's own timed region, mod.rs:324-334) */
     /* per-kernel accumulated device time from HIP events on the render stream (ms) */
-    double ms_raygen, ms_extend, ms_shade, ms_shadow, ms_compact, ms_other;
+    double ms_raygen, ms_extend, ms_shade, ms_shadow, ms_compact, ms_other;   /* ms_other = the fused kernel */
     uint64_t n_extend_launches;
     uint64_t reserved[4];
 } rl_render_stats;

@@ -23,6 +23,7 @@ RL_OK = 0
 RL_ERR_NO_DEVICE = -2
 STRATEGY_ALL, STRATEGY_BSDF, STRATEGY_EMITTER = 0, 1, 2
 STREAM_REFERENCE_ORDER, STREAM_PER_SAMPLE = 0, 1
+PIPELINE_AUTO, PIPELINE_WAVEFRONT, PIPELINE_FUSED = 0, 1, 2
 
 # every symbol include/rustlight_amd.h declares (tests check the .so exports all of them)
 PUBLIC_SYMBOLS = [
@@ -214,7 +215,7 @@ class Scene:
 
 
 def path_params(spp=1, min_depth=0, max_depth=None, rr_depth=0, strategy=STRATEGY_ALL, single_scattering=False,
-                stream_mode=STREAM_PER_SAMPLE, seed_variant=0, shard_index=0, shard_count=1, pool_slots=0) -> abi.PathParams:
+                stream_mode=STREAM_PER_SAMPLE, seed_variant=0, shard_index=0, shard_count=1, pool_slots=0, pipeline=0) -> abi.PathParams:
     p = abi.PathParams()
     lib().rl_path_params_default(C.byref(p))
     p.spp = spp
@@ -227,6 +228,7 @@ def path_params(spp=1, min_depth=0, max_depth=None, rr_depth=0, strategy=STRATEG
     p.seed_variant = seed_variant
     p.shard_index, p.shard_count = shard_index, shard_count
     p.pool_slots = pool_slots
+    p.pipeline = pipeline
     return p
 
 

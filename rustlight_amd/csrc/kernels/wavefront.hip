@@ -68,6 +68,9 @@ enum : unsigned {
 };
 enum : unsigned { PREV_SENSOR = 0u, PREV_SURFACE = 1u, PREV_SURFACE_SMOOTH = 2u, PREV_VOLUME = 3u };
 
+#ifndef RL_FUSED_WAVES
+#define RL_FUSED_WAVES 4   // min waves per SIMD requested for the persistent fused kernel (<= 168 VGPRs)
+#endif
 static constexpr unsigned kDepthCap = 2048u;   // same cut as the oracle (NaN-throughput paths never die)
 
 struct Pool {
@@ -118,16 +121,32 @@ struct RenderConst {
     unsigned long long* partials;       // [max grid blocks][STAT_COUNT] statistics rows
 };
 
-#define PF(field) pool.f[(size_t)(field) * pool.P + slot]
-#define PU(field) pool.u[(size_t)(field) * pool.P + slot]
-#define PQ(field) pool.q[(size_t)(field) * pool.P + slot]
+// Path-state accessors.  The stage functions below are written once against `ps.f/u/q(field)`:
+//  * PoolState: the wavefront kernels — state lives in the HBM pool, one coalesced word per lane;
+//  * RegState:  the persistent fused kernel — the same fields are plain locals (every index is a compile-time
+//    constant, so the arrays are scalarised into VGPRs and untouched fields disappear).
+struct PoolState {
+    Pool pool; unsigned slot;
+    RL_DEV float& f(int field) const { return pool.f[(size_t)field * pool.P + slot]; }
+    RL_DEV unsigned& u(int field) const { return pool.u[(size_t)field * pool.P + slot]; }
+    RL_DEV unsigned long long& q(int field) const { return pool.q[(size_t)field * pool.P + slot]; }
+};
+struct RegState {
+    float fv[F_COUNT]; unsigned uv[U_COUNT]; unsigned long long qv[Q_COUNT];
+    RL_DEV float& f(int field) { return fv[field]; }
+    RL_DEV unsigned& u(int field) { return uv[field]; }
+    RL_DEV unsigned long long& q(int field) { return qv[field]; }
+};
+#define PF(field) ps.f(field)
+#define PU(field) ps.u(field)
+#define PQ(field) ps.q(field)
 
-RL_DEV V3 load3(const Pool& pool, unsigned slot, int f0) { return mk3(PF(f0), PF(f0 + 1), PF(f0 + 2)); }
-RL_DEV Col loadc(const Pool& pool, unsigned slot, int f0) { return mkc(PF(f0), PF(f0 + 1), PF(f0 + 2)); }
-RL_DEV void store3(const Pool& pool, unsigned slot, int f0, V3 v) { PF(f0) = v.x; PF(f0 + 1) = v.y; PF(f0 + 2) = v.z; }
-RL_DEV void storec(const Pool& pool, unsigned slot, int f0, Col c) { PF(f0) = c.r; PF(f0 + 1) = c.g; PF(f0 + 2) = c.b; }
-RL_DEV Rng load_rng(const Pool& pool, unsigned slot, int q0) { Rng r; r.s0 = PQ(q0); r.s1 = PQ(q0 + 1); r.s2 = PQ(q0 + 2); r.s3 = PQ(q0 + 3); return r; }
-RL_DEV void store_rng(const Pool& pool, unsigned slot, int q0, const Rng& r) { PQ(q0) = r.s0; PQ(q0 + 1) = r.s1; PQ(q0 + 2) = r.s2; PQ(q0 + 3) = r.s3; }
+template <class PS> RL_DEV V3 load3(PS& ps, int f0) { return mk3(PF(f0), PF(f0 + 1), PF(f0 + 2)); }
+template <class PS> RL_DEV Col loadc(PS& ps, int f0) { return mkc(PF(f0), PF(f0 + 1), PF(f0 + 2)); }
+template <class PS> RL_DEV void store3(PS& ps, int f0, V3 v) { PF(f0) = v.x; PF(f0 + 1) = v.y; PF(f0 + 2) = v.z; }
+template <class PS> RL_DEV void storec(PS& ps, int f0, Col c) { PF(f0) = c.r; PF(f0 + 1) = c.g; PF(f0 + 2) = c.b; }
+template <class PS> RL_DEV Rng load_rng(PS& ps, int q0) { Rng r; r.s0 = PQ(q0); r.s1 = PQ(q0 + 1); r.s2 = PQ(q0 + 2); r.s3 = PQ(q0 + 3); return r; }
+template <class PS> RL_DEV void store_rng(PS& ps, int q0, const Rng& r) { PQ(q0) = r.s0; PQ(q0 + 1) = r.s1; PQ(q0 + 2) = r.s2; PQ(q0 + 3) = r.s3; }
 
 // Statistics without atomics on shared words (a device-scope atomic on one word costs ~10 ns and
 // serialises: MI355X_MICROARCH "fanin"): wave64 shuffle sum -> LDS per block -> one plain
@@ -200,125 +219,166 @@ __global__ void k_seed_pixels(RenderConst rc) {
 __global__ void k_init(RenderConst rc, Pool pool) {
     unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= pool.P) return;
+    PoolState ps{pool, slot};
     PU(U_ITEM) = slot;
     PU(U_CURSOR) = 0u;
     PU(U_SAMPLE) = 0u;
     PU(U_DEPTH) = 0u;
     PU(U_PRIM) = 0xffffffffu;
     PU(U_FLAGS) = slot < rc.n_items ? (ST_REGEN | ST_FRESH) : ST_FINISHED;
-    storec(pool, slot, F_AR, czero());
-    storec(pool, slot, F_LR, czero());
+    storec(ps, F_AR, czero());
+    storec(ps, F_LR, czero());
 }
 
 // ------------------------------------------------------------------------------------------
-// k_raygen — persistent threads (grid-stride): sample completion, work-item hand-out, seeding,
-// Path::from_sensor (2 draws) and Camera::generate.
+// raygen_slot — sample completion, work-item hand-out, sampler forking, Path::from_sensor (2 draws) and
+// Camera::generate for one slot that asked for regeneration.  DYNAMIC: work items come from the global
+// dispenser (wavefront pool); otherwise the slot owns exactly one item (persistent fused kernel).
+template <bool DYNAMIC, class PS>
+RL_DEV void raygen_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, unsigned& n_samples, unsigned& n_draws) {
+    unsigned flags = PU(U_FLAGS);
+    if (!(flags & ST_REGEN)) return;
+    const bool fresh = (flags & ST_FRESH) != 0u;
+    unsigned item = PU(U_ITEM), s = PU(U_SAMPLE), cursor = PU(U_CURSOR);
+    Col acc = loadc(ps, F_AR);
+    bool need_item = fresh;
+    unsigned bx = 0, by = 0, bw = 1, bh = 1;
+    if (rc.stream_mode == RL_STREAM_REFERENCE_ORDER && item < rc.n_items) block_geometry(rc, rc.owned_blocks[item], &bx, &by, &bw, &bh);
+    if (!fresh) {
+        // im_block.accumulate(.., c, "primal") in sample order (mod.rs:431)
+        acc = acc + loadc(ps, F_LR);
+        s++;
+        if (s == rc.spp) {
+            unsigned pix = rc.stream_mode == RL_STREAM_PER_SAMPLE ? rc.item_pixel[item] : (by + cursor / bw) * rc.W + (bx + cursor % bw);
+            Col px = scale_unguarded(acc, rc.inv_spp);            // im_block.scale(1 / spp) (mod.rs:436)
+            rc.out[3 * (size_t)pix] = px.r; rc.out[3 * (size_t)pix + 1] = px.g; rc.out[3 * (size_t)pix + 2] = px.b;
+            acc = czero();
+            s = 0;
+            if (rc.stream_mode == RL_STREAM_PER_SAMPLE) need_item = true;
+            else { cursor++; if (cursor == bw * bh) need_item = true; }
+        }
+    }
+    Rng rng;
+    if (need_item) {
+        if (!fresh) item = DYNAMIC ? atomicAdd(&rc.counters->next_item, 1u) : rc.n_items;   // fused kernel: one item per thread
+        if (item >= rc.n_items) {
+            PU(U_FLAGS) = ST_FINISHED;
+            if (DYNAMIC) atomicSub(&rc.counters->active, 1u);
+            return;
+        }
+        cursor = 0;
+        if (rc.stream_mode == RL_STREAM_PER_SAMPLE) {
+            Rng item_rng = rng_seed(rc.item_seed[item], rc.seed_variant);   // pixel sampler = block_sampler.clone_box()
+            rng = rng_seed(rng_next_u64(item_rng), rc.seed_variant);        // sample sampler = pixel_sampler.clone_box()
+            store_rng(ps, Q_I0, item_rng);
+        } else {
+            unsigned b = rc.owned_blocks[item];
+            block_geometry(rc, b, &bx, &by, &bw, &bh);
+            rng = rng_seed(rc.block_seeds[b], rc.seed_variant);            // the block's own sampler (mod.rs:371)
+        }
+        PU(U_ITEM) = item;
+    } else if (rc.stream_mode == RL_STREAM_PER_SAMPLE) {
+        Rng item_rng = load_rng(ps, Q_I0);
+        rng = rng_seed(rng_next_u64(item_rng), rc.seed_variant);
+        store_rng(ps, Q_I0, item_rng);
+    } else {
+        rng = load_rng(ps, Q_R0);
+    }
+    unsigned px, py;
+    if (rc.stream_mode == RL_STREAM_PER_SAMPLE) { unsigned pix = rc.item_pixel[item]; px = pix % rc.W; py = pix / rc.W; }
+    else { px = bx + cursor % bw; py = by + cursor / bw; }
+    // Path::from_sensor: uv = (ix + next(), iy + next())
+    float u = (float)px + rng_next_f32(rng);
+    float v = (float)py + rng_next_f32(rng);
+    n_draws += 2;
+    n_samples++;
+    storec(ps, F_AR, acc);
+    PU(U_SAMPLE) = s;
+    PU(U_CURSOR) = cursor;
+    const bool expand = (!rc.has_max || 1u < rc.max_depth);   // TechniquePathTracing::expand at depth 1
+    if (!expand) {   // sensor not expanded: the sample is 0 (next raygen pass folds it)
+        storec(ps, F_LR, czero());
+        store_rng(ps, Q_R0, rng);
+        PU(U_FLAGS) = ST_REGEN;
+        return;
+    }
+    // Camera::generate (camera.rs:81-91)
+    const float* m = sc.camera.sample_to_camera;
+    float sx = div_rn(u, (float)sc.camera.width), sy = div_rn(v, (float)sc.camera.height), sz = 0.0f;
+    float hx = ((m[0] * sx + m[4] * sy) + m[8] * sz) + m[12] * 1.0f;
+    float hy = ((m[1] * sx + m[5] * sy) + m[9] * sz) + m[13] * 1.0f;
+    float hz = ((m[2] * sx + m[6] * sy) + m[10] * sz) + m[14] * 1.0f;
+    float hw = ((m[3] * sx + m[7] * sy) + m[11] * sz) + m[15] * 1.0f;
+    float inv_w = div_rn(1.0f, hw);
+    V3 near_p = mk3(hx * inv_w, hy * inv_w, hz * inv_w);
+    V3 dl = normalize(near_p);
+    const float* tw = sc.camera.to_world;
+    V3 d = mk3(((tw[0] * dl.x + tw[4] * dl.y) + tw[8] * dl.z) + tw[12] * 0.0f,
+               ((tw[1] * dl.x + tw[5] * dl.y) + tw[9] * dl.z) + tw[13] * 0.0f,
+               ((tw[2] * dl.x + tw[6] * dl.y) + tw[10] * dl.z) + tw[14] * 0.0f);
+    // the sensor edge's state is implied by PREV_SENSOR and never stored: origin = Camera::position(),
+    // weight 1, rr_weight 1, PDF::SolidAngle(1), beta = thr = 1 (strategies/directional.rs:27-41)
+    store3(ps, F_DX, d);
+    if (sc.medium.enabled) { PF(F_XI) = rng_next_f32(rng); n_draws++; }   // Edge::from_ray's medium.sample(ray, next())
+    store_rng(ps, Q_R0, rng);
+    PU(U_DEPTH) = 1u;
+    PU(U_FLAGS) = ST_RAY | (PREV_SENSOR << ST_PREV_SHIFT) | ST_PDF_SA;
+}
+
+// k_raygen — persistent threads (grid-stride loop over the pool).
 __global__ void __launch_bounds__(256) k_raygen(RenderConst rc, DeviceScene sc, Pool pool) {
     unsigned n_samples = 0, n_draws = 0;
     for (unsigned slot = blockIdx.x * blockDim.x + threadIdx.x; slot < pool.P; slot += gridDim.x * blockDim.x) {
-        unsigned flags = PU(U_FLAGS);
-        if (!(flags & ST_REGEN)) continue;
-        const bool fresh = (flags & ST_FRESH) != 0u;
-        unsigned item = PU(U_ITEM), s = PU(U_SAMPLE), cursor = PU(U_CURSOR);
-        Col acc = loadc(pool, slot, F_AR);
-        bool need_item = fresh;
-        unsigned bx = 0, by = 0, bw = 1, bh = 1;
-        if (rc.stream_mode == RL_STREAM_REFERENCE_ORDER && item < rc.n_items) block_geometry(rc, rc.owned_blocks[item], &bx, &by, &bw, &bh);
-        if (!fresh) {
-            // im_block.accumulate(.., c, "primal") in sample order (mod.rs:431)
-            acc = acc + loadc(pool, slot, F_LR);
-            s++;
-            if (s == rc.spp) {
-                unsigned pix = rc.stream_mode == RL_STREAM_PER_SAMPLE ? rc.item_pixel[item] : (by + cursor / bw) * rc.W + (bx + cursor % bw);
-                Col px = scale_unguarded(acc, rc.inv_spp);            // im_block.scale(1 / spp) (mod.rs:436)
-                rc.out[3 * (size_t)pix] = px.r; rc.out[3 * (size_t)pix + 1] = px.g; rc.out[3 * (size_t)pix + 2] = px.b;
-                acc = czero();
-                s = 0;
-                if (rc.stream_mode == RL_STREAM_PER_SAMPLE) need_item = true;
-                else { cursor++; if (cursor == bw * bh) need_item = true; }
-            }
-        }
-        Rng rng;
-        if (need_item) {
-            if (!fresh) item = atomicAdd(&rc.counters->next_item, 1u);
-            if (item >= rc.n_items) {
-                PU(U_FLAGS) = ST_FINISHED;
-                atomicSub(&rc.counters->active, 1u);
-                continue;
-            }
-            cursor = 0;
-            if (rc.stream_mode == RL_STREAM_PER_SAMPLE) {
-                Rng item_rng = rng_seed(rc.item_seed[item], rc.seed_variant);   // pixel sampler = block_sampler.clone_box()
-                rng = rng_seed(rng_next_u64(item_rng), rc.seed_variant);        // sample sampler = pixel_sampler.clone_box()
-                store_rng(pool, slot, Q_I0, item_rng);
-            } else {
-                unsigned b = rc.owned_blocks[item];
-                block_geometry(rc, b, &bx, &by, &bw, &bh);
-                rng = rng_seed(rc.block_seeds[b], rc.seed_variant);            // the block's own sampler (mod.rs:371)
-            }
-            PU(U_ITEM) = item;
-        } else if (rc.stream_mode == RL_STREAM_PER_SAMPLE) {
-            Rng item_rng = load_rng(pool, slot, Q_I0);
-            rng = rng_seed(rng_next_u64(item_rng), rc.seed_variant);
-            store_rng(pool, slot, Q_I0, item_rng);
-        } else {
-            rng = load_rng(pool, slot, Q_R0);
-        }
-        unsigned px, py;
-        if (rc.stream_mode == RL_STREAM_PER_SAMPLE) { unsigned pix = rc.item_pixel[item]; px = pix % rc.W; py = pix / rc.W; }
-        else { px = bx + cursor % bw; py = by + cursor / bw; }
-        // Path::from_sensor: uv = (ix + next(), iy + next())
-        float u = (float)px + rng_next_f32(rng);
-        float v = (float)py + rng_next_f32(rng);
-        n_draws += 2;
-        n_samples++;
-        storec(pool, slot, F_AR, acc);
-        PU(U_SAMPLE) = s;
-        PU(U_CURSOR) = cursor;
-        const bool expand = (!rc.has_max || 1u < rc.max_depth);   // TechniquePathTracing::expand at depth 1
-        if (!expand) {   // sensor not expanded: the sample is 0 (next raygen pass folds it)
-            storec(pool, slot, F_LR, czero());
-            store_rng(pool, slot, Q_R0, rng);
-            PU(U_FLAGS) = ST_REGEN;
-            continue;
-        }
-        // Camera::generate (camera.rs:81-91)
-        const float* m = sc.camera.sample_to_camera;
-        float sx = div_rn(u, (float)sc.camera.width), sy = div_rn(v, (float)sc.camera.height), sz = 0.0f;
-        float hx = ((m[0] * sx + m[4] * sy) + m[8] * sz) + m[12] * 1.0f;
-        float hy = ((m[1] * sx + m[5] * sy) + m[9] * sz) + m[13] * 1.0f;
-        float hz = ((m[2] * sx + m[6] * sy) + m[10] * sz) + m[14] * 1.0f;
-        float hw = ((m[3] * sx + m[7] * sy) + m[11] * sz) + m[15] * 1.0f;
-        float inv_w = div_rn(1.0f, hw);
-        V3 near_p = mk3(hx * inv_w, hy * inv_w, hz * inv_w);
-        V3 dl = normalize(near_p);
-        const float* tw = sc.camera.to_world;
-        V3 d = mk3(((tw[0] * dl.x + tw[4] * dl.y) + tw[8] * dl.z) + tw[12] * 0.0f,
-                   ((tw[1] * dl.x + tw[5] * dl.y) + tw[9] * dl.z) + tw[13] * 0.0f,
-                   ((tw[2] * dl.x + tw[6] * dl.y) + tw[10] * dl.z) + tw[14] * 0.0f);
-        // the sensor edge's state is implied by PREV_SENSOR and never stored: origin = Camera::position(),
-        // weight 1, rr_weight 1, PDF::SolidAngle(1), beta = thr = 1 (strategies/directional.rs:27-41)
-        store3(pool, slot, F_DX, d);
-        if (sc.medium.enabled) { PF(F_XI) = rng_next_f32(rng); n_draws++; }   // Edge::from_ray's medium.sample(ray, next())
-        store_rng(pool, slot, Q_R0, rng);
-        PU(U_DEPTH) = 1u;
-        PU(U_FLAGS) = ST_RAY | (PREV_SENSOR << ST_PREV_SHIFT) | ST_PDF_SA;
+        PoolState ps{pool, slot};
+        raygen_slot<true>(rc, sc, ps, n_samples, n_draws);
     }
     { const int which[2] = {STAT_SAMPLES, STAT_DRAWS}; const unsigned vals[2] = {n_samples, n_draws}; block_stats<2>(rc.partials, which, vals); }
 }
 
 // ------------------------------------------------------------------------------------------
-// k_extend / k_shadow — traversal kernels.  Dynamic LDS = [staged scene] + per-lane stack.
-template <bool LDS_SCENE>
-__global__ void __launch_bounds__(256) k_extend(RenderConst rc, DeviceScene sc, Pool pool, StackConf stc) {
+// extend_slot / shadow_slot — Acceleration::trace and Acceleration::visible for one slot.
+template <class PS>
+RL_DEV void extend_slot(const DeviceScene& sc, const SceneRecs& recs, const TravStack& stack, PS& ps) {
+    const unsigned flags = PU(U_FLAGS);
+    const bool primary = ((flags >> ST_PREV_SHIFT) & 3u) == PREV_SENSOR;    // camera rays start at Camera::position()
+    V3 o = primary ? mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]) : load3(ps, F_OX);
+    V3 d = load3(ps, F_DX);
+    Hit hit; hit.t = kF32Max; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
+    traverse<false>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
+                    o, d, kEps, kF32Max, hit, stack);
+    PF(F_T) = hit.t; PF(F_U) = hit.u; PF(F_V) = hit.v;
+    PU(U_PRIM) = (unsigned)hit.prim;
+}
+template <class PS>
+RL_DEV void shadow_slot(const DeviceScene& sc, const SceneRecs& recs, const TravStack& stack, PS& ps) {
+    // Acceleration::visible(p0, p1) (accel.rs:316-343)
+    V3 p0 = load3(ps, F_OX), p1 = load3(ps, F_SX);
+    V3 d = p1 - p0;
+    float len = length(d);
+    d = d / len;
+    float tfar = len * (1.0f - 0.00001f);
+    Hit hit; hit.t = tfar; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
+    V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
+    float te;
+    bool vis;
+    if (!slab(mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]), p0, inv_d, kEps, tfar, &te))
+        vis = false;   // root box missed => "occluded" (accel.rs:338-340)
+    else
+        vis = !traverse<true>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
+                              p0, d, kEps, tfar, hit, stack);
+    if (vis) storec(ps, F_LR, loadc(ps, F_LR) + loadc(ps, F_CR));
+}
+
+// k_extend / k_shadow — traversal kernels.  Dynamic LDS = [staged scene][compaction list][per-lane stacks].
+template <bool LDS_SCENE, bool SHADOW>
+RL_DEV void trace_kernel_body(const DeviceScene& sc, const Pool& pool, const StackConf& stc) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
-    // LDS layout: [staged scene (LDS_SCENE)] [compaction list 272 words] [per-lane stacks]
     float4* after_scene = LDS_SCENE ? smem + 4 * (sc.n_nodes + sc.n_prims) : smem;
     unsigned* list = reinterpret_cast<unsigned*>(after_scene);
     unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
     const TravStack stack = make_stack(stc, list + 272, slot);
-    unsigned flags = slot < pool.P ? PU(U_FLAGS) : 0u;
-    const unsigned n_live = block_compact((flags & ST_RAY) != 0u, slot, list);
+    const unsigned flags = slot < pool.P ? pool.u[(size_t)U_FLAGS * pool.P + slot] : 0u;
+    const unsigned n_live = block_compact((flags & (SHADOW ? ST_SHADOW : ST_RAY)) != 0u, slot, list);
     if (n_live == 0u) return;          // whole tile idle (finished pixels): skip the scene staging too
     SceneRecs recs;
     if (LDS_SCENE) {
@@ -329,80 +389,35 @@ __global__ void __launch_bounds__(256) k_extend(RenderConst rc, DeviceScene sc, 
         recs.tris = reinterpret_cast<const float4*>(sc.tris);
     }
     if (threadIdx.x < n_live) {
-        slot = list[threadIdx.x];
-        flags = PU(U_FLAGS);
-        const bool primary = ((flags >> ST_PREV_SHIFT) & 3u) == PREV_SENSOR;    // camera rays start at Camera::position()
-        V3 o = primary ? mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]) : load3(pool, slot, F_OX);
-        V3 d = load3(pool, slot, F_DX);
-        Hit hit; hit.t = kF32Max; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
-        traverse<false>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
-                        o, d, kEps, kF32Max, hit, stack);
-        PF(F_T) = hit.t; PF(F_U) = hit.u; PF(F_V) = hit.v;
-        PU(U_PRIM) = (unsigned)hit.prim;
+        PoolState ps{pool, list[threadIdx.x]};
+        if (SHADOW) shadow_slot(sc, recs, stack, ps);
+        else extend_slot(sc, recs, stack, ps);
     }
 }
 
 template <bool LDS_SCENE>
-__global__ void __launch_bounds__(256) k_shadow(RenderConst rc, DeviceScene sc, Pool pool, StackConf stc) {
-    extern __shared__ __attribute__((aligned(16))) float4 smem[];
-    // LDS layout: [staged scene (LDS_SCENE)] [compaction list 272 words] [per-lane stacks]
-    float4* after_scene = LDS_SCENE ? smem + 4 * (sc.n_nodes + sc.n_prims) : smem;
-    unsigned* list = reinterpret_cast<unsigned*>(after_scene);
-    unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const TravStack stack = make_stack(stc, list + 272, slot);
-    const unsigned flags = slot < pool.P ? PU(U_FLAGS) : 0u;
-    const unsigned n_live = block_compact((flags & ST_SHADOW) != 0u, slot, list);
-    if (n_live == 0u) return;          // whole tile idle (finished pixels): skip the scene staging too
-    SceneRecs recs;
-    if (LDS_SCENE) {
-        stage_scene_lds(sc, smem, smem + 4 * sc.n_nodes);
-        recs.nodes = smem; recs.tris = smem + 4 * sc.n_nodes;
-    } else {
-        recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
-        recs.tris = reinterpret_cast<const float4*>(sc.tris);
-    }
-    if (threadIdx.x < n_live) {
-        slot = list[threadIdx.x];
-        // Acceleration::visible(p0, p1) (accel.rs:316-343)
-        V3 p0 = load3(pool, slot, F_OX), p1 = load3(pool, slot, F_SX);
-        V3 d = p1 - p0;
-        float len = length(d);
-        d = d / len;
-        float tfar = len * (1.0f - 0.00001f);
-        Hit hit; hit.t = tfar; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
-        // traverse() starts with the root-box test: a segment that misses it is reported occluded
-        // only in the sense of "no hit found" => the caller below must treat a root miss as NOT visible
-        V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
-        float te;
-        bool vis;
-        if (!slab(mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]), p0, inv_d, kEps, tfar, &te))
-            vis = false;   // root box missed => "occluded" (accel.rs:338-340)
-        else
-            vis = !traverse<true>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
-                                  p0, d, kEps, tfar, hit, stack);
-        if (vis) storec(pool, slot, F_LR, loadc(pool, slot, F_LR) + loadc(pool, slot, F_CR));
-    }
-}
+__global__ void __launch_bounds__(256) k_extend(RenderConst rc, DeviceScene sc, Pool pool, StackConf stc) { trace_kernel_body<LDS_SCENE, false>(sc, pool, stc); }
+template <bool LDS_SCENE>
+__global__ void __launch_bounds__(256) k_shadow(RenderConst rc, DeviceScene sc, Pool pool, StackConf stc) { trace_kernel_body<LDS_SCENE, true>(sc, pool, stc); }
 
-// ------------------------------------------------------------------------------------------
 // shade_slot<MAT, MEDIUM> — one path vertex of one slot.  MAT >= 0: the hit material is known to have that
 // BSDF type (per-BSDF code path, uniform over the calling lanes); MAT = -1: generic (run-time switch).
-template <int MAT, bool MEDIUM>
-RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, const Pool& pool, unsigned slot, unsigned flags,
+template <int MAT, bool MEDIUM, class PS>
+RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, unsigned flags,
                        unsigned& n_vertices, unsigned& n_draws, unsigned& n_shadow, unsigned& n_ext) {
     n_ext += 1;      // every shaded slot carried exactly one extension ray through k_extend
     const unsigned prev = (flags >> ST_PREV_SHIFT) & 3u;
     const unsigned depth = PU(U_DEPTH);          // generate()'s depth at which the edge's origin vertex was expanded
     const int prim = (int)PU(U_PRIM);
     const bool primary = prev == PREV_SENSOR;     // sensor edge: implied state, see k_raygen
-    const V3 ro = primary ? mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]) : load3(pool, slot, F_OX);
-    const V3 rd = load3(pool, slot, F_DX);
+    const V3 ro = primary ? mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]) : load3(ps, F_OX);
+    const V3 rd = load3(ps, F_DX);
     const float t_hit = PF(F_T);
-    Col w_edge = primary ? cone() : loadc(pool, slot, F_WR);
+    Col w_edge = primary ? cone() : loadc(ps, F_WR);
     const float rr = primary ? 1.0f : PF(F_RR);
     const float pdf_edge = primary ? 1.0f : PF(F_PDF);
-    Col beta = primary ? cone() : loadc(pool, slot, F_BR);
-    Col L = primary ? czero() : loadc(pool, slot, F_LR);
+    Col beta = primary ? cone() : loadc(ps, F_BR);
+    Col L = primary ? czero() : loadc(ps, F_LR);
     bool zeroed = (flags & ST_ZEROED) != 0u;
     const bool hit = prim >= 0;
     bool is_volume = false;
@@ -437,7 +452,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, const Pool&
                     L = L + beta * (contrib * wmis);
                 }
             }
-            storec(pool, slot, F_LR, L);
+            storec(ps, F_LR, L);
         }
     }
     if (!ended) {
@@ -481,8 +496,8 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, const Pool&
         const bool expand = (rc.has_max ? gen < rc.max_depth : true) && gen < kDepthCap;
         if (expand) {
             n_vertices += 1;
-            Rng rng = load_rng(pool, slot, Q_R0);
-            Col thr = primary ? cone() : loadc(pool, slot, F_TR);
+            Rng rng = load_rng(ps, Q_R0);
+            Col thr = primary ? cone() : loadc(ps, F_TR);
             const V3 vp = is_volume ? vpos : sp.p;
             const V3 d_in = -rd;
             // strategy 0: DirectionalSamplingStrategy::bounce (strategies/directional.rs:44-153)
@@ -561,19 +576,19 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, const Pool&
                         // a zero contribution needs no visibility test: the image cannot change
                         if (!is_zero(pending)) {
                             shadow = true;
-                            store3(pool, slot, F_SX, ls.p);
-                            storec(pool, slot, F_CR, pending);
+                            store3(ps, F_SX, ls.p);
+                            storec(ps, F_CR, pending);
                         }
                     }
                 }
             }
-            store_rng(pool, slot, Q_R0, rng);
-            store3(pool, slot, F_OX, vp);
+            store_rng(ps, Q_R0, rng);
+            store3(ps, F_OX, vp);
             new_flags = shadow ? ST_SHADOW : 0u;
             if (has_edge) {
-                store3(pool, slot, F_DX, sd_world);
-                storec(pool, slot, F_TR, thr);
-                storec(pool, slot, F_WR, sw);
+                store3(ps, F_DX, sd_world);
+                storec(ps, F_TR, thr);
+                storec(ps, F_WR, sw);
                 PF(F_RR) = rr_new;
                 PF(F_PDF) = spdf;
                 PU(U_DEPTH) = gen;
@@ -581,9 +596,9 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, const Pool&
                 new_flags |= ST_RAY | (kind << ST_PREV_SHIFT) | (spdf_kind == PDF_SOLID_ANGLE ? ST_PDF_SA : 0u) | (zeroed ? ST_ZEROED : 0u);
             } else new_flags |= ST_REGEN;
         }
-        storec(pool, slot, F_BR, beta);
-        storec(pool, slot, F_LR, L);
-    } else if (primary && sc.env_emitter < 0) storec(pool, slot, F_LR, L);   // camera ray left the scene: the sample is 0
+        storec(ps, F_BR, beta);
+        storec(ps, F_LR, L);
+    } else if (primary && sc.env_emitter < 0) storec(ps, F_LR, L);   // camera ray left the scene: the sample is 0
     PU(U_FLAGS) = new_flags;
 }
 
@@ -592,8 +607,9 @@ template <int MAT, bool MEDIUM>
 __global__ void __launch_bounds__(256) k_shade(RenderConst rc, DeviceScene sc, Pool pool) {
     unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned n_vertices = 0, n_draws = 0, n_shadow = 0, n_ext = 0;
+    PoolState ps{pool, slot};
     unsigned flags = slot < pool.P ? PU(U_FLAGS) : 0u;
-    if (flags & ST_RAY) shade_slot<MAT, MEDIUM>(rc, sc, pool, slot, flags, n_vertices, n_draws, n_shadow, n_ext);
+    if (flags & ST_RAY) shade_slot<MAT, MEDIUM>(rc, sc, ps, flags, n_vertices, n_draws, n_shadow, n_ext);
     {
         const int which[4] = {STAT_VERTICES, STAT_DRAWS, STAT_SHADOW_RAYS, STAT_EXT_RAYS};
         const unsigned vals[4] = {n_vertices, n_draws, n_shadow, n_ext};
@@ -612,6 +628,7 @@ __global__ void __launch_bounds__(256) k_shade_sorted(RenderConst rc, DeviceScen
     __shared__ unsigned s_wave_cnt[kNumBins][4];
     unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned n_vertices = 0, n_draws = 0, n_shadow = 0, n_ext = 0;
+    PoolState ps{pool, slot};
     const unsigned flags = slot < pool.P ? PU(U_FLAGS) : 0u;
     int bin = -1;
     if (flags & ST_RAY) {
@@ -641,14 +658,61 @@ __global__ void __launch_bounds__(256) k_shade_sorted(RenderConst rc, DeviceScen
     __syncthreads();
 #define RL_SHADE_BIN(B)                                                                                       \
     { const unsigned n = bin_begin[(B) + 1] - bin_begin[B];                                                   \
-      if (threadIdx.x < n) { const unsigned sl = s_list[bin_begin[B] + threadIdx.x];                           \
-          shade_slot<B, MEDIUM>(rc, sc, pool, sl, pool.u[(size_t)U_FLAGS * pool.P + sl], n_vertices, n_draws, n_shadow, n_ext); } }
+      if (threadIdx.x < n) { PoolState pb{pool, s_list[bin_begin[B] + threadIdx.x]};                           \
+          shade_slot<B, MEDIUM>(rc, sc, pb, pb.u(U_FLAGS), n_vertices, n_draws, n_shadow, n_ext); } }
     RL_SHADE_BIN(0) RL_SHADE_BIN(1) RL_SHADE_BIN(2) RL_SHADE_BIN(3) RL_SHADE_BIN(4)
 #undef RL_SHADE_BIN
     {
         const int which[4] = {STAT_VERTICES, STAT_DRAWS, STAT_SHADOW_RAYS, STAT_EXT_RAYS};
         const unsigned vals[4] = {n_vertices, n_draws, n_shadow, n_ext};
         block_stats<4>(rc.partials, which, vals);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_path_fused<MAT, MEDIUM, LDS> — the persistent form of the pipeline for scenes with one BSDF type: one
+// launch, one lane per pixel item, the four stage functions above run back-to-back per iteration
+// (raygen -> extend -> shade -> shadow) with the whole path state in registers (RegState) and the scene +
+// traversal stacks in LDS.  Same functions, same order of operations, same results as the wavefront kernels;
+// what disappears is ~1.4 KB/sample of state traffic through HBM and ~2000 kernel boundaries per render.
+template <int MAT, bool MEDIUM, bool LDS_SCENE>
+__global__ void __launch_bounds__(256, RL_FUSED_WAVES) k_path_fused(RenderConst rc, DeviceScene sc, StackConf stc) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    SceneRecs recs;
+    float4* after_scene = smem;
+    if (LDS_SCENE) {
+        stage_scene_lds(sc, smem, smem + 4 * sc.n_nodes);
+        recs.nodes = smem; recs.tris = smem + 4 * sc.n_nodes;
+        after_scene = smem + 4 * (sc.n_nodes + sc.n_prims);
+    } else {
+        recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
+        recs.tris = reinterpret_cast<const float4*>(sc.tris);
+    }
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const TravStack stack = make_stack(stc, reinterpret_cast<unsigned*>(after_scene), tid);
+    RegState ps;
+#pragma unroll
+    for (int i = 0; i < F_COUNT; i++) ps.fv[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < U_COUNT; i++) ps.uv[i] = 0u;
+#pragma unroll
+    for (int i = 0; i < Q_COUNT; i++) ps.qv[i] = 0ull;
+    PU(U_ITEM) = tid;
+    PU(U_PRIM) = 0xffffffffu;
+    PU(U_FLAGS) = tid < rc.n_items ? (ST_REGEN | ST_FRESH) : ST_FINISHED;
+    unsigned n_samples = 0, n_draws = 0, n_vertices = 0, n_shadow = 0, n_ext = 0;
+    while (!(PU(U_FLAGS) & ST_FINISHED)) {
+        if (PU(U_FLAGS) & ST_REGEN) raygen_slot<false>(rc, sc, ps, n_samples, n_draws);
+        if (PU(U_FLAGS) & ST_RAY) {
+            extend_slot(sc, recs, stack, ps);
+            shade_slot<MAT, MEDIUM>(rc, sc, ps, PU(U_FLAGS), n_vertices, n_draws, n_shadow, n_ext);
+        }
+        if (PU(U_FLAGS) & ST_SHADOW) shadow_slot(sc, recs, stack, ps);
+    }
+    {
+        const int which[5] = {STAT_SAMPLES, STAT_VERTICES, STAT_DRAWS, STAT_SHADOW_RAYS, STAT_EXT_RAYS};
+        const unsigned vals[5] = {n_samples, n_vertices, n_draws, n_shadow, n_ext};
+        block_stats<5>(rc.partials, which, vals);
     }
 }
 
@@ -903,6 +967,21 @@ static void launch_shade_type(int type, bool medium, dim3 grid, dim3 block, hipS
     }
 }
 
+template <int MAT>
+static void launch_fused(bool medium, bool lds, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc) {
+    if (medium) { if (lds) hipLaunchKernelGGL((k_path_fused<MAT, true, true>), grid, block, lds_bytes, st, rc, ds, stc); else hipLaunchKernelGGL((k_path_fused<MAT, true, false>), grid, block, lds_bytes, st, rc, ds, stc); }
+    else { if (lds) hipLaunchKernelGGL((k_path_fused<MAT, false, true>), grid, block, lds_bytes, st, rc, ds, stc); else hipLaunchKernelGGL((k_path_fused<MAT, false, false>), grid, block, lds_bytes, st, rc, ds, stc); }
+}
+static void launch_fused_type(int type, bool medium, bool lds, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc) {
+    switch (type) {
+        case BSDF_DIFFUSE: launch_fused<BSDF_DIFFUSE>(medium, lds, grid, block, lds_bytes, st, rc, ds, stc); break;
+        case BSDF_PHONG: launch_fused<BSDF_PHONG>(medium, lds, grid, block, lds_bytes, st, rc, ds, stc); break;
+        case BSDF_METAL: launch_fused<BSDF_METAL>(medium, lds, grid, block, lds_bytes, st, rc, ds, stc); break;
+        case BSDF_GLASS: launch_fused<BSDF_GLASS>(medium, lds, grid, block, lds_bytes, st, rc, ds, stc); break;
+        default: launch_fused<BSDF_SUBSTRATE>(medium, lds, grid, block, lds_bytes, st, rc, ds, stc); break;
+    }
+}
+
 extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, const uint64_t* block_seeds, size_t n_blocks, float* out_rgb,
                               int out_is_device, void* stream_arg, rl_render_stats* stats) {
     if (!ctx || !params || !block_seeds || !out_rgb) return RL_ERR_INVALID_ARGUMENT;
@@ -932,8 +1011,13 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     }
     const bool per_sample = params->stream_mode == RL_STREAM_PER_SAMPLE;
     const unsigned n_items = per_sample ? n_pixels : (unsigned)owned.size();
+    // pipeline: 1 = wavefront stage kernels, 2 = persistent fused kernel (single-BSDF scenes), 0 = auto
+    if (params->pipeline > 2) return RL_ERR_INVALID_ARGUMENT;
+    if (params->pipeline == 2 && !ctx->single_bsdf) { rl_set_error("the fused pipeline needs a scene with a single BSDF type"); return RL_ERR_UNSUPPORTED; }
+    const bool fused = params->pipeline == 2 || (params->pipeline == 0 && ctx->single_bsdf && per_sample && params->pool_slots == 0);
     unsigned P = params->pool_slots ? params->pool_slots : std::min<unsigned>(n_items, 4u << 20);
     P = std::max(256u, (P + 255u) / 256u * 256u);
+    if (fused) P = std::max(256u, (n_items + 255u) / 256u * 256u);   // one lane per item; no HBM pool is allocated
 
     int rcode;
     if ((rcode = ensure(&ctx->d_owned, &ctx->owned_capacity, owned.size())) != RL_OK) return rcode;
@@ -943,7 +1027,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         if ((rcode = ensure(&ctx->d_item_seed, &ctx->item_capacity, n_pixels)) != RL_OK) return rcode;
         if ((rcode = ensure(&ctx->d_item_pixel, &ctx->item_pixel_capacity, n_pixels)) != RL_OK) return rcode;
     }
-    if (ctx->pool_capacity < P) {
+    if (!fused && ctx->pool_capacity < P) {
         if (ctx->pool.f) hipFree(ctx->pool.f);
         if (ctx->pool.u) hipFree(ctx->pool.u);
         if (ctx->pool.q) hipFree(ctx->pool.q);
@@ -1003,7 +1087,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     if ((rcode = stack_conf(ctx, (size_t)grid_all.x * 256, &stc)) != RL_OK) return rcode;
 
     if (per_sample && !owned.empty()) hipLaunchKernelGGL(k_seed_pixels, dim3(((unsigned)owned.size() + 63) / 64), dim3(64), 0, st, rc);
-    hipLaunchKernelGGL(k_init, grid_all, block, 0, st, rc, pool);
+    if (!fused) hipLaunchKernelGGL(k_init, grid_all, block, 0, st, rc, pool);
 
     // events: 4 timed kernel classes per iteration
     const bool timing = stats != nullptr && !getenv("RL_NO_EVENTS");
@@ -1025,7 +1109,17 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             }
         return RL_OK;
     };
-    for (;;) {
+    double ms_fused = 0.0;
+    if (fused) {
+        const size_t lds_fused = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false);
+        if (timing) hipEventRecord(ctx->events[0], st);
+        launch_fused_type(ctx->bsdf_type, medium, ctx->lds_scene, grid_all, block, lds_fused, st, rc, ds, stc);
+        if (timing) hipEventRecord(ctx->events[1], st);
+        HIP_OK(hipStreamSynchronize(st));
+        if (timing) { float t = 0.0f; HIP_OK(hipEventElapsedTime(&t, ctx->events[0], ctx->events[1])); ms_fused = t; }
+        launches += 1;
+        iterations = 1;
+    } else for (;;) {
         hipEvent_t* ev = timing ? &ctx->events[kEventsPerIter * in_batch] : nullptr;
         if (timing) hipEventRecord(ev[0], st);
         hipLaunchKernelGGL(k_raygen, grid_persistent, block, 0, st, rc, ds, pool);
@@ -1075,6 +1169,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         stats->kernel_launches = launches;
         stats->render_ms = std::chrono::duration<double, std::milli>(t_end - t_start).count();
         stats->ms_raygen = ms[0]; stats->ms_extend = ms[1]; stats->ms_shade = ms[2]; stats->ms_shadow = ms[3];
+        stats->ms_other = ms_fused;   // the persistent fused kernel (pipeline 2)
         stats->n_extend_launches = n_extend;
     }
     return RL_OK;

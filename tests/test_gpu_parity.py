@@ -84,7 +84,7 @@ def test_visible_batch_matches_oracle(built, cbox64, ctx_cbox, orc_cbox64):
 def _render_pair(sd, ctx=None, osc=None, seed=0, **kw):
     ctx = ctx or api.Context(api.Scene(sd), 0)
     osc = osc or orc.Scene(sd)
-    okw = {k: v for k, v in kw.items() if k != "pool_slots"}
+    okw = {k: v for k, v in kw.items() if k not in ("pool_slots", "pipeline")}
     img, st = ctx.render(api.IndependentSampler(seed, kw.get("seed_variant", 0)).block_seeds(sd.width, sd.height), api.path_params(**kw))
     ref_fwd, ost = osc.render(master_seed=seed, eval_order=1, **okw)
     ref_rec, _ = osc.render(master_seed=seed, eval_order=0, **okw)
@@ -101,11 +101,14 @@ def _assert_parity(img, st, ref_fwd, ref_rec, ost):
     assert e.max() < L2_TOL and e.mean() < 1e-9, (e.max(), e.mean())
 
 
+@pytest.mark.parametrize("pipeline", [api.PIPELINE_WAVEFRONT, api.PIPELINE_FUSED])
 @pytest.mark.parametrize("mode", [api.STREAM_PER_SAMPLE, api.STREAM_REFERENCE_ORDER])
-def test_cbox_render_parity(built, cbox64, ctx_cbox, orc_cbox64, mode):
-    out = _render_pair(cbox64, ctx_cbox, orc_cbox64, spp=8, stream_mode=mode)
+def test_cbox_render_parity(built, cbox64, ctx_cbox, orc_cbox64, mode, pipeline):
+    """Both pipelines (wavefront stage kernels / persistent fused kernel) x both stream modes, bit-exact."""
+    out = _render_pair(cbox64, ctx_cbox, orc_cbox64, spp=8, stream_mode=mode, pipeline=pipeline)
     _assert_parity(*out)
     assert out[0].mean() > 0.05
+    assert (out[1]["iterations"] == 1) == (pipeline == api.PIPELINE_FUSED)
 
 
 @pytest.mark.parametrize("kw", [dict(strategy=api.STRATEGY_BSDF), dict(strategy=api.STRATEGY_EMITTER), dict(max_depth=2), dict(max_depth=3, min_depth=1),
@@ -138,11 +141,12 @@ def test_shards_sum_to_full_image(built, cbox64, ctx_cbox):
     np.testing.assert_array_equal(acc, full)   # sums with zeros are exact: N-GPU image == 1-GPU image bitwise
 
 
-def test_medium_parity(built):
+@pytest.mark.parametrize("pipeline", [api.PIPELINE_WAVEFRONT, api.PIPELINE_FUSED])
+def test_medium_parity(built, pipeline):
     for sd in (scenes.cbox_medium(48, 48, 0.5), scenes.cbox_medium(32, 32, 0.8, 0.2, g=0.6)):
-        out = _render_pair(sd, spp=4)
+        out = _render_pair(sd, spp=4, pipeline=pipeline)
         _assert_parity(*out)
-        out = _render_pair(sd, spp=2, single_scattering=True)
+        out = _render_pair(sd, spp=2, single_scattering=True, pipeline=pipeline)
         _assert_parity(*out)
 
 
@@ -185,9 +189,12 @@ def test_full_size_properties(built):
     seeds = api.IndependentSampler(0).block_seeds(1920, 1080)
     a, st = ctx.render(seeds, api.path_params(spp=4))
     b, _ = ctx.render(seeds, api.path_params(spp=4, pool_slots=1 << 19))
+    c, stc = ctx.render(seeds, api.path_params(spp=4, pipeline=api.PIPELINE_WAVEFRONT))
     np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a, c)                      # fused (auto) == wavefront, bitwise
+    assert all(st[k] == stc[k] for k in ("vertices", "extension_rays", "shadow_rays", "rng_draws"))
     assert st["camera_samples"] == 1920 * 1080 * 4 and np.isfinite(a).all() and (a >= 0).all()
-    parts = [ctx.render(seeds, api.path_params(spp=4, shard_index=r, shard_count=8))[0] for r in range(8)]
+    parts = [ctx.render(seeds, api.path_params(spp=4, shard_index=r, shard_count=8, pipeline=1 + r % 2))[0] for r in range(8)]
     np.testing.assert_array_equal(sum(parts[1:], parts[0]), a)
     # a 64x64 crop of blocks rendered by the oracle with the same block seeds agrees bit-exactly
     osc = orc.Scene(sd)
