@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--spp", type=int, default=128)
     ap.add_argument("--scene", default="cbox", choices=["cbox", "cbox_medium", "living_room"])
     ap.add_argument("--pool", type=int, default=0)
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "wavefront", "fused"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -66,7 +67,8 @@ def main():
 
     def step(seed):
         seeds = api.IndependentSampler(seed).block_seeds(args.width, args.height)     # same master stream on every rank
-        p = api.path_params(spp=spp_total, shard_index=rank, shard_count=world, pool_slots=args.pool)
+        p = api.path_params(spp=spp_total, shard_index=rank, shard_count=world, pool_slots=args.pool,
+                            pipeline={"auto": 0, "wavefront": 1, "fused": 2}[args.pipeline])
         _, st = ctx.render(seeds, p, out_device_ptr=fb.data_ptr(), stream=stream)
         if world > 1:
             rd.reduce_framebuffer(fb)                                                   # one RCCL reduce over xGMI
@@ -88,27 +90,44 @@ def main():
 
     samples_per_step = args.width * args.height * spp_total
     value = samples_per_step * args.steps / dt / 1e6
-    agg = {k: sum(s[k] for s in stats) for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "iterations", "n_extend_launches")}
-    ms = {k: sum(s[k] for s in stats) for k in ("ms_raygen", "ms_extend", "ms_shade", "ms_shadow")}
+    agg = {k: sum(s[k] for s in stats) for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "iterations", "n_extend_launches", "kernel_launches")}
+    ms = {k: sum(s[k] for s in stats) for k in ("ms_raygen", "ms_extend", "ms_shade", "ms_shadow", "ms_other")}
     agg_all = rd.sum_over_ranks(agg)
 
     if rank == 0:
-        # ---- roofline of the dominant kernel.  Algorithmic bytes:
-        # k_extend reads a ray {o 12, d 12, flags 4} and writes a hit {t, u, v, prim = 16} per live slot.
-        dominant = max(ms, key=ms.get)
-        per_unit = {"ms_extend": 28 + 16, "ms_shade": 2 * (80 + 28) + 16 + 4 + 44, "ms_shadow": 44 + 4 + 2 * 12, "ms_raygen": 80 + 28}[dominant]
-        units = {"ms_extend": agg["extension_rays"], "ms_shade": agg["extension_rays"], "ms_shadow": agg["shadow_rays"], "ms_raygen": agg["camera_samples"]}[dominant]
-        launches = max(1, agg["n_extend_launches"])
-        avg_ms = ms[dominant] / launches
-        achieved = (per_unit * units / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # whole-pipeline figure: 248 B per camera sample + 352 B per vertex + 12 B per pixel
-        pipe_bytes = 248 * agg["camera_samples"] + 352 * agg["vertices"] + 12 * args.width * args.height * args.steps / world
-        pipe_gbs = pipe_bytes / (dt) / 1e9
-        roofline = {"bound": "hbm", "kernel": {"ms_extend": "k_extend", "ms_shade": "k_shade", "ms_shadow": "k_shadow", "ms_raygen": "k_raygen"}[dominant],
-                    "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                    "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_unit": per_unit,
-                    "pipeline_algorithmic_GBps": pipe_gbs, "pipeline_frac": pipe_gbs / 8000.0,
-                    "kernel_ms_per_step": {k: v / args.steps for k, v in ms.items()},
+        # ---- roofline.  Algorithmic bytes per unit:
+        #   k_raygen 108 B/camera sample, k_extend 44 B/ray, k_shade 280 B/vertex, k_shadow 72 B/shadow ray,
+        #   k_path_fused (all four stages in one persistent launch): the whole-pipeline figure
+        #   248 B/camera sample + 352 B/expanded vertex + 12 B/pixel.
+        pix = args.width * args.height / world
+        pipe_bytes = 248 * agg["camera_samples"] + 352 * agg["vertices"] + 12 * pix * args.steps
+        fused = ms["ms_other"] > 0.0
+        names = {"ms_raygen": "k_raygen", "ms_extend": "k_extend", "ms_shade": "k_shade", "ms_shadow": "k_shadow", "ms_other": "k_path_fused"}
+        per_unit = {"ms_raygen": 108, "ms_extend": 44, "ms_shade": 280, "ms_shadow": 72}
+        units = {"ms_raygen": agg["camera_samples"], "ms_extend": agg["extension_rays"], "ms_shade": agg["extension_rays"], "ms_shadow": agg["shadow_rays"]}
+        n_launch = {k: max(1, agg["n_extend_launches"]) for k in per_unit}
+        kernels = {}
+        for k in per_unit:
+            if ms[k] > 0:
+                avg = ms[k] / n_launch[k]
+                gbs = per_unit[k] * units[k] / n_launch[k] / (avg * 1e-3) / 1e9
+                kernels[names[k]] = {"avg_launch_ms": avg, "launches": n_launch[k], "algorithmic_bytes_per_unit": per_unit[k], "achieved_GBps": gbs, "frac": gbs / 8000.0}
+        if fused:
+            avg = ms["ms_other"] / args.steps
+            gbs = pipe_bytes / args.steps / (avg * 1e-3) / 1e9
+            kernels["k_path_fused"] = {"avg_launch_ms": avg, "launches": args.steps, "algorithmic_bytes_per_unit": "248/sample + 352/vertex + 12/pixel",
+                                       "achieved_GBps": gbs, "frac": gbs / 8000.0}
+        dominant = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches"])
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            traffic = pmc["kernels"].get(dominant, {}).get("hbm_bytes")
+        except Exception:
+            pass
+        roofline = {"bound": "hbm", "kernel": dominant, "achieved": kernels[dominant]["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
+                    "frac": kernels[dominant]["frac"], "traffic": traffic, "avg_launch_ms": kernels[dominant]["avg_launch_ms"],
+                    "launches": kernels[dominant]["launches"], "kernels": kernels,
+                    "pipeline_algorithmic_GBps": pipe_bytes / dt / 1e9, "pipeline_frac": pipe_bytes / dt / 1e9 / 8000.0,
                     "rays_per_s": (agg_all["extension_rays"] + agg_all["shadow_rays"]) / dt}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
@@ -123,7 +142,7 @@ def main():
         out = {"metric": "Msamples/s (paths/s) at 1080p x 128spp cbox", "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
-               "config": {"workload": workload, "spp_total": spp_total, "stream_mode": "per_sample", "parallelism": f"tile-shard x{world} + 1 RCCL reduce",
+               "config": {"workload": workload, "spp_total": spp_total, "stream_mode": "per_sample", "pipeline": "fused (k_path_fused)" if fused else "wavefront (raygen/extend/shade/shadow)", "parallelism": f"tile-shard x{world} + 1 RCCL reduce",
                           "mean_vertices_per_sample": agg_all["vertices"] / max(1, agg_all["camera_samples"]),
                           "image_mean": float(host_img.mean())},
                "roofline": roofline, "cpu_baseline": cpu}
