@@ -137,6 +137,17 @@ struct RegState {
     RL_DEV unsigned& u(int field) { return uv[field]; }
     RL_DEV unsigned long long& q(int field) { return qv[field]; }
 };
+// FusedState: RegState whose "cold" fields (touched once per camera sample, by raygen only) are parked in LDS
+// ([field][thread] layout, conflict-free) instead of occupying VGPRs through the traversal and shading code.
+struct FusedState {
+    float fv[F_COUNT]; unsigned uv[U_COUNT]; unsigned long long qv[Q_COUNT];
+    float* cold_f; unsigned* cold_u; unsigned long long* cold_q;     // already offset by threadIdx.x
+    static constexpr int kColdF = 3, kColdU = 3, kColdQ = 4;
+    RL_DEV float& f(int field) { return (field >= F_AR && field <= F_AB) ? cold_f[(field - F_AR) * 256] : fv[field]; }
+    RL_DEV unsigned& u(int field) { return (field >= U_ITEM && field <= U_SAMPLE) ? cold_u[(field - U_ITEM) * 256] : uv[field]; }
+    RL_DEV unsigned long long& q(int field) { return (field >= Q_I0) ? cold_q[(field - Q_I0) * 256] : qv[field]; }
+};
+static constexpr size_t kFusedColdBytes = 256 * (FusedState::kColdQ * 8 + FusedState::kColdF * 4 + FusedState::kColdU * 4);
 #define PF(field) ps.f(field)
 #define PU(field) ps.u(field)
 #define PQ(field) ps.q(field)
@@ -689,14 +700,21 @@ __global__ void __launch_bounds__(256, RL_FUSED_WAVES) k_path_fused(RenderConst 
         recs.tris = reinterpret_cast<const float4*>(sc.tris);
     }
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const TravStack stack = make_stack(stc, reinterpret_cast<unsigned*>(after_scene), tid);
-    RegState ps;
+    // LDS: [scene][cold path state (u64 | f32 | u32 planes)][per-lane stacks]
+    unsigned long long* cold_q = reinterpret_cast<unsigned long long*>(after_scene);
+    float* cold_f = reinterpret_cast<float*>(cold_q + 256 * FusedState::kColdQ);
+    unsigned* cold_u = reinterpret_cast<unsigned*>(cold_f + 256 * FusedState::kColdF);
+    const TravStack stack = make_stack(stc, cold_u + 256 * FusedState::kColdU, tid);
+    FusedState ps;
+    ps.cold_q = cold_q + threadIdx.x; ps.cold_f = cold_f + threadIdx.x; ps.cold_u = cold_u + threadIdx.x;
 #pragma unroll
     for (int i = 0; i < F_COUNT; i++) ps.fv[i] = 0.0f;
 #pragma unroll
     for (int i = 0; i < U_COUNT; i++) ps.uv[i] = 0u;
 #pragma unroll
     for (int i = 0; i < Q_COUNT; i++) ps.qv[i] = 0ull;
+    storec(ps, F_AR, czero());
+    PU(U_CURSOR) = 0u; PU(U_SAMPLE) = 0u;
     PU(U_ITEM) = tid;
     PU(U_PRIM) = 0xffffffffu;
     PU(U_FLAGS) = tid < rc.n_items ? (ST_REGEN | ST_FRESH) : ST_FINISHED;
@@ -1111,7 +1129,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     };
     double ms_fused = 0.0;
     if (fused) {
-        const size_t lds_fused = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false);
+        const size_t lds_fused = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + kFusedColdBytes;
         if (timing) hipEventRecord(ctx->events[0], st);
         launch_fused_type(ctx->bsdf_type, medium, ctx->lds_scene, grid_all, block, lds_fused, st, rc, ds, stc);
         if (timing) hipEventRecord(ctx->events[1], st);
