@@ -132,8 +132,9 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             from oracle import orc
-            cw, ch, cspp = 480, 270, 16                           # bounded sample of the same workload (same scene, 1/16 res, 1/8 spp)
+            cw, ch, cspp = args.width, args.height, max(1, args.spp // 8)   # bounded sample of the same workload: same scene and resolution, 1/8 of the spp
             osc = orc.Scene(scenes.cbox(cw, ch) if args.scene == "cbox" else (scenes.cbox_medium(cw, ch, 0.5) if args.scene == "cbox_medium" else scenes.living_room(cw, ch)))
+            osc.render(master_seed=1, spp=1, stream_mode=0, threads=0)                # warm the thread pool / page in
             t1 = time.perf_counter()
             _, ost = osc.render(master_seed=0, spp=cspp, stream_mode=0, threads=0)
             ct = time.perf_counter() - t1
