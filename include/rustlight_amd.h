@@ -243,6 +243,32 @@ int rl_render_path(rl_context* ctx, const rl_path_params* params, const uint64_t
                    size_t n_blocks, float* out_rgb, int out_is_device, void* stream,
                    rl_render_stats* stats);
 
+/* ---- the two other `compute_mc` integrators that reuse this path's kernels ---- */
+
+/* struct IntegratorAO { max_distance: Option<f32>, normal_correction } (src/integrators/ao.rs:4-7; CLI `ao -d 1.0 -n`,
+ * examples/cli.rs:149-154,856-865) and struct IntegratorDirect { nb_bsdf_samples, nb_light_samples }
+ * (src/integrators/direct.rs:5-8; CLI `direct -b 1 -l 1`). */
+typedef struct rl_mc_params {
+    uint32_t spp;               /* scene.nb_samples */
+    int32_t stream_mode;        /* rl_stream_mode */
+    int32_t seed_variant;
+    uint32_t shard_index, shard_count;
+    int32_t has_max_distance;   /* ao: Option<f32> */
+    float max_distance;
+    int32_t normal_correction;  /* ao */
+    uint32_t nb_bsdf_samples;   /* direct */
+    uint32_t nb_light_samples;  /* direct */
+    uint32_t reserved[4];
+} rl_mc_params;
+
+/* Integrator::compute for IntegratorAO (src/integrators/ao.rs:9-70). Same output / sharding contract as rl_render_path. */
+int rl_render_ao(rl_context* ctx, const rl_mc_params* params, const uint64_t* block_seeds, size_t n_blocks,
+                 float* out_rgb, int out_is_device, void* stream, rl_render_stats* stats);
+/* Integrator::compute for IntegratorDirect (src/integrators/direct.rs:10-233): direct lighting with the power
+ * heuristic `mis_weight` (src/integrators/mod.rs:462-478). */
+int rl_render_direct(rl_context* ctx, const rl_mc_params* params, const uint64_t* block_seeds, size_t n_blocks,
+                     float* out_rgb, int out_is_device, void* stream, rl_render_stats* stats);
+
 /* Batched `Acceleration::trace` (src/accel.rs:292-315): rays (o, d, tnear=1e-4, tfar=MAX).
  * Host pointers.  mesh[i] = -1 on a miss. */
 int rl_trace_batch(rl_context* ctx, size_t n, const float* origins, const float* directions,

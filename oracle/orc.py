@@ -25,6 +25,12 @@ class OrcPathParams(C.Structure):
                 ("shard_count", C.c_uint32), ("eval_order", C.c_int32)]
 
 
+class OrcMcParams(C.Structure):
+    _fields_ = [("spp", C.c_uint32), ("stream_mode", C.c_int32), ("seed_variant", C.c_int32), ("shard_index", C.c_uint32),
+                ("shard_count", C.c_uint32), ("has_max_distance", C.c_int32), ("max_distance", C.c_float),
+                ("normal_correction", C.c_int32), ("nb_bsdf_samples", C.c_uint32), ("nb_light_samples", C.c_uint32)]
+
+
 class OrcStats(C.Structure):
     _fields_ = [("camera_samples", C.c_uint64), ("vertices", C.c_uint64), ("extension_rays", C.c_uint64),
                 ("shadow_rays", C.c_uint64), ("rng_draws", C.c_uint64), ("threads", C.c_uint32)]
@@ -89,6 +95,8 @@ def lib():
         L.orc_compute_pixel.restype = C.c_uint64
         L.orc_render_path.argtypes = [C.c_void_p, C.POINTER(OrcPathParams), C.POINTER(C.c_uint64), C.c_size_t,
                                       C.POINTER(C.c_float), C.c_int, C.POINTER(OrcStats)]
+        L.orc_render_mc.argtypes = [C.c_void_p, C.c_int, C.POINTER(OrcMcParams), C.POINTER(C.c_uint64), C.c_size_t,
+                                    C.POINTER(C.c_float), C.c_int, C.POINTER(OrcStats)]
         _lib = L
     return _lib
 
@@ -259,3 +267,26 @@ class Scene:
         if rc != 0:
             raise RuntimeError(f"orc_render_path failed: {rc}")
         return img, st.as_dict()
+
+
+def _render_mc(self, kind, master_seed=0, threads=0, seeds=None, spp=1, stream_mode=1, seed_variant=0, shard_index=0, shard_count=1,
+               max_distance=1.0, normal_correction=False, nb_bsdf_samples=1, nb_light_samples=1):
+    """ao (kind 0: IntegratorAO) / direct (kind 1: IntegratorDirect) through compute_mc."""
+    p = OrcMcParams()
+    p.spp, p.stream_mode, p.seed_variant, p.shard_index, p.shard_count = spp, stream_mode, seed_variant, shard_index, shard_count
+    p.has_max_distance, p.max_distance = (0, 0.0) if max_distance is None else (1, max_distance)
+    p.normal_correction = int(normal_correction)
+    p.nb_bsdf_samples, p.nb_light_samples = nb_bsdf_samples, nb_light_samples
+    sd = self.sd
+    if seeds is None:
+        seeds = block_seeds(master_seed, sd.width, sd.height, seed_variant)
+    img = np.zeros((sd.height, sd.width, 3), dtype=np.float32)
+    st = OrcStats()
+    rc = lib().orc_render_mc(self.h, kind, C.byref(p), abi.u64ptr(seeds), seeds.shape[0], abi.fptr(img), threads, C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"orc_render_mc failed: {rc}")
+    return img, st.as_dict()
+
+
+Scene.render_ao = lambda self, **kw: _render_mc(self, 0, **kw)
+Scene.render_direct = lambda self, **kw: _render_mc(self, 1, **kw)

@@ -1585,6 +1585,98 @@ struct PathTracer {
     }
 };
 
+// ------------------------------------------------------------------------------------------
+// mis_weight: power heuristic with the reference's guards (src/integrators/mod.rs:462-478)
+static inline float mis_weight(float pdf_a, float pdf_b) {
+    if (pdf_a == 0.0f) return 0.0f;
+    if (!is_finite(pdf_a) || !is_finite(pdf_b)) return 0.0f;
+    float w = (pdf_a * pdf_a) / (pdf_a * pdf_a + pdf_b * pdf_b);
+    return is_finite(w) ? w : 0.0f;
+}
+
+// IntegratorAO::compute_pixel (src/integrators/ao.rs:20-70)
+struct AOParams { bool has_max_distance = true; float max_distance = 1.0f; bool normal_correction = false; };
+static Color ao_compute_pixel(const Scene& scene, const AOParams& ap, uint32_t ix, uint32_t iy, Sampler& sampler, Counters& cnt) {
+    float u = (float)ix + sampler.next();
+    float v = (float)iy + sampler.next();
+    Ray ray = scene.camera.generate({u, v});
+    cnt.samples++;
+    Intersection its;
+    cnt.extension_rays++;
+    if (!scene.trace(ray, &its)) return Color::zero();
+    if (!ap.normal_correction && its.wi.z <= 0.0f) return Color::zero();
+    bool flipped = ap.normal_correction && its.wi.z <= 0.0f;
+    V3 d_local = cosine_sample_hemisphere(sampler.next2d());
+    V3 d_world = flipped ? its.frame.to_world(-d_local) : its.frame.to_world(d_local);
+    Ray r2 = {its.p, d_world, EPSILON, F32_MAX};
+    Intersection n2;
+    cnt.extension_rays++;
+    if (!scene.trace(r2, &n2)) return Color::one();
+    if (!ap.has_max_distance) return Color::zero();
+    return n2.dist > ap.max_distance ? Color::one() : Color::zero();
+}
+
+// IntegratorDirect::compute_pixel (src/integrators/direct.rs:21-233)
+struct DirectParams { uint32_t nb_bsdf_samples = 1, nb_light_samples = 1; };
+static Color direct_compute_pixel(const Scene& scene, const DirectParams& dp, uint32_t ix, uint32_t iy, Sampler& sampler, Counters& cnt) {
+    float u = (float)ix + sampler.next();
+    float v = (float)iy + sampler.next();
+    Ray ray = scene.camera.generate({u, v});
+    cnt.samples++;
+    Color l_i = Color::zero();
+    Intersection its;
+    cnt.extension_rays++;
+    if (!scene.trace(ray, &its)) return scene.environment_luminance();
+    if (its.wi.z <= 0.0f) return l_i;
+    const Mesh& mesh = scene.meshes[its.mesh];
+    add_assign(l_i, mesh.emit());
+    float w_nb_bsdf = dp.nb_bsdf_samples == 0 ? 0.0f : 1.0f / (float)dp.nb_bsdf_samples;
+    float w_nb_light = dp.nb_light_samples == 0 ? 0.0f : 1.0f / (float)dp.nb_light_samples;
+    cnt.vertices++;
+    for (uint32_t k = 0; k < dp.nb_light_samples; k++) {
+        float a = sampler.next();
+        float b = sampler.next();
+        V2 c = sampler.next2d();
+        LightSampling lr = scene.sample_light(its.p, a, b, c);
+        V3 d_out_local = its.frame.to_local(lr.d);
+        if (!lr.is_valid()) continue;
+        cnt.shadow_rays++;
+        if (!scene.visible(its.p, lr.p)) continue;
+        if (mesh.bsdf.is_smooth()) continue;
+        PDF pdf_bsdf = mesh.bsdf.pdf(its.has_uv, its.uv, its.wi, d_out_local, DomSolidAngle);
+        float weight_light;
+        if (lr.pdf.kind == PDF::SolidAngle) weight_light = mis_weight(lr.pdf.v * w_nb_light, pdf_bsdf.v * w_nb_bsdf);
+        else weight_light = 1.0f;   // (Discrete, _): the light is discrete, MIS does not apply
+        add_assign(l_i, weight_light * mesh.bsdf.eval(its.has_uv, its.uv, its.wi, d_out_local, DomSolidAngle) * w_nb_light * lr.weight);
+    }
+    for (uint32_t k = 0; k < dp.nb_bsdf_samples; k++) {
+        SampledDirection sd;
+        V2 s2 = sampler.next2d();
+        if (!mesh.bsdf.sample(its.has_uv, its.uv, its.wi, s2, &sd)) continue;
+        V3 d_out_world = its.frame.to_world(sd.d);
+        Ray r2 = {its.p, d_out_world, EPSILON, F32_MAX};
+        Intersection nx;
+        cnt.extension_rays++;
+        if (scene.trace(r2, &nx)) {
+            const Mesh& nm = scene.meshes[nx.mesh];
+            if (nm.is_light && dot(nx.n_g, -r2.d) > 0.0f) {
+                float weight_bsdf;
+                if (sd.pdf.kind == PDF::SolidAngle) {
+                    float light_pdf = scene.direct_pdf(nx.mesh, {r2.o, nx.p, nx.n_g, r2.d}).value();
+                    weight_bsdf = mis_weight(sd.pdf.v * w_nb_bsdf, light_pdf * w_nb_light);
+                } else weight_bsdf = 1.0f;
+                add_assign(l_i, weight_bsdf * sd.weight * nm.emit() * w_nb_bsdf);
+            }
+        } else if (scene.has_env) {
+            float weight_bsdf;
+            if (sd.pdf.kind == PDF::SolidAngle) weight_bsdf = mis_weight(sd.pdf.v * w_nb_bsdf, scene.direct_pdf_env().value() * w_nb_light);
+            else weight_bsdf = 1.0f;
+            add_assign(l_i, weight_bsdf * sd.weight * scene.environment_luminance() * w_nb_bsdf);
+        }
+    }
+    return l_i;
+}
+
 }  // namespace orc
 
 // ==========================================================================================
@@ -1816,56 +1908,55 @@ uint64_t orc_compute_pixel(const orc_scene* sc, const orc_path_params* pp, uint3
     return s.draws;
 }
 
+}  // extern "C" (reopened below)
+
 // compute_mc (integrators/mod.rs:403-450): tiles, per-block sampler, accumulate, scale, merge.
 // block_seeds: one u64 per block in creation order.  Renders blocks with b % shard_count == shard_index.
-int orc_render_path(const orc_scene* sc, const orc_path_params* pp, const uint64_t* block_seeds, size_t n_blocks,
-                    float* out_rgb, int n_threads, orc_stats* stats) {
-    const Scene& scene = sc->s;
+// `make_worker()` returns a per-thread object with `Color pixel(ix, iy, Sampler&)` and a `Counters cnt`.
+template <class MakeWorker>
+static int render_tiles(const Scene& scene, uint32_t spp, int stream_mode, int seed_variant, uint32_t shard_index, uint32_t shard_count_,
+                        const uint64_t* block_seeds, size_t n_blocks, float* out_rgb, int n_threads, orc_stats* stats, MakeWorker make_worker) {
     if (!scene.bvh_built || !scene.emitters_built) return -4;
     uint32_t W = scene.camera.w, H = scene.camera.h;
     size_t nby = (H + 15) / 16, nbx = (W + 15) / 16;
     if (n_blocks != nbx * nby) return -1;
-    if (pp->spp == 0) return -1;
-    PathParams p;
-    p.has_min = pp->has_min_depth; p.min_depth = pp->min_depth; p.has_max = pp->has_max_depth; p.max_depth = pp->max_depth;
-    p.has_rr = pp->has_rr_depth; p.rr_depth = pp->rr_depth; p.strategy = pp->strategy; p.single_scattering = pp->single_scattering; p.eval_order = pp->eval_order;
-    if ((p.strategy == RL_STRATEGY_ALL || p.strategy == RL_STRATEGY_EMITTER) && scene.emitters.empty()) return -8;
+    if (spp == 0) return -1;
     std::memset(out_rgb, 0, sizeof(float) * 3 * (size_t)W * H);
-    uint32_t shard_count = pp->shard_count ? pp->shard_count : 1;
+    uint32_t shard_count = shard_count_ ? shard_count_ : 1;
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
     if (n_threads <= 0) n_threads = 1;
     std::atomic<size_t> next_block{0};
     std::vector<Counters> counters(n_threads);
     auto worker = [&](int tid) {
-        PathTracer pt(scene, p);
+        auto wk = make_worker();
         std::vector<Color> block(256);
         for (;;) {
             size_t b = next_block.fetch_add(1);
             if (b >= n_blocks) break;
-            if (b % shard_count != pp->shard_index) continue;
+            if (b % shard_count != shard_index) continue;
             uint32_t bx = (uint32_t)(b / nby) * 16, by = (uint32_t)(b % nby) * 16;
             uint32_t bw = std::min(16u, W - bx), bh = std::min(16u, H - by);
-            Sampler block_sampler; block_sampler.rnd = Rng::seed_from_u64(block_seeds[b], pp->seed_variant); block_sampler.variant = pp->seed_variant;
+            Sampler block_sampler; block_sampler.rnd = Rng::seed_from_u64(block_seeds[b], seed_variant); block_sampler.variant = seed_variant;
             std::fill(block.begin(), block.end(), Color::zero());
             for (uint32_t iy = 0; iy < bh; iy++)
                 for (uint32_t ix = 0; ix < bw; ix++) {
                     Sampler pixel_sampler;
-                    if (pp->stream_mode == RL_STREAM_PER_SAMPLE) pixel_sampler = block_sampler.clone_box();
-                    for (uint32_t s = 0; s < pp->spp; s++) {
+                    if (stream_mode == RL_STREAM_PER_SAMPLE) pixel_sampler = block_sampler.clone_box();
+                    for (uint32_t s = 0; s < spp; s++) {
                         Color c;
-                        if (pp->stream_mode == RL_STREAM_PER_SAMPLE) {
+                        if (stream_mode == RL_STREAM_PER_SAMPLE) {
                             Sampler sample_sampler = pixel_sampler.clone_box();
-                            c = pt.compute_pixel(ix + bx, iy + by, sample_sampler);
-                            pt.cnt.draws += sample_sampler.draws;
+                            c = wk.pixel(ix + bx, iy + by, sample_sampler);
+                            wk.cnt.draws += sample_sampler.draws;
                         } else {
                             uint64_t d0 = block_sampler.draws;
-                            c = pt.compute_pixel(ix + bx, iy + by, block_sampler);
-                            pt.cnt.draws += block_sampler.draws - d0;
+                            c = wk.pixel(ix + bx, iy + by, block_sampler);
+                            wk.cnt.draws += block_sampler.draws - d0;
                         }
                         add_assign(block[iy * 16 + ix], c);
                     }
                 }
-            float inv = 1.0f / (float)pp->spp;
+            float inv = 1.0f / (float)spp;
             for (uint32_t iy = 0; iy < bh; iy++)
                 for (uint32_t ix = 0; ix < bw; ix++) {
                     Color c = block[iy * 16 + ix];
@@ -1874,7 +1965,7 @@ int orc_render_path(const orc_scene* sc, const orc_path_params* pp, const uint64
                     o[0] += c.r; o[1] += c.g; o[2] += c.b;  // accumulate_bitmap into a zeroed image
                 }
         }
-        counters[tid] = pt.cnt;
+        counters[tid] = wk.cnt;
     };
     std::vector<std::thread> th;
     for (int t = 1; t < n_threads; t++) th.emplace_back(worker, t);
@@ -1886,6 +1977,40 @@ int orc_render_path(const orc_scene* sc, const orc_path_params* pp, const uint64
         stats->threads = (uint32_t)n_threads;
     }
     return 0;
+}
+
+extern "C" {
+
+int orc_render_path(const orc_scene* sc, const orc_path_params* pp, const uint64_t* block_seeds, size_t n_blocks,
+                    float* out_rgb, int n_threads, orc_stats* stats) {
+    const Scene& scene = sc->s;
+    PathParams p;
+    p.has_min = pp->has_min_depth; p.min_depth = pp->min_depth; p.has_max = pp->has_max_depth; p.max_depth = pp->max_depth;
+    p.has_rr = pp->has_rr_depth; p.rr_depth = pp->rr_depth; p.strategy = pp->strategy; p.single_scattering = pp->single_scattering; p.eval_order = pp->eval_order;
+    if ((p.strategy == RL_STRATEGY_ALL || p.strategy == RL_STRATEGY_EMITTER) && scene.emitters.empty()) return -8;
+    struct W { PathTracer pt; Counters& cnt; W(const Scene& s, const PathParams& p) : pt(s, p), cnt(pt.cnt) {} Color pixel(uint32_t x, uint32_t y, Sampler& sm) { return pt.compute_pixel(x, y, sm); } };
+    return render_tiles(scene, pp->spp, pp->stream_mode, pp->seed_variant, pp->shard_index, pp->shard_count, block_seeds, n_blocks, out_rgb, n_threads, stats,
+                        [&]() { return W(scene, p); });
+}
+
+// ao / direct.  kind: 0 = ao, 1 = direct
+int orc_render_mc(const orc_scene* sc, int kind, const orc_mc_params* mp, const uint64_t* block_seeds, size_t n_blocks,
+                  float* out_rgb, int n_threads, orc_stats* stats) {
+    const Scene& scene = sc->s;
+    if (kind == 0) {
+        AOParams ap; ap.has_max_distance = mp->has_max_distance != 0; ap.max_distance = mp->max_distance; ap.normal_correction = mp->normal_correction != 0;
+        struct W { const Scene& s; AOParams ap; Counters cnt; Color pixel(uint32_t x, uint32_t y, Sampler& sm) { return ao_compute_pixel(s, ap, x, y, sm, cnt); } };
+        return render_tiles(scene, mp->spp, mp->stream_mode, mp->seed_variant, mp->shard_index, mp->shard_count, block_seeds, n_blocks, out_rgb, n_threads, stats,
+                            [&]() { return W{scene, ap, Counters()}; });
+    }
+    if (kind == 1) {
+        if (mp->nb_light_samples > 0 && scene.emitters.empty()) return -8;
+        DirectParams dp; dp.nb_bsdf_samples = mp->nb_bsdf_samples; dp.nb_light_samples = mp->nb_light_samples;
+        struct W { const Scene& s; DirectParams dp; Counters cnt; Color pixel(uint32_t x, uint32_t y, Sampler& sm) { return direct_compute_pixel(s, dp, x, y, sm, cnt); } };
+        return render_tiles(scene, mp->spp, mp->stream_mode, mp->seed_variant, mp->shard_index, mp->shard_count, block_seeds, n_blocks, out_rgb, n_threads, stats,
+                            [&]() { return W{scene, dp, Counters()}; });
+    }
+    return -1;
 }
 
 }  // extern "C"

@@ -23,6 +23,14 @@ typedef struct orc_path_params {
     int32_t eval_order;         /* 0 = reference recursion (inner-first), 1 = forward (GPU accumulation order) */
 } orc_path_params;
 
+typedef struct orc_mc_params {   /* ao / direct integrators */
+    uint32_t spp;
+    int32_t stream_mode, seed_variant;
+    uint32_t shard_index, shard_count;
+    int32_t has_max_distance; float max_distance; int32_t normal_correction;   /* IntegratorAO */
+    uint32_t nb_bsdf_samples, nb_light_samples;                                /* IntegratorDirect */
+} orc_mc_params;
+
 typedef struct orc_stats {
     uint64_t camera_samples, vertices, extension_rays, shadow_rays, rng_draws;
     uint32_t threads;
@@ -61,6 +69,8 @@ int orc_bsdf_probe(const orc_scene* sc, int mesh, int op, const float* wi, const
 int orc_sample_light(const orc_scene* sc, const float* p, float r_sel, float r, float ux, float uy, float* out);
 uint64_t orc_compute_pixel(const orc_scene* sc, const orc_path_params* pp, uint32_t ix, uint32_t iy, uint64_t* rng_state,
                            float* rgb, uint64_t* n_vertices, uint64_t* n_shadow);
+int orc_render_mc(const orc_scene* sc, int kind, const orc_mc_params* mp, const uint64_t* block_seeds, size_t n_blocks,
+                  float* out_rgb, int n_threads, orc_stats* stats);
 int orc_render_path(const orc_scene* sc, const orc_path_params* pp, const uint64_t* block_seeds, size_t n_blocks,
                     float* out_rgb, int n_threads, orc_stats* stats);
 #ifdef __cplusplus

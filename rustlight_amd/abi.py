@@ -33,6 +33,13 @@ class PathParams(C.Structure):
                 ("shard_count", C.c_uint32), ("pool_slots", C.c_uint32), ("pipeline", C.c_uint32), ("reserved", C.c_uint32 * 2)]
 
 
+class McParams(C.Structure):
+    _fields_ = [("spp", C.c_uint32), ("stream_mode", C.c_int32), ("seed_variant", C.c_int32), ("shard_index", C.c_uint32),
+                ("shard_count", C.c_uint32), ("has_max_distance", C.c_int32), ("max_distance", C.c_float),
+                ("normal_correction", C.c_int32), ("nb_bsdf_samples", C.c_uint32), ("nb_light_samples", C.c_uint32),
+                ("reserved", C.c_uint32 * 4)]
+
+
 class RenderStats(C.Structure):
     _fields_ = [("camera_samples", C.c_uint64), ("vertices", C.c_uint64), ("extension_rays", C.c_uint64),
                 ("shadow_rays", C.c_uint64), ("rng_draws", C.c_uint64), ("iterations", C.c_uint64),

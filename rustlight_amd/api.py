@@ -32,7 +32,7 @@ PUBLIC_SYMBOLS = [
     "rl_scene_set_environment", "rl_scene_build_emitters", "rl_scene_load_pbrt",
     "rl_scene_image_size", "rl_scene_counts", "rl_sampler_seed", "rl_sampler_next_u64", "rl_sampler_next_f32",
     "rl_path_params_default", "rl_context_create", "rl_context_destroy", "rl_last_error", "rl_block_count",
-    "rl_generate_block_seeds", "rl_render_path", "rl_trace_batch", "rl_visible_batch", "rl_save_pfm", "rl_build_info",
+    "rl_generate_block_seeds", "rl_render_path", "rl_render_ao", "rl_render_direct", "rl_trace_batch", "rl_visible_batch", "rl_save_pfm", "rl_build_info",
 ]
 
 
@@ -89,6 +89,8 @@ def lib():
     L.rl_block_count.restype = C.c_size_t
     L.rl_generate_block_seeds.argtypes = [C.POINTER(abi.Sampler), C.c_uint32, C.c_uint32, u64p, C.c_size_t]
     L.rl_render_path.argtypes = [vp, C.POINTER(abi.PathParams), u64p, C.c_size_t, vp, C.c_int, vp, C.POINTER(abi.RenderStats)]
+    for fn in (L.rl_render_ao, L.rl_render_direct):
+        fn.argtypes = [vp, C.POINTER(abi.McParams), u64p, C.c_size_t, vp, C.c_int, vp, C.POINTER(abi.RenderStats)]
     L.rl_trace_batch.argtypes = [vp, C.c_size_t, f32p, f32p, f32p, f32p, f32p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rl_visible_batch.argtypes = [vp, C.c_size_t, f32p, f32p, C.POINTER(C.c_uint8)]
     L.rl_save_pfm.argtypes = [C.c_char_p, f32p, C.c_uint32, C.c_uint32]
@@ -266,6 +268,27 @@ class Context:
         _check(lib().rl_render_path(self.h, C.byref(params), abi.u64ptr(seeds), seeds.shape[0], C.c_void_p(out_device_ptr), 1,
                                     C.c_void_p(stream) if stream else None, C.byref(st)))
         return None, st.as_dict()
+
+    def _render_mc(self, fn, seeds, spp=1, stream_mode=STREAM_PER_SAMPLE, seed_variant=0, shard_index=0, shard_count=1,
+                   max_distance=1.0, normal_correction=False, nb_bsdf_samples=1, nb_light_samples=1):
+        p = abi.McParams()
+        p.spp, p.stream_mode, p.seed_variant, p.shard_index, p.shard_count = spp, stream_mode, seed_variant, shard_index, shard_count
+        p.has_max_distance, p.max_distance = (0, 0.0) if max_distance is None else (1, max_distance)
+        p.normal_correction = int(normal_correction)
+        p.nb_bsdf_samples, p.nb_light_samples = nb_bsdf_samples, nb_light_samples
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        st = abi.RenderStats()
+        img = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        _check(fn(self.h, C.byref(p), abi.u64ptr(seeds), seeds.shape[0], img.ctypes.data_as(C.c_void_p), 0, None, C.byref(st)))
+        return img, st.as_dict()
+
+    def render_ao(self, seeds, **kw):
+        """IntegratorAO { max_distance, normal_correction } (src/integrators/ao.rs)."""
+        return self._render_mc(lib().rl_render_ao, seeds, **kw)
+
+    def render_direct(self, seeds, **kw):
+        """IntegratorDirect { nb_bsdf_samples, nb_light_samples } (src/integrators/direct.rs)."""
+        return self._render_mc(lib().rl_render_direct, seeds, **kw)
 
     def trace(self, origins, directions):
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)

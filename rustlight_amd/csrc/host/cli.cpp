@@ -3,6 +3,8 @@
 //   rustlight-amd <scene.pbrt> -n SPP -o out.pfm [-r independent:SEED] [-m s[:a[:g]]] [-s SCALE] [-t N]
 //                 [--device D] [--stream-mode reference|per-sample]
 //                 path [-m MAX|inf] [-n MIN] [-r RR|inf] [-x] [-s all|bsdf|emitter]
+//               | ao [-d DIST|inf] [-n]            (examples/cli.rs:149-154)
+//               | direct [-b NB_BSDF] [-l NB_LIGHT] (examples/cli.rs:155-160)
 // Note `-n` / `-m` / `-r` / `-s` mean spp / medium / sampler / scale before the subcommand and
 // min-depth / max-depth / rr-depth / strategy after it, exactly as in the reference.
 #include <chrono>
@@ -32,12 +34,15 @@ int main(int argc, char** argv) {
     float scale_image = 1.0f;
     int device = 0;
     bool single_scattering = false, have_cmd = false;
+    std::string cmd, ao_distance = "1.0";
+    bool ao_normal_correction = false;
+    size_t nb_bsdf = 1, nb_light = 1;
     rl_stream_mode mode = RL_STREAM_PER_SAMPLE;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() -> std::string { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
         if (!have_cmd) {
-            if (a == "path") have_cmd = true;
+            if (a == "path" || a == "ao" || a == "direct") { have_cmd = true; cmd = a; }
             else if (a == "-n" || a == "--nbsamples") nbsamples = std::strtoull(val().c_str(), nullptr, 10);
             else if (a == "-o" || a == "--output") output = val();
             else if (a == "-r" || a == "--random-number-generator") rng = val();
@@ -49,7 +54,15 @@ int main(int argc, char** argv) {
             else if (a == "-a" || a == "-e" || a == "-l" || a == "-x") { std::fprintf(stderr, "option %s is not supported by this drop-in yet\n", a.c_str()); return 2; }
             else if (a[0] == '-') { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
             else if (scene_path.empty()) scene_path = a;
-            else { std::fprintf(stderr, "only the `path` subcommand is provided (got %s)\n", a.c_str()); return 2; }
+            else { std::fprintf(stderr, "only the `path`, `ao` and `direct` subcommands are provided (got %s)\n", a.c_str()); return 2; }
+        } else if (cmd == "ao") {
+            if (a == "-d" || a == "--distance") ao_distance = val();
+            else if (a == "-n" || a == "--normal-correction") ao_normal_correction = true;
+            else { std::fprintf(stderr, "unknown ao option %s\n", a.c_str()); return 2; }
+        } else if (cmd == "direct") {
+            if (a == "-b" || a == "--nb-bsdf-samples") nb_bsdf = std::strtoull(val().c_str(), nullptr, 10);
+            else if (a == "-l" || a == "--nb-light-samples") nb_light = std::strtoull(val().c_str(), nullptr, 10);
+            else { std::fprintf(stderr, "unknown direct option %s\n", a.c_str()); return 2; }
         } else {
             if (a == "-m" || a == "--max-depth") max_depth = val();
             else if (a == "-n" || a == "--min-depth") min_depth = val();
@@ -98,8 +111,19 @@ int main(int argc, char** argv) {
         else if (rng.rfind("independent:", 0) == 0) seed = std::strtoull(rng.c_str() + 12, nullptr, 10);
         else { std::fprintf(stderr, "Wrong sampler type provided %s (only independent[:seed])\n", rng.c_str()); return 2; }
         IndependentSampler sampler(seed);
-        BufferCollection img = integrator.compute(sampler, *scene);
-        std::fprintf(stderr, "INFO Elapsed Integrator: %.0f ms\n", integrator.last_stats.render_ms);
+        BufferCollection img;
+        double elapsed_ms = 0.0;
+        if (cmd == "ao") {
+            IntegratorAO ao;
+            ao.device = device; ao.stream_mode = mode; ao.normal_correction = ao_normal_correction;
+            if (ao_distance == "inf") ao.max_distance = std::nullopt; else ao.max_distance = std::strtof(ao_distance.c_str(), nullptr);
+            img = ao.compute(sampler, *scene); elapsed_ms = ao.last_stats.render_ms;
+        } else if (cmd == "direct") {
+            IntegratorDirect di;
+            di.device = device; di.stream_mode = mode; di.nb_bsdf_samples = nb_bsdf; di.nb_light_samples = nb_light;
+            img = di.compute(sampler, *scene); elapsed_ms = di.last_stats.render_ms;
+        } else { img = integrator.compute(sampler, *scene); elapsed_ms = integrator.last_stats.render_ms; }
+        std::fprintf(stderr, "INFO Elapsed Integrator: %.0f ms\n", elapsed_ms);
         std::fprintf(stderr, "INFO Save final image: %s\n", output.c_str());
         if (output.size() < 4 || output.substr(output.size() - 4) != ".pfm") { std::fprintf(stderr, "only .pfm output is supported\n"); return 2; }
         img.save("primal", output);

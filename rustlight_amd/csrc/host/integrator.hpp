@@ -90,4 +90,48 @@ struct IntegratorPathTracing {
     }
 };
 
+// struct IntegratorAO (src/integrators/ao.rs:4-7) / struct IntegratorDirect (src/integrators/direct.rs:5-8)
+struct IntegratorMC {
+    int device = 0;
+    rl_stream_mode stream_mode = RL_STREAM_PER_SAMPLE;
+    rl_render_stats last_stats{};
+  protected:
+    BufferCollection run(bool direct, rl_mc_params p, IndependentSampler& sampler, Scene& scene) {
+        rl_context* ctx = nullptr;
+        int rc = rl_context_create(scene.handle, device, &ctx);
+        if (rc != RL_OK) throw std::runtime_error(std::string("rl_context_create: ") + rl_last_error());
+        BufferCollection img;
+        rl_scene_image_size(scene.handle, &img.width, &img.height);
+        img.primal.assign((size_t)3 * img.width * img.height, 0.0f);
+        p.spp = (uint32_t)scene.nb_samples;
+        p.stream_mode = stream_mode;
+        p.seed_variant = sampler.variant;
+        p.shard_index = 0; p.shard_count = 1;
+        std::vector<uint64_t> seeds(rl_block_count(img.width, img.height));
+        rl_generate_block_seeds(&sampler.rnd, img.width, img.height, seeds.data(), seeds.size());
+        rc = (direct ? rl_render_direct : rl_render_ao)(ctx, &p, seeds.data(), seeds.size(), img.primal.data(), 0, nullptr, &last_stats);
+        rl_context_destroy(ctx);
+        if (rc != RL_OK) throw std::runtime_error(std::string("render: ") + rl_last_error());
+        return img;
+    }
+};
+struct IntegratorAO : IntegratorMC {
+    std::optional<float> max_distance = 1.0f;
+    bool normal_correction = false;
+    BufferCollection compute(IndependentSampler& sampler, Scene& scene) {
+        rl_mc_params p{};
+        p.has_max_distance = max_distance.has_value(); p.max_distance = max_distance.value_or(0.0f);
+        p.normal_correction = normal_correction;
+        return run(false, p, sampler, scene);
+    }
+};
+struct IntegratorDirect : IntegratorMC {
+    size_t nb_bsdf_samples = 1, nb_light_samples = 1;
+    BufferCollection compute(IndependentSampler& sampler, Scene& scene) {
+        rl_mc_params p{};
+        p.nb_bsdf_samples = (uint32_t)nb_bsdf_samples; p.nb_light_samples = (uint32_t)nb_light_samples;
+        return run(true, p, sampler, scene);
+    }
+};
+
 }  // namespace rustlight

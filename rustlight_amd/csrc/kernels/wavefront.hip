@@ -242,6 +242,23 @@ __global__ void k_init(RenderConst rc, Pool pool) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Camera::generate (src/camera.rs:81-91): direction of the ray through image position (u, v)
+RL_DEV V3 camera_direction(const DeviceScene& sc, float u, float v) {
+    const float* m = sc.camera.sample_to_camera;
+    float sx = div_rn(u, (float)sc.camera.width), sy = div_rn(v, (float)sc.camera.height), sz = 0.0f;
+    float hx = ((m[0] * sx + m[4] * sy) + m[8] * sz) + m[12] * 1.0f;
+    float hy = ((m[1] * sx + m[5] * sy) + m[9] * sz) + m[13] * 1.0f;
+    float hz = ((m[2] * sx + m[6] * sy) + m[10] * sz) + m[14] * 1.0f;
+    float hw = ((m[3] * sx + m[7] * sy) + m[11] * sz) + m[15] * 1.0f;
+    float inv_w = div_rn(1.0f, hw);
+    V3 near_p = mk3(hx * inv_w, hy * inv_w, hz * inv_w);
+    V3 dl = normalize(near_p);
+    const float* tw = sc.camera.to_world;
+    return mk3(((tw[0] * dl.x + tw[4] * dl.y) + tw[8] * dl.z) + tw[12] * 0.0f,
+               ((tw[1] * dl.x + tw[5] * dl.y) + tw[9] * dl.z) + tw[13] * 0.0f,
+               ((tw[2] * dl.x + tw[6] * dl.y) + tw[10] * dl.z) + tw[14] * 0.0f);
+}
+
 // raygen_slot — sample completion, work-item hand-out, sampler forking, Path::from_sensor (2 draws) and
 // Camera::generate for one slot that asked for regeneration.  DYNAMIC: work items come from the global
 // dispenser (wavefront pool); otherwise the slot owns exactly one item (persistent fused kernel).
@@ -313,20 +330,7 @@ RL_DEV void raygen_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, un
         PU(U_FLAGS) = ST_REGEN;
         return;
     }
-    // Camera::generate (camera.rs:81-91)
-    const float* m = sc.camera.sample_to_camera;
-    float sx = div_rn(u, (float)sc.camera.width), sy = div_rn(v, (float)sc.camera.height), sz = 0.0f;
-    float hx = ((m[0] * sx + m[4] * sy) + m[8] * sz) + m[12] * 1.0f;
-    float hy = ((m[1] * sx + m[5] * sy) + m[9] * sz) + m[13] * 1.0f;
-    float hz = ((m[2] * sx + m[6] * sy) + m[10] * sz) + m[14] * 1.0f;
-    float hw = ((m[3] * sx + m[7] * sy) + m[11] * sz) + m[15] * 1.0f;
-    float inv_w = div_rn(1.0f, hw);
-    V3 near_p = mk3(hx * inv_w, hy * inv_w, hz * inv_w);
-    V3 dl = normalize(near_p);
-    const float* tw = sc.camera.to_world;
-    V3 d = mk3(((tw[0] * dl.x + tw[4] * dl.y) + tw[8] * dl.z) + tw[12] * 0.0f,
-               ((tw[1] * dl.x + tw[5] * dl.y) + tw[9] * dl.z) + tw[13] * 0.0f,
-               ((tw[2] * dl.x + tw[6] * dl.y) + tw[10] * dl.z) + tw[14] * 0.0f);
+    const V3 d = camera_direction(sc, u, v);   // Camera::generate (camera.rs:81-91)
     // the sensor edge's state is implied by PREV_SENSOR and never stored: origin = Camera::position(),
     // weight 1, rr_weight 1, PDF::SolidAngle(1), beta = thr = 1 (strategies/directional.rs:27-41)
     store3(ps, F_DX, d);
@@ -726,6 +730,173 @@ __global__ void __launch_bounds__(256, RL_FUSED_WAVES) k_path_fused(RenderConst 
             shade_slot<MAT, MEDIUM>(rc, sc, ps, PU(U_FLAGS), n_vertices, n_draws, n_shadow, n_ext);
         }
         if (PU(U_FLAGS) & ST_SHADOW) shadow_slot(sc, recs, stack, ps);
+    }
+    {
+        const int which[5] = {STAT_SAMPLES, STAT_VERTICES, STAT_DRAWS, STAT_SHADOW_RAYS, STAT_EXT_RAYS};
+        const unsigned vals[5] = {n_samples, n_vertices, n_draws, n_shadow, n_ext};
+        block_stats<5>(rc.partials, which, vals);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_pixel_mc<KIND> — the other two `compute_mc` integrators, one lane per work item
+// (pixel, or block in reference-order mode), samples folded in order:
+//   KIND 0  IntegratorAO::compute_pixel      src/integrators/ao.rs:20-70
+//   KIND 1  IntegratorDirect::compute_pixel  src/integrators/direct.rs:21-233 (power heuristic, mod.rs:462-478)
+struct McConst {
+    int has_max_distance; float max_distance; int normal_correction;
+    unsigned nb_bsdf_samples, nb_light_samples;
+};
+RL_DEV float mis_weight_power(float pdf_a, float pdf_b) {
+    if (pdf_a == 0.0f) return 0.0f;
+    if (!finite_f(pdf_a) || !finite_f(pdf_b)) return 0.0f;
+    float w = div_rn(pdf_a * pdf_a, pdf_a * pdf_a + pdf_b * pdf_b);
+    return finite_f(w) ? w : 0.0f;
+}
+RL_DEV bool trace_closest(const DeviceScene& sc, const SceneRecs& recs, const TravStack& stack, V3 o, V3 d, Hit& hit) {
+    hit.t = kF32Max; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
+    traverse<false>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
+                    o, d, kEps, kF32Max, hit, stack);
+    return hit.prim >= 0;
+}
+RL_DEV bool trace_visible(const DeviceScene& sc, const SceneRecs& recs, const TravStack& stack, V3 p0, V3 p1) {
+    V3 d = p1 - p0;
+    float len = length(d);
+    d = d / len;
+    float tfar = len * (1.0f - 0.00001f);
+    Hit hit; hit.t = tfar; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
+    V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
+    float te;
+    if (!slab(mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]), p0, inv_d, kEps, tfar, &te)) return false;
+    return !traverse<true>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
+                           p0, d, kEps, tfar, hit, stack);
+}
+
+template <int KIND>
+RL_DEV Col mc_compute_pixel(const DeviceScene& sc, const SceneRecs& recs, const TravStack& stack, const McConst& mp, unsigned px, unsigned py, Rng& rng,
+                            unsigned& n_draws, unsigned& n_ext, unsigned& n_shadow, unsigned& n_vertices) {
+    float u = (float)px + rng_next_f32(rng);
+    float v = (float)py + rng_next_f32(rng);
+    n_draws += 2;
+    const V3 o = mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]);
+    const V3 d = camera_direction(sc, u, v);
+    Hit hit;
+    n_ext++;
+    if (!trace_closest(sc, recs, stack, o, d, hit)) {
+        if (KIND == 1 && sc.env_emitter >= 0) return mkc(sc.env_color[0], sc.env_color[1], sc.env_color[2]);   // scene.enviroment_luminance(ray.d)
+        return czero();
+    }
+    const SurfacePoint sp = fill_intersection(sc, hit.prim, hit.u, hit.v, o, d, hit.t);
+    if (KIND == 0) {
+        if (!mp.normal_correction && sp.wi.z <= 0.0f) return czero();
+        const bool flipped = mp.normal_correction && sp.wi.z <= 0.0f;
+        V2 s2; s2.x = rng_next_f32(rng); s2.y = rng_next_f32(rng);
+        n_draws += 2;
+        V3 d_local = cosine_sample_hemisphere(s2);
+        V3 d_world = flipped ? to_world(sp.frame, -d_local) : to_world(sp.frame, d_local);
+        Hit h2;
+        n_ext++;
+        if (!trace_closest(sc, recs, stack, sp.p, d_world, h2)) return cone();
+        if (!mp.has_max_distance) return czero();
+        return h2.t > mp.max_distance ? cone() : czero();
+    }
+    // ---- direct
+    Col l_i = czero();
+    if (sp.wi.z <= 0.0f) return l_i;
+    const MeshRecord mr = sc.meshes[sp.mesh];
+    const Material& mat = sc.materials[mr.material];
+    l_i = l_i + ((mr.flags & MESH_IS_LIGHT) ? mkc(mr.emission[0], mr.emission[1], mr.emission[2]) : czero());
+    const float w_nb_bsdf = mp.nb_bsdf_samples == 0u ? 0.0f : div_rn(1.0f, (float)mp.nb_bsdf_samples);
+    const float w_nb_light = mp.nb_light_samples == 0u ? 0.0f : div_rn(1.0f, (float)mp.nb_light_samples);
+    n_vertices++;
+    for (unsigned k = 0; k < mp.nb_light_samples; k++) {
+        float a = rng_next_f32(rng);
+        float b = rng_next_f32(rng);
+        V2 c; c.x = rng_next_f32(rng); c.y = rng_next_f32(rng);
+        n_draws += 4;
+        LightSample ls = sample_light(sc, sp.p, a, b, c);
+        V3 d_out_local = to_local(sp.frame, ls.d);
+        if (ls.pdf == 0.0f) continue;
+        n_shadow++;
+        if (!trace_visible(sc, recs, stack, sp.p, ls.p)) continue;
+        if (mat.smooth) continue;
+        float pdf_bsdf = bsdf_pdf<-1>(sc, mat, sp.has_uv, sp.uv, sp.wi, d_out_local, false);
+        float weight_light = ls.pdf_kind == PDF_SOLID_ANGLE ? mis_weight_power(ls.pdf * w_nb_light, pdf_bsdf * w_nb_bsdf) : 1.0f;
+        l_i = l_i + weight_light * bsdf_eval<-1>(sc, mat, sp.has_uv, sp.uv, sp.wi, d_out_local, false) * w_nb_light * ls.weight;
+    }
+    for (unsigned k = 0; k < mp.nb_bsdf_samples; k++) {
+        V2 s2; s2.x = rng_next_f32(rng); s2.y = rng_next_f32(rng);
+        n_draws += 2;
+        BsdfSample bs;
+        if (!bsdf_sample<-1>(sc, mat, sp.has_uv, sp.uv, sp.wi, s2, &bs)) continue;
+        V3 d_out_world = to_world(sp.frame, bs.d);
+        Hit h2;
+        n_ext++;
+        if (trace_closest(sc, recs, stack, sp.p, d_out_world, h2)) {
+            const SurfacePoint nx = fill_intersection(sc, h2.prim, h2.u, h2.v, sp.p, d_out_world, h2.t);
+            const MeshRecord nm = sc.meshes[nx.mesh];
+            if ((nm.flags & MESH_IS_LIGHT) && dot(nx.n_g, -d_out_world) > 0.0f) {
+                float weight_bsdf = 1.0f;
+                if (bs.pdf_kind == PDF_SOLID_ANGLE) {
+                    float light_pdf = light_direct_pdf(nm, sp.p, nx.p, nx.n_g, d_out_world);
+                    weight_bsdf = mis_weight_power(bs.pdf * w_nb_bsdf, light_pdf * w_nb_light);
+                }
+                l_i = l_i + weight_bsdf * bs.weight * mkc(nm.emission[0], nm.emission[1], nm.emission[2]) * w_nb_bsdf;
+            }
+        } else if (sc.env_emitter >= 0) {
+            float weight_bsdf = bs.pdf_kind == PDF_SOLID_ANGLE ? mis_weight_power(bs.pdf * w_nb_bsdf, sc.env_pdf * w_nb_light) : 1.0f;
+            l_i = l_i + weight_bsdf * bs.weight * mkc(sc.env_color[0], sc.env_color[1], sc.env_color[2]) * w_nb_bsdf;
+        }
+    }
+    return l_i;
+}
+
+template <int KIND, bool LDS_SCENE>
+__global__ void __launch_bounds__(256) k_pixel_mc(RenderConst rc, DeviceScene sc, StackConf stc, McConst mp) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    SceneRecs recs;
+    float4* after_scene = smem;
+    if (LDS_SCENE) {
+        stage_scene_lds(sc, smem, smem + 4 * sc.n_nodes);
+        recs.nodes = smem; recs.tris = smem + 4 * sc.n_nodes;
+        after_scene = smem + 4 * (sc.n_nodes + sc.n_prims);
+    } else {
+        recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
+        recs.tris = reinterpret_cast<const float4*>(sc.tris);
+    }
+    const unsigned item = blockIdx.x * blockDim.x + threadIdx.x;
+    const TravStack stack = make_stack(stc, reinterpret_cast<unsigned*>(after_scene), item);
+    unsigned n_samples = 0, n_draws = 0, n_ext = 0, n_shadow = 0, n_vertices = 0;
+    if (item < rc.n_items) {
+        const float inv = rc.inv_spp;
+        if (rc.stream_mode == RL_STREAM_PER_SAMPLE) {
+            Rng pixel_rng = rng_seed(rc.item_seed[item], rc.seed_variant);
+            const unsigned pix = rc.item_pixel[item];
+            Col acc = czero();
+            for (unsigned s = 0; s < rc.spp; s++) {
+                Rng rng = rng_seed(rng_next_u64(pixel_rng), rc.seed_variant);
+                acc = acc + mc_compute_pixel<KIND>(sc, recs, stack, mp, pix % rc.W, pix / rc.W, rng, n_draws, n_ext, n_shadow, n_vertices);
+                n_samples++;
+            }
+            Col px = scale_unguarded(acc, inv);
+            rc.out[3 * (size_t)pix] = px.r; rc.out[3 * (size_t)pix + 1] = px.g; rc.out[3 * (size_t)pix + 2] = px.b;
+        } else {
+            unsigned bx, by, bw, bh;
+            const unsigned b = rc.owned_blocks[item];
+            block_geometry(rc, b, &bx, &by, &bw, &bh);
+            Rng rng = rng_seed(rc.block_seeds[b], rc.seed_variant);
+            for (unsigned iy = 0; iy < bh; iy++)
+                for (unsigned ix = 0; ix < bw; ix++) {
+                    Col acc = czero();
+                    for (unsigned s = 0; s < rc.spp; s++) {
+                        acc = acc + mc_compute_pixel<KIND>(sc, recs, stack, mp, bx + ix, by + iy, rng, n_draws, n_ext, n_shadow, n_vertices);
+                        n_samples++;
+                    }
+                    Col px = scale_unguarded(acc, inv);
+                    const size_t pix = (size_t)(by + iy) * rc.W + (bx + ix);
+                    rc.out[3 * pix] = px.r; rc.out[3 * pix + 1] = px.g; rc.out[3 * pix + 2] = px.b;
+                }
+        }
     }
     {
         const int which[5] = {STAT_SAMPLES, STAT_VERTICES, STAT_DRAWS, STAT_SHADOW_RAYS, STAT_EXT_RAYS};
@@ -1192,6 +1363,93 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     }
     return RL_OK;
 }
+
+// ---- ao / direct: Integrator::compute through the same tiling driver (one launch)
+static int render_mc(rl_context* ctx, int kind, const rl_mc_params* params, const uint64_t* block_seeds, size_t n_blocks, float* out_rgb,
+                     int out_is_device, void* stream_arg, rl_render_stats* stats) {
+    if (!ctx || !params || !block_seeds || !out_rgb) return RL_ERR_INVALID_ARGUMENT;
+    const uint32_t W = ctx->width, H = ctx->height;
+    const size_t nbx = (W + 15) / 16, nby = (H + 15) / 16;
+    if (n_blocks != nbx * nby || params->spp == 0) return RL_ERR_INVALID_ARGUMENT;
+    if (params->stream_mode != RL_STREAM_REFERENCE_ORDER && params->stream_mode != RL_STREAM_PER_SAMPLE) return RL_ERR_INVALID_ARGUMENT;
+    const uint32_t shard_count = params->shard_count ? params->shard_count : 1;
+    if (params->shard_index >= shard_count) return RL_ERR_INVALID_ARGUMENT;
+    if (kind == 1 && params->nb_light_samples > 0 && ctx->ds.n_emitters == 0) { rl_set_error("light sampling requested but the scene has no emitter"); return RL_ERR_NO_EMITTER; }
+    HIP_OK(hipSetDevice(ctx->device));
+    hipStream_t st = stream_arg ? (hipStream_t)stream_arg : ctx->stream;
+    auto t_start = std::chrono::steady_clock::now();
+    std::vector<unsigned> owned, item_base;
+    unsigned n_pixels = 0;
+    for (size_t b = 0; b < n_blocks; b++) {
+        if (b % shard_count != params->shard_index) continue;
+        unsigned bx = (unsigned)(b / nby) * 16u, by = (unsigned)(b % nby) * 16u;
+        owned.push_back((unsigned)b);
+        item_base.push_back(n_pixels);
+        n_pixels += std::min(16u, W - bx) * std::min(16u, H - by);
+    }
+    const bool per_sample = params->stream_mode == RL_STREAM_PER_SAMPLE;
+    const unsigned n_items = per_sample ? n_pixels : (unsigned)owned.size();
+    const unsigned n_threads = std::max(256u, (n_items + 255u) / 256u * 256u);
+    int rcode;
+    if ((rcode = ensure(&ctx->d_owned, &ctx->owned_capacity, owned.size())) != RL_OK) return rcode;
+    if ((rcode = ensure(&ctx->d_item_base, &ctx->item_base_capacity, owned.size())) != RL_OK) return rcode;
+    if ((rcode = ensure(&ctx->d_block_seeds, &ctx->seeds_capacity, n_blocks)) != RL_OK) return rcode;
+    if (per_sample) {
+        if ((rcode = ensure(&ctx->d_item_seed, &ctx->item_capacity, n_pixels)) != RL_OK) return rcode;
+        if ((rcode = ensure(&ctx->d_item_pixel, &ctx->item_pixel_capacity, n_pixels)) != RL_OK) return rcode;
+    }
+    float* d_out = out_rgb;
+    if (!out_is_device) {
+        if ((rcode = ensure(&ctx->d_out, &ctx->out_capacity, (size_t)3 * W * H)) != RL_OK) return rcode;
+        d_out = ctx->d_out;
+    }
+    const size_t n_rows = n_threads / 256;
+    if ((rcode = ensure(&ctx->d_partials, &ctx->partials_capacity, n_rows * STAT_COUNT)) != RL_OK) return rcode;
+    HIP_OK(hipMemcpyAsync(ctx->d_owned, owned.data(), owned.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(ctx->d_item_base, item_base.data(), item_base.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(ctx->d_block_seeds, block_seeds, n_blocks * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemsetAsync(d_out, 0, (size_t)3 * W * H * sizeof(float), st));
+    HIP_OK(hipMemsetAsync(ctx->d_partials, 0, n_rows * STAT_COUNT * sizeof(unsigned long long), st));
+    RenderConst rc{};
+    rc.spp = params->spp;
+    rc.stream_mode = params->stream_mode; rc.seed_variant = params->seed_variant;
+    rc.inv_spp = 1.0f / (float)params->spp;
+    rc.W = W; rc.H = H; rc.nby = (unsigned)nby;
+    rc.n_items = n_items;
+    rc.owned_blocks = ctx->d_owned; rc.block_item_base = ctx->d_item_base; rc.n_owned = (unsigned)owned.size();
+    rc.block_seeds = ctx->d_block_seeds;
+    rc.item_seed = ctx->d_item_seed; rc.item_pixel = ctx->d_item_pixel;
+    rc.out = d_out;
+    rc.counters = ctx->d_counters;
+    rc.partials = ctx->d_partials;
+    McConst mp{params->has_max_distance, params->max_distance, params->normal_correction, params->nb_bsdf_samples, params->nb_light_samples};
+    StackConf stc;
+    if ((rcode = stack_conf(ctx, n_threads, &stc)) != RL_OK) return rcode;
+    const size_t lds = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false);
+    const dim3 grid(n_threads / 256), block(256);
+    if (per_sample && !owned.empty()) hipLaunchKernelGGL(k_seed_pixels, dim3(((unsigned)owned.size() + 63) / 64), dim3(64), 0, st, rc);
+    if (kind == 0) { if (ctx->lds_scene) hipLaunchKernelGGL((k_pixel_mc<0, true>), grid, block, lds, st, rc, ctx->ds, stc, mp); else hipLaunchKernelGGL((k_pixel_mc<0, false>), grid, block, lds, st, rc, ctx->ds, stc, mp); }
+    else { if (ctx->lds_scene) hipLaunchKernelGGL((k_pixel_mc<1, true>), grid, block, lds, st, rc, ctx->ds, stc, mp); else hipLaunchKernelGGL((k_pixel_mc<1, false>), grid, block, lds, st, rc, ctx->ds, stc, mp); }
+    if (!out_is_device) HIP_OK(hipMemcpyAsync(out_rgb, d_out, (size_t)3 * W * H * sizeof(float), hipMemcpyDeviceToHost, st));
+    std::vector<unsigned long long> partials(n_rows * STAT_COUNT);
+    HIP_OK(hipMemcpyAsync(partials.data(), ctx->d_partials, partials.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    HIP_OK(hipGetLastError());
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        unsigned long long totals[STAT_COUNT] = {0};
+        for (size_t r = 0; r < n_rows; r++) for (int k = 0; k < STAT_COUNT; k++) totals[k] += partials[r * STAT_COUNT + k];
+        stats->camera_samples = totals[STAT_SAMPLES]; stats->vertices = totals[STAT_VERTICES]; stats->extension_rays = totals[STAT_EXT_RAYS];
+        stats->shadow_rays = totals[STAT_SHADOW_RAYS]; stats->rng_draws = totals[STAT_DRAWS];
+        stats->iterations = 1; stats->kernel_launches = per_sample ? 2 : 1;
+        stats->render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    }
+    return RL_OK;
+}
+extern "C" int rl_render_ao(rl_context* ctx, const rl_mc_params* params, const uint64_t* block_seeds, size_t n_blocks, float* out_rgb, int out_is_device,
+                            void* stream, rl_render_stats* stats) { return render_mc(ctx, 0, params, block_seeds, n_blocks, out_rgb, out_is_device, stream, stats); }
+extern "C" int rl_render_direct(rl_context* ctx, const rl_mc_params* params, const uint64_t* block_seeds, size_t n_blocks, float* out_rgb, int out_is_device,
+                                void* stream, rl_render_stats* stats) { return render_mc(ctx, 1, params, block_seeds, n_blocks, out_rgb, out_is_device, stream, stats); }
 
 // ---- batched Acceleration::{trace, visible}
 extern "C" int rl_trace_batch(rl_context* ctx, size_t n, const float* origins, const float* directions, float* t_out, float* u_out,

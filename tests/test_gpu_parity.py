@@ -175,6 +175,25 @@ def test_point_directional_environment_emitters_parity(built, combo):
         _assert_parity(*_render_pair(sd, **kw))
 
 
+@pytest.mark.parametrize("mode", [api.STREAM_PER_SAMPLE, api.STREAM_REFERENCE_ORDER])
+def test_ao_and_direct_integrators_parity(built, mode):
+    """`ao` and `direct` through the same tiling driver, bit-exact vs the oracle."""
+    for sd in (scenes.cbox(48, 40), scenes.cbox_other_lights(40, 40), scenes.living_room(48, 32, n_spheres=20, tess=8)):
+        ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+        seeds = api.IndependentSampler(4).block_seeds(sd.width, sd.height)
+        for kw in (dict(max_distance=1.0), dict(max_distance=None), dict(max_distance=0.3, normal_correction=True)):
+            img, st = ctx.render_ao(seeds, spp=3, stream_mode=mode, **kw)
+            ref, ost = osc.render_ao(seeds=seeds, spp=3, stream_mode=mode, **kw)
+            np.testing.assert_array_equal(img, ref)
+            assert all(st[k] == ost[k] for k in ("camera_samples", "extension_rays", "rng_draws"))
+        for kw in (dict(), dict(nb_bsdf_samples=2, nb_light_samples=3), dict(nb_bsdf_samples=0, nb_light_samples=1), dict(nb_bsdf_samples=1, nb_light_samples=0)):
+            img, st = ctx.render_direct(seeds, spp=3, stream_mode=mode, **kw)
+            ref, ost = osc.render_direct(seeds=seeds, spp=3, stream_mode=mode, **kw)
+            np.testing.assert_array_equal(img, ref)
+            assert all(st[k] == ost[k] for k in ("camera_samples", "extension_rays", "shadow_rays", "rng_draws"))
+            assert img.mean() > 0
+
+
 def test_furnace_invariant_on_gpu(built):
     sd = scenes.furnace(albedo=0.5, le=1.0, width=16, height=16)
     ctx = api.Context(api.Scene(sd), 0)

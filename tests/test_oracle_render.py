@@ -127,3 +127,16 @@ def test_other_emitters(built):
         assert abs(img3.mean() - 0.5) < 0.01
     leak = [orc.Scene(env_only).render(master_seed=5 + s_, spp=64, strategy=s_, min_depth=1)[0].mean() for s_ in (1, 2)]
     assert leak[1] > 1.3 * leak[0]           # the quirk is visible in the closed box
+
+
+def test_ao_and_direct(built, orc_cbox64):
+    ao, st = orc_cbox64.render_ao(master_seed=1, spp=8)
+    assert set(np.unique(ao)).issubset({i / 8 for i in range(9)}) and 0.2 < ao.mean() < 0.9        # occlusion is 0/1 per sample
+    open_ao, _ = orc_cbox64.render_ao(master_seed=1, spp=8, max_distance=None)
+    assert open_ao.mean() < ao.mean()                                                               # "inf": only escaping rays count
+    d, st = orc_cbox64.render_direct(master_seed=2, spp=32)
+    p1, _ = orc_cbox64.render(master_seed=3, spp=32, max_depth=3)                                   # path tracer cut at one bounce = direct lighting
+    assert abs(d.mean() - p1.mean()) / p1.mean() < 0.05
+    dl, _ = orc_cbox64.render_direct(master_seed=4, spp=32, nb_bsdf_samples=0, nb_light_samples=2)
+    db, _ = orc_cbox64.render_direct(master_seed=5, spp=128, nb_bsdf_samples=2, nb_light_samples=0)
+    assert abs(dl.mean() - d.mean()) / d.mean() < 0.05 and abs(db.mean() - d.mean()) / d.mean() < 0.1
