@@ -281,6 +281,14 @@ int rl_visible_batch(rl_context* ctx, size_t n, const float* p0, const float* p1
 /* Bitmap::save_pfm (src/structure.rs:547-560): bottom-up rows, |value|, little-endian, "-1.0" scale. */
 int rl_save_pfm(const char* path, const float* rgb, uint32_t width, uint32_t height);
 
+/* Bitmap::save_ldr_image (src/structure.rs:471-484) with Color::to_rgba (161-168): 8-bit RGB PNG,
+ * (min(c, 1)^(1/2.2) * 255) as u8. */
+int rl_save_png(const char* path, const float* rgb, uint32_t width, uint32_t height);
+/* Bitmap::save_exr (src/structure.rs:490-527): scanline OpenEXR, FLOAT channels R, G, B, no compression. */
+int rl_save_exr(const char* path, const float* rgb, uint32_t width, uint32_t height);
+/* Bitmap::save (src/structure.rs:528-545): dispatch on the file extension (.pfm | .png | .exr). */
+int rl_save_image(const char* path, const float* rgb, uint32_t width, uint32_t height);
+
 /* Library/build info (for tests: which arch the kernels were compiled for). */
 const char* rl_build_info(void);
 

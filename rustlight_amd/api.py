@@ -32,7 +32,7 @@ PUBLIC_SYMBOLS = [
     "rl_scene_set_environment", "rl_scene_build_emitters", "rl_scene_load_pbrt",
     "rl_scene_image_size", "rl_scene_counts", "rl_sampler_seed", "rl_sampler_next_u64", "rl_sampler_next_f32",
     "rl_path_params_default", "rl_context_create", "rl_context_destroy", "rl_last_error", "rl_block_count",
-    "rl_generate_block_seeds", "rl_render_path", "rl_render_ao", "rl_render_direct", "rl_trace_batch", "rl_visible_batch", "rl_save_pfm", "rl_build_info",
+    "rl_generate_block_seeds", "rl_render_path", "rl_render_ao", "rl_render_direct", "rl_trace_batch", "rl_visible_batch", "rl_save_pfm", "rl_save_png", "rl_save_exr", "rl_save_image", "rl_build_info",
 ]
 
 
@@ -93,7 +93,8 @@ def lib():
         fn.argtypes = [vp, C.POINTER(abi.McParams), u64p, C.c_size_t, vp, C.c_int, vp, C.POINTER(abi.RenderStats)]
     L.rl_trace_batch.argtypes = [vp, C.c_size_t, f32p, f32p, f32p, f32p, f32p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rl_visible_batch.argtypes = [vp, C.c_size_t, f32p, f32p, C.POINTER(C.c_uint8)]
-    L.rl_save_pfm.argtypes = [C.c_char_p, f32p, C.c_uint32, C.c_uint32]
+    for fn in (L.rl_save_pfm, L.rl_save_png, L.rl_save_exr, L.rl_save_image):
+        fn.argtypes = [C.c_char_p, f32p, C.c_uint32, C.c_uint32]
     L.rl_build_info.restype = C.c_char_p
     # test hooks
     L.rl_debug_numerics.argtypes = [C.c_int, C.c_size_t, f32p, f32p, f32p]
@@ -341,6 +342,69 @@ class IntegratorPathTracing:
 def save_pfm(path: str, img: np.ndarray):
     a = np.ascontiguousarray(img, dtype=np.float32)
     _check(lib().rl_save_pfm(path.encode(), abi.fptr(a), a.shape[1], a.shape[0]))
+
+
+def save_image(path: str, img: np.ndarray):
+    """Bitmap::save: .pfm | .png | .exr by extension (src/structure.rs:528-545)."""
+    a = np.ascontiguousarray(img, dtype=np.float32)
+    _check(lib().rl_save_image(path.encode(), abi.fptr(a), a.shape[1], a.shape[0]))
+
+
+class IntegratorAverage:
+    """IntegratorAverage { time_out, integrator, dump_all } (src/integrators/avg.rs:5-131): re-runs the inner integrator with
+    the same, advancing master sampler, keeps the running average, dumps `<base>_<iter>.<ext>` and `<base>_time.csv`."""
+
+    def __init__(self, integrator, time_out=None, dump_all=True, max_iterations=None):
+        self.integrator, self.time_out, self.dump_all, self.max_iterations = integrator, time_out, dump_all, max_iterations
+        self.iterations = 0
+
+    def compute(self, sampler, scene, nb_samples=1, output_img_path="out.pfm"):
+        import time
+        if not self.dump_all and self.time_out is None and self.max_iterations is None:
+            raise ValueError("Impossible to have infinite approach and not dumping all images")
+        base, ext = os.path.splitext(output_img_path)
+        csv = open(base + "_time.csv", "w") if self.dump_all else None
+        bitmap, iteration, elapsed = None, 1, 0.0
+        while True:
+            t0 = time.perf_counter()
+            new = self.integrator.compute(sampler, scene, nb_samples)
+            if iteration == 1:
+                bitmap = new
+            else:   # bitmap.scale(iteration); accumulate_bitmap; scale(1 / (iteration + 1))   (avg.rs:59-61, sic)
+                bitmap = ((bitmap * np.float32(iteration)) + new) * (np.float32(1.0) / np.float32(iteration + 1))
+            elapsed += time.perf_counter() - t0
+            if self.dump_all:
+                save_image(f"{base}_{iteration}{ext}", bitmap)
+                csv.write(f"{int(elapsed)}.{int((elapsed % 1) * 1000)},\n")
+            self.iterations = iteration
+            if (self.time_out is not None and int(elapsed) >= self.time_out) or (self.max_iterations is not None and iteration >= self.max_iterations):
+                break
+            iteration += 1
+        if csv:
+            csv.close()
+        return bitmap
+
+
+class IntegratorEqualTime:
+    """IntegratorEqualTime { target_time_ms, integrator } (src/integrators/equal_time.rs:4-66)."""
+
+    def __init__(self, integrator, target_time_ms):
+        self.integrator, self.target_time_ms = integrator, target_time_ms
+        self.iterations = 0
+
+    def compute(self, sampler, scene, nb_samples=1):
+        import time
+        bitmap, iteration, elapsed = None, 1, 0.0
+        while True:
+            t0 = time.perf_counter()
+            new = self.integrator.compute(sampler, scene, nb_samples)
+            bitmap = new if iteration == 1 else bitmap + new
+            elapsed += time.perf_counter() - t0
+            if elapsed * 1000.0 >= self.target_time_ms:
+                break
+            iteration += 1
+        self.iterations = iteration
+        return bitmap * (np.float32(1.0) / np.float32(iteration))
 
 
 def numerics_probe(a: np.ndarray, b: np.ndarray, device: int = 0) -> np.ndarray:

@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
     float scale_image = 1.0f;
     int device = 0;
     bool single_scattering = false, have_cmd = false;
-    std::string cmd, ao_distance = "1.0";
+    std::string cmd, ao_distance = "1.0", average, equal_time;
     bool ao_normal_correction = false;
     size_t nb_bsdf = 1, nb_light = 1;
     rl_stream_mode mode = RL_STREAM_PER_SAMPLE;
@@ -51,7 +51,9 @@ int main(int argc, char** argv) {
             else if (a == "-t" || a == "--threads") (void)val();   // host threads are irrelevant on the GPU path
             else if (a == "--device") device = std::atoi(val().c_str());
             else if (a == "--stream-mode") mode = val() == "reference" ? RL_STREAM_REFERENCE_ORDER : RL_STREAM_PER_SAMPLE;
-            else if (a == "-a" || a == "-e" || a == "-l" || a == "-x") { std::fprintf(stderr, "option %s is not supported by this drop-in yet\n", a.c_str()); return 2; }
+            else if (a == "-a" || a == "--average") average = val();
+            else if (a == "-e" || a == "--equal-time") equal_time = val();
+            else if (a == "-l" || a == "-x") { std::fprintf(stderr, "option %s is not supported by this drop-in\n", a.c_str()); return 2; }
             else if (a[0] == '-') { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
             else if (scene_path.empty()) scene_path = a;
             else { std::fprintf(stderr, "only the `path`, `ao` and `direct` subcommands are provided (got %s)\n", a.c_str()); return 2; }
@@ -122,10 +124,17 @@ int main(int argc, char** argv) {
             IntegratorDirect di;
             di.device = device; di.stream_mode = mode; di.nb_bsdf_samples = nb_bsdf; di.nb_light_samples = nb_light;
             img = di.compute(sampler, *scene); elapsed_ms = di.last_stats.render_ms;
+        } else if (!equal_time.empty()) {        // cli.rs:898-907
+            IntegratorEqualTime<IntegratorPathTracing> eq{integrator, std::strtod(equal_time.c_str(), nullptr) * 1000.0};
+            img = eq.compute(sampler, *scene); elapsed_ms = integrator.last_stats.render_ms;
+            std::fprintf(stderr, "INFO Number iter: %zu\nINFO Number spp: %zu\n", eq.iterations, eq.iterations * scene->nb_samples);
+        } else if (!average.empty()) {           // cli.rs:908-917
+            IntegratorAverage<IntegratorPathTracing> av{integrator, std::nullopt, true};
+            if (average != "inf") av.time_out = (size_t)std::strtoull(average.c_str(), nullptr, 10);
+            img = av.compute(sampler, *scene); elapsed_ms = integrator.last_stats.render_ms;
         } else { img = integrator.compute(sampler, *scene); elapsed_ms = integrator.last_stats.render_ms; }
         std::fprintf(stderr, "INFO Elapsed Integrator: %.0f ms\n", elapsed_ms);
         std::fprintf(stderr, "INFO Save final image: %s\n", output.c_str());
-        if (output.size() < 4 || output.substr(output.size() - 4) != ".pfm") { std::fprintf(stderr, "only .pfm output is supported\n"); return 2; }
         img.save("primal", output);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "ERROR %s\n", e.what());

@@ -7,7 +7,9 @@
 //   struct IntegratorPathTracing            src/integrators/explicit/path.rs:14-20
 //   IntegratorType::compute (BVH build is untimed, then "Elapsed Integrator")  mod.rs:274-338
 #pragma once
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -45,9 +47,11 @@ struct Scene {
 struct BufferCollection {   // only the "primal" buffer exists on this path
     uint32_t width = 0, height = 0;
     std::vector<float> primal;   // W*H*3, row-major, origin top-left
-    void save(const std::string& /*name = "primal"*/, const std::string& path) const {
-        if (rl_save_pfm(path.c_str(), primal.data(), width, height) != RL_OK) throw std::runtime_error("cannot write " + path);
+    void save(const std::string& /*name = "primal"*/, const std::string& path) const {   // Bitmap::save: .pfm | .png | .exr
+        if (rl_save_image(path.c_str(), primal.data(), width, height) != RL_OK) throw std::runtime_error("cannot write " + path);
     }
+    void scale(float v) { for (float& x : primal) x *= v; }                                   // Bitmap::scale
+    void accumulate_bitmap(const BufferCollection& o) { for (size_t i = 0; i < primal.size(); i++) primal[i] += o.primal[i]; }
 };
 
 enum class IntegratorPathTracingStrategies { All = RL_STRATEGY_ALL, BSDF = RL_STRATEGY_BSDF, Emitter = RL_STRATEGY_EMITTER };
@@ -62,11 +66,23 @@ struct IntegratorPathTracing {
     uint32_t shard_index = 0, shard_count = 1;
     rl_render_stats last_stats{};
 
-    // IntegratorType::compute + Integrator::compute: builds the BVH (untimed), renders, returns the image
+    // the device context (BVH + uploaded scene) is built once per scene, like `BVHAccel::new` in IntegratorType::compute
+    rl_context* ctx = nullptr;
+    const Scene* ctx_scene = nullptr;
+    IntegratorPathTracing() = default;
+    IntegratorPathTracing(const IntegratorPathTracing&) = delete;
+    ~IntegratorPathTracing() { if (ctx) rl_context_destroy(ctx); }
+
+    // IntegratorType::compute + Integrator::compute: builds the BVH (untimed, first call), renders, returns the image
     BufferCollection compute(IndependentSampler& sampler, Scene& scene) {
-        rl_context* ctx = nullptr;
-        int rc = rl_context_create(scene.handle, device, &ctx);
-        if (rc != RL_OK) throw std::runtime_error(std::string("rl_context_create: ") + rl_last_error());
+        int rc;
+        if (!ctx || ctx_scene != &scene) {
+            if (ctx) rl_context_destroy(ctx);
+            ctx = nullptr;
+            rc = rl_context_create(scene.handle, device, &ctx);
+            if (rc != RL_OK) throw std::runtime_error(std::string("rl_context_create: ") + rl_last_error());
+            ctx_scene = &scene;
+        }
         BufferCollection img;
         rl_scene_image_size(scene.handle, &img.width, &img.height);
         img.primal.assign((size_t)3 * img.width * img.height, 0.0f);
@@ -84,7 +100,6 @@ struct IntegratorPathTracing {
         std::vector<uint64_t> seeds(rl_block_count(img.width, img.height));
         rl_generate_block_seeds(&sampler.rnd, img.width, img.height, seeds.data(), seeds.size());   // generate_img_blocks
         rc = rl_render_path(ctx, &p, seeds.data(), seeds.size(), img.primal.data(), 0, nullptr, &last_stats);
-        rl_context_destroy(ctx);
         if (rc != RL_OK) throw std::runtime_error(std::string("rl_render_path: ") + rl_last_error());
         return img;
     }
@@ -131,6 +146,63 @@ struct IntegratorDirect : IntegratorMC {
         rl_mc_params p{};
         p.nb_bsdf_samples = (uint32_t)nb_bsdf_samples; p.nb_light_samples = (uint32_t)nb_light_samples;
         return run(true, p, sampler, scene);
+    }
+};
+
+// IntegratorAverage (src/integrators/avg.rs:5-131) and IntegratorEqualTime (src/integrators/equal_time.rs:4-66):
+// host loops around any inner integrator with `compute(IndependentSampler&, Scene&)`.
+template <class Inner>
+struct IntegratorAverage {
+    Inner& integrator;
+    std::optional<size_t> time_out;   // seconds
+    bool dump_all = true;
+    BufferCollection compute(IndependentSampler& sampler, Scene& scene) {
+        if (!dump_all && !time_out) throw std::runtime_error("Impossible to have infinite approach and not dumping all images");
+        const std::string& out = scene.output_img_path;
+        size_t dot = out.rfind('.');
+        if (dot == std::string::npos) throw std::runtime_error("No file extension provided");
+        const std::string base = out.substr(0, dot), ext = out.substr(dot + 1);
+        FILE* csv = dump_all ? std::fopen((base + "_time.csv").c_str(), "w") : nullptr;
+        BufferCollection bitmap;
+        size_t iteration = 1;
+        double elapsed = 0.0;
+        for (;;) {
+            auto t0 = std::chrono::steady_clock::now();
+            BufferCollection nb = integrator.compute(sampler, scene);
+            if (iteration == 1) bitmap = nb;
+            else { bitmap.scale((float)iteration); bitmap.accumulate_bitmap(nb); bitmap.scale(1.0f / (float)(iteration + 1)); }   // avg.rs:59-61
+            elapsed += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (dump_all) {
+                bitmap.save("primal", base + "_" + std::to_string(iteration) + "." + ext);
+                std::fprintf(csv, "%llu.%u,\n", (unsigned long long)elapsed, (unsigned)((elapsed - (double)(unsigned long long)elapsed) * 1000.0));
+            }
+            if (time_out && (size_t)elapsed >= *time_out) break;
+            iteration++;
+        }
+        if (csv) std::fclose(csv);
+        return bitmap;
+    }
+};
+template <class Inner>
+struct IntegratorEqualTime {
+    Inner& integrator;
+    double target_time_ms;
+    size_t iterations = 0;
+    BufferCollection compute(IndependentSampler& sampler, Scene& scene) {
+        BufferCollection bitmap;
+        size_t iteration = 1;
+        double elapsed_ms = 0.0;
+        for (;;) {
+            auto t0 = std::chrono::steady_clock::now();
+            BufferCollection nb = integrator.compute(sampler, scene);
+            if (iteration == 1) bitmap = nb; else bitmap.accumulate_bitmap(nb);
+            elapsed_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (elapsed_ms >= target_time_ms) break;
+            iteration++;
+        }
+        bitmap.scale(1.0f / (float)iteration);
+        iterations = iteration;
+        return bitmap;
     }
 };
 

@@ -1,6 +1,9 @@
 // io.cpp — image output and host-only debug hooks.
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "../kernels/wavefront.h"
 #include "scene.h"
@@ -24,6 +27,114 @@ int rl_save_pfm(const char* path, const float* rgb, uint32_t width, uint32_t hei
     }
     std::fclose(f);
     return RL_OK;
+}
+
+// ---- PNG (stored deflate blocks; no external zlib needed)
+static uint32_t crc32_update(uint32_t crc, const unsigned char* p, size_t n) {
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1; table[i] = c; }
+        init = true;
+    }
+    crc = ~crc;
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xff] ^ (crc >> 8);
+    return ~crc;
+}
+static void put_be32(std::vector<unsigned char>& v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
+static bool write_chunk(FILE* f, const char* type, const std::vector<unsigned char>& data) {
+    std::vector<unsigned char> buf;
+    put_be32(buf, (uint32_t)data.size());
+    buf.insert(buf.end(), type, type + 4);
+    buf.insert(buf.end(), data.begin(), data.end());
+    uint32_t crc = crc32_update(0, buf.data() + 4, buf.size() - 4);
+    put_be32(buf, crc);
+    return std::fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+}
+// Color::to_rgba (structure.rs:161-168): (c.min(1.0).powf(1/2.2) * 255.0) as u8 — `as u8` saturates, NaN -> 0
+static unsigned char to_u8(float c) {
+    float v = std::pow(std::fmin(c, 1.0f), 1.0f / 2.2f) * 255.0f;
+    if (!(v > 0.0f)) return 0;
+    if (v >= 255.0f) return 255;
+    return (unsigned char)v;
+}
+int rl_save_png(const char* path, const float* rgb, uint32_t width, uint32_t height) {
+    if (!path || !rgb || width == 0 || height == 0) return RL_ERR_INVALID_ARGUMENT;
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return RL_ERR_IO;
+    const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    bool ok = std::fwrite(sig, 1, 8, f) == 8;
+    std::vector<unsigned char> ihdr;
+    put_be32(ihdr, width); put_be32(ihdr, height);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    ok = ok && write_chunk(f, "IHDR", ihdr);
+    std::vector<unsigned char> raw;
+    raw.reserve((size_t)height * (3 * width + 1));
+    for (uint32_t y = 0; y < height; y++) {
+        raw.push_back(0);
+        for (uint32_t x = 0; x < 3 * width; x++) raw.push_back(to_u8(rgb[(size_t)3 * width * y + x]));
+    }
+    std::vector<unsigned char> z;
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;
+    for (size_t off = 0; off < raw.size(); off += 65535) {
+        size_t n = std::min<size_t>(65535, raw.size() - off);
+        z.push_back(off + n == raw.size() ? 1 : 0);
+        z.push_back(n & 0xff); z.push_back(n >> 8); z.push_back(~n & 0xff); z.push_back((~n >> 8) & 0xff);
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+    }
+    for (unsigned char c : raw) { a = (a + c) % 65521; b = (b + a) % 65521; }
+    put_be32(z, (b << 16) | a);
+    ok = ok && write_chunk(f, "IDAT", z) && write_chunk(f, "IEND", {});
+    std::fclose(f);
+    return ok ? RL_OK : RL_ERR_IO;
+}
+
+// ---- OpenEXR: single-part scanline file, NO_COMPRESSION, FLOAT channels (stored alphabetically: B, G, R)
+int rl_save_exr(const char* path, const float* rgb, uint32_t width, uint32_t height) {
+    if (!path || !rgb || width == 0 || height == 0) return RL_ERR_INVALID_ARGUMENT;
+    std::vector<unsigned char> h;
+    auto put32 = [&](std::vector<unsigned char>& v, uint32_t x) { for (int i = 0; i < 4; i++) v.push_back((x >> (8 * i)) & 0xff); };
+    auto putf = [&](std::vector<unsigned char>& v, float x) { uint32_t u; std::memcpy(&u, &x, 4); put32(v, u); };
+    auto puts = [&](std::vector<unsigned char>& v, const char* s) { while (*s) v.push_back((unsigned char)*s++); v.push_back(0); };
+    auto attr = [&](const char* name, const char* type, const std::vector<unsigned char>& val) { puts(h, name); puts(h, type); put32(h, (uint32_t)val.size()); h.insert(h.end(), val.begin(), val.end()); };
+    put32(h, 20000630u);   // magic
+    put32(h, 2u);          // version 2, scanline, single part
+    { std::vector<unsigned char> v; for (const char* c : {"B", "G", "R"}) { puts(v, c); put32(v, 2u /*FLOAT*/); v.push_back(0); v.push_back(0); v.push_back(0); v.push_back(0); put32(v, 1); put32(v, 1); } v.push_back(0); attr("channels", "chlist", v); }
+    { std::vector<unsigned char> v; v.push_back(0); attr("compression", "compression", v); }
+    { std::vector<unsigned char> v; put32(v, 0); put32(v, 0); put32(v, width - 1); put32(v, height - 1); attr("dataWindow", "box2i", v); attr("displayWindow", "box2i", v); }
+    { std::vector<unsigned char> v; v.push_back(0); attr("lineOrder", "lineOrder", v); }
+    { std::vector<unsigned char> v; putf(v, 1.0f); attr("pixelAspectRatio", "float", v); }
+    { std::vector<unsigned char> v; putf(v, 0.0f); putf(v, 0.0f); attr("screenWindowCenter", "v2f", v); }
+    { std::vector<unsigned char> v; putf(v, 1.0f); attr("screenWindowWidth", "float", v); }
+    h.push_back(0);
+    const uint64_t line_bytes = (uint64_t)width * 12;
+    const uint64_t table_off = h.size();
+    uint64_t off = table_off + (uint64_t)8 * height;
+    for (uint32_t y = 0; y < height; y++) { uint64_t o = off + (uint64_t)y * (8 + line_bytes); for (int i = 0; i < 8; i++) h.push_back((o >> (8 * i)) & 0xff); }
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return RL_ERR_IO;
+    bool ok = std::fwrite(h.data(), 1, h.size(), f) == h.size();
+    std::vector<unsigned char> line;
+    for (uint32_t y = 0; y < height && ok; y++) {
+        line.clear();
+        put32(line, y); put32(line, (uint32_t)line_bytes);
+        for (int c = 2; c >= 0; c--)       // B, G, R planes
+            for (uint32_t x = 0; x < width; x++) putf(line, rgb[(size_t)3 * ((size_t)y * width + x) + c]);
+        ok = std::fwrite(line.data(), 1, line.size(), f) == line.size();
+    }
+    std::fclose(f);
+    return ok ? RL_OK : RL_ERR_IO;
+}
+
+int rl_save_image(const char* path, const float* rgb, uint32_t width, uint32_t height) {
+    if (!path) return RL_ERR_INVALID_ARGUMENT;
+    const char* dot = std::strrchr(path, '.');
+    if (!dot) return RL_ERR_INVALID_ARGUMENT;            // "No file extension provided"
+    if (!std::strcmp(dot, ".pfm")) return rl_save_pfm(path, rgb, width, height);
+    if (!std::strcmp(dot, ".png")) return rl_save_png(path, rgb, width, height);
+    if (!std::strcmp(dot, ".exr")) return rl_save_exr(path, rgb, width, height);
+    return RL_ERR_UNSUPPORTED;                            // "Unknow output file extension"
 }
 
 int rl_debug_bvh(const rl_scene* scene, uint64_t* n_nodes, uint64_t* n_prims, float* boxes, uint64_t* info, uint64_t* count,

@@ -98,3 +98,34 @@ def test_save_pfm(built, tmp_path):
     assert raw.startswith(b"PF\n3 2\n-1.0\n")
     data = np.frombuffer(raw[len(b"PF\n3 2\n-1.0\n"):], dtype="<f4").reshape(2, 3, 3)
     np.testing.assert_array_equal(data, np.abs(img[::-1]))      # bottom-up rows, abs() (structure.rs:547-560)
+
+
+def test_save_png_and_exr(built, tmp_path):
+    import struct
+    from PIL import Image
+
+    img = np.random.default_rng(0).uniform(-0.2, 1.5, (6, 9, 3)).astype(np.float32)
+    png, exr = str(tmp_path / "a.png"), str(tmp_path / "a.exr")
+    api.save_image(png, img)
+    api.save_image(exr, img)
+    got = np.array(Image.open(png))
+    want = (np.clip(np.minimum(img, 1.0), 0, None) ** (1 / 2.2) * 255).astype(np.uint8)       # Color::to_rgba
+    assert got.shape == (6, 9, 3) and np.abs(got.astype(int) - want.astype(int)).max() <= 1
+    raw = open(exr, "rb").read()
+    assert struct.unpack("<II", raw[:8]) == (20000630, 2)
+    pos, attrs = 8, {}
+    while raw[pos] != 0:                                                                         # header attributes
+        name = raw[pos:raw.index(b"\0", pos)].decode(); pos += len(name) + 1
+        typ = raw[pos:raw.index(b"\0", pos)].decode(); pos += len(typ) + 1
+        size = struct.unpack("<I", raw[pos:pos + 4])[0]; pos += 4
+        attrs[name] = (typ, raw[pos:pos + size]); pos += size
+    pos += 1
+    assert attrs["compression"][1] == b"\0" and struct.unpack("<4i", attrs["dataWindow"][1]) == (0, 0, 8, 5)
+    offsets = struct.unpack("<6Q", raw[pos:pos + 48])
+    for y, off in enumerate(offsets):
+        yy, nbytes = struct.unpack("<iI", raw[off:off + 8])
+        assert (yy, nbytes) == (y, 9 * 12)
+        planes = np.frombuffer(raw[off + 8:off + 8 + nbytes], "<f4").reshape(3, 9)              # B, G, R
+        np.testing.assert_array_equal(planes[::-1].T, img[y])
+    with pytest.raises(api.RustlightError):
+        api.save_image(str(tmp_path / "a.jpg"), img)

@@ -194,6 +194,29 @@ def test_ao_and_direct_integrators_parity(built, mode):
             assert img.mean() > 0
 
 
+def test_progressive_wrappers(built, cbox64, tmp_path):
+    """IntegratorAverage / IntegratorEqualTime (avg.rs, equal_time.rs): every pass draws fresh block seeds from the same,
+    advancing master sampler; pass k of the wrapper equals a plain render with the k-th batch of seeds."""
+    scene = api.Scene(cbox64)
+    inner = api.IntegratorPathTracing()
+    avg = api.IntegratorAverage(inner, max_iterations=3)
+    out = str(tmp_path / "avg.pfm")
+    img = avg.compute(api.IndependentSampler(9), scene, nb_samples=2, output_img_path=out)
+    s = api.IndependentSampler(9)
+    passes = [api.Context(scene, 0).render(s.block_seeds(64, 64), api.path_params(spp=2))[0] for _ in range(3)]
+    want = passes[0]
+    for k, p in enumerate(passes[1:], start=2):
+        # avg.rs:59-61 weighs the old image by k and divides by k + 1 (the counter is already one ahead); kept as is
+        want = ((want * np.float32(k)) + p) * (np.float32(1.0) / np.float32(k + 1))
+    np.testing.assert_array_equal(img, want)
+    import os
+    assert all(os.path.exists(str(tmp_path / f"avg_{k}.pfm")) for k in (1, 2, 3)) and os.path.exists(str(tmp_path / "avg_time.csv"))
+    eq = api.IntegratorEqualTime(api.IntegratorPathTracing(), target_time_ms=0.0)
+    one = eq.compute(api.IndependentSampler(9), scene, nb_samples=2)
+    assert eq.iterations == 1
+    np.testing.assert_array_equal(one, passes[0])
+
+
 def test_furnace_invariant_on_gpu(built):
     sd = scenes.furnace(albedo=0.5, le=1.0, width=16, height=16)
     ctx = api.Context(api.Scene(sd), 0)
