@@ -135,11 +135,15 @@ def main():
             cw, ch, cspp = args.width, args.height, max(1, args.spp // 8)   # bounded sample of the same workload: same scene and resolution, 1/8 of the spp
             osc = orc.Scene(scenes.cbox(cw, ch) if args.scene == "cbox" else (scenes.cbox_medium(cw, ch, 0.5) if args.scene == "cbox_medium" else scenes.living_room(cw, ch)))
             osc.render(master_seed=1, spp=1, stream_mode=0, threads=0)                # warm the thread pool / page in
-            t1 = time.perf_counter()
-            _, ost = osc.render(master_seed=0, spp=cspp, stream_mode=0, threads=0)
-            ct = time.perf_counter() - t1
-            cpu = {"value": cw * ch * cspp / ct / 1e6, "unit": "Msamples/s", "cores": ost["threads"], "kind": "port",
-                   "sample": f"{args.scene} {cw}x{ch}x{cspp}spp, reference-order streams, CPU restatement of rustlight `path` (C++), {ost['threads']} threads"}
+            runs = []
+            for _ in range(3):      # the host is shared and noisy: report the best of three passes (all three listed)
+                t1 = time.perf_counter()
+                _, ost = osc.render(master_seed=0, spp=cspp, stream_mode=0, threads=0)
+                runs.append(cw * ch * cspp / (time.perf_counter() - t1) / 1e6)
+                if sum(cw * ch * cspp / r / 1e6 for r in runs) > 30.0:
+                    break
+            cpu = {"value": max(runs), "unit": "Msamples/s", "cores": ost["threads"], "kind": "port", "runs": [round(r, 2) for r in runs],
+                   "sample": f"{args.scene} {cw}x{ch}x{cspp}spp, reference-order streams, CPU restatement of rustlight `path` (C++), {ost['threads']} threads, best of {len(runs)}"}
         out = {"metric": "Msamples/s (paths/s) at 1080p x 128spp cbox", "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",

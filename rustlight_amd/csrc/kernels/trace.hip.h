@@ -19,9 +19,15 @@ namespace rl {
 
 struct Hit { float t, u, v; int prim; };
 
-// AABB::intersect (src/structure.rs:849-869) with 1/d hoisted out of the loop.  The reference leaves the
-// axis loop as soon as `t_max <= t_min`; the remaining axes have no side effects, so evaluating all three
-// and AND-ing the three tests is equivalent (NaNs compare false exactly as there) and keeps the wave converged.
+// AABB::intersect (src/structure.rs:849-869) with 1/d hoisted out of the loop, restated without its per-axis
+// early exit and compare/select chains — same value, same verdict, a third fewer VALU instructions:
+//  * `t_min = if a0 > t_min {a0} else {t_min}` never makes t_min a NaN (a NaN a0 = 0 * inf loses the compare), so it
+//    is IEEE maxNum(a0, t_min) = v_max_f32, and likewise t_max = minNum(a1, t_max); maxNum/minNum skip NaNs in any
+//    association, so the three axes fold into v_max3_f32 / v_min3_f32.  (t_min >= tnear > 0: no signed-zero case.)
+//  * t_min only grows and t_max only shrinks, so the reference's exit `t_max <= t_min` after axis k implies the
+//    same relation after axis 3: one final test decides, and on success t_min is the returned entry distance.
+// The near/far plane choice stays a select on the sign of 1/d (min/max of t0, t1 would resurrect a NaN plane).
+#ifdef RL_SLAB_REFERENCE_FORM
 RL_DEV bool slab(V3 lo, V3 hi, V3 o, V3 inv_d, float tnear, float tfar, float* t_entry) {
     float t_min = tnear, t_max = tfar;
     float t0 = (lo.x - o.x) * inv_d.x, t1 = (hi.x - o.x) * inv_d.x;
@@ -42,6 +48,18 @@ RL_DEV bool slab(V3 lo, V3 hi, V3 o, V3 inv_d, float tnear, float tfar, float* t
     *t_entry = t_min;
     return ok;
 }
+#else
+RL_DEV bool slab(V3 lo, V3 hi, V3 o, V3 inv_d, float tnear, float tfar, float* t_entry) {
+    const float x0 = (lo.x - o.x) * inv_d.x, x1 = (hi.x - o.x) * inv_d.x;
+    const float y0 = (lo.y - o.y) * inv_d.y, y1 = (hi.y - o.y) * inv_d.y;
+    const float z0 = (lo.z - o.z) * inv_d.z, z1 = (hi.z - o.z) * inv_d.z;
+    const bool sx = inv_d.x < 0.0f, sy = inv_d.y < 0.0f, sz = inv_d.z < 0.0f;
+    const float t_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(sx ? x1 : x0, sy ? y1 : y0), sz ? z1 : z0), tnear);
+    const float t_max = __builtin_fminf(__builtin_fminf(__builtin_fminf(sx ? x0 : x1, sy ? y0 : y1), sz ? z0 : z1), tfar);
+    *t_entry = t_min;
+    return !(t_max <= t_min);
+}
+#endif
 
 // Mesh::intersection_tri; returns true and updates `hit` if the triangle is the new closest hit.
 // The reference evaluates u, v (two sqrt + two divides) before it looks at `t < its.t && t > 1e-5`
@@ -82,23 +100,28 @@ struct SceneRecs {
 // Control flow is "while-while": every lane first descends inner nodes until it holds a leaf (or is
 // done), then the wave tests leaves together.  Visit order and pruning are those of the reference's
 // recursion; only the interleaving between lanes changes (wave64 lane utilisation 32 % -> see profiles/).
-// Per-lane traversal stack: the first `lds_levels` entries live in LDS (layout [level][lane], conflict-free),
-// deeper levels spill to a global overflow buffer with the same coalesced layout.  Keeping only ~12 levels
+// Per-lane traversal stack: the first `lds_levels` entries live in LDS (layout [level][lane] of 8-byte pairs,
+// conflict-free, one ds_read_b64 / ds_write_b64 per pop / push), deeper levels spill to a global overflow buffer
+// with the same coalesced layout.  LDS_ONLY (BVH depth <= the LDS levels, always the case for LDS-staged scenes)
+// compiles the overflow path out, which keeps every stack access a plain ds_* instruction instead of a flat one.  Keeping only ~12 levels
 // in LDS (96 B/lane) lets 8 waves/SIMD stay resident on scenes whose BVH is 20-40 levels deep.
-struct TravStack {
-    int* lds; int lds_stride; int lds_levels;
-    int* glob; size_t glob_stride;     // glob already offset to this lane
+template <bool LDS_ONLY>
+struct TravStackT {
+    int2* lds; int lds_stride; int lds_levels;   // lds already offset to this lane; one (code, distance bits) pair per level
+    int* glob; size_t glob_stride;               // glob already offset to this lane
     RL_DEV void push(int sp, int code, float dist) const {
-        if (sp < lds_levels) { lds[(2 * sp) * lds_stride] = code; lds[(2 * sp + 1) * lds_stride] = __float_as_int(dist); }
+        if (LDS_ONLY || sp < lds_levels) lds[sp * lds_stride] = make_int2(code, __float_as_int(dist));
         else { size_t k = (size_t)(2 * (sp - lds_levels)); glob[k * glob_stride] = code; glob[(k + 1) * glob_stride] = __float_as_int(dist); }
     }
     RL_DEV void get(int sp, int* code, float* dist) const {
-        if (sp < lds_levels) { *code = lds[(2 * sp) * lds_stride]; *dist = __int_as_float(lds[(2 * sp + 1) * lds_stride]); }
+        if (LDS_ONLY || sp < lds_levels) { const int2 e = lds[sp * lds_stride]; *code = e.x; *dist = __int_as_float(e.y); }
         else { size_t k = (size_t)(2 * (sp - lds_levels)); *code = glob[k * glob_stride]; *dist = __int_as_float(glob[(k + 1) * glob_stride]); }
     }
 };
+using TravStack = TravStackT<false>;
 
-RL_DEV int stack_pop(const TravStack& st, int& sp, float t_best) {
+template <class Stack>
+RL_DEV int stack_pop(const Stack& st, int& sp, float t_best) {
     while (sp > 0) {
         sp--;
         int code; float dist;
@@ -108,9 +131,9 @@ RL_DEV int stack_pop(const TravStack& st, int& sp, float t_best) {
     return RL_CHILD_NONE;
 }
 
-template <bool ANY_HIT>
+template <bool ANY_HIT, class Stack>
 RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3 o, V3 d, float tnear, float tfar,
-                     Hit& hit, const TravStack& st) {
+                     Hit& hit, const Stack& st) {
     V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
     float dummy;
     int cur = root;

@@ -86,12 +86,14 @@ struct Counters {
     unsigned int pad[2];
 };
 
+static constexpr int kLdsStackLevels = 12;   // stack levels kept in LDS per lane
 // traversal stack configuration (see TravStack)
 struct StackConf { int lds_levels; int* overflow; size_t overflow_stride; };
 
-RL_DEV TravStack make_stack(const StackConf& sc_, unsigned* lds_after_list, size_t global_thread) {
-    TravStack st;
-    st.lds = reinterpret_cast<int*>(lds_after_list) + threadIdx.x;
+template <bool LDS_ONLY = false>
+RL_DEV TravStackT<LDS_ONLY> make_stack(const StackConf& sc_, unsigned* lds_after_list, size_t global_thread) {
+    TravStackT<LDS_ONLY> st;
+    st.lds = reinterpret_cast<int2*>(lds_after_list) + threadIdx.x;
     st.lds_stride = (int)blockDim.x;
     st.lds_levels = sc_.lds_levels;
     st.glob = sc_.overflow ? sc_.overflow + global_thread : nullptr;
@@ -352,8 +354,8 @@ __global__ void __launch_bounds__(256) k_raygen(RenderConst rc, DeviceScene sc, 
 
 // ------------------------------------------------------------------------------------------
 // extend_slot / shadow_slot — Acceleration::trace and Acceleration::visible for one slot.
-template <class PS>
-RL_DEV void extend_slot(const DeviceScene& sc, const SceneRecs& recs, const TravStack& stack, PS& ps) {
+template <class PS, class Stack>
+RL_DEV void extend_slot(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, PS& ps) {
     const unsigned flags = PU(U_FLAGS);
     const bool primary = ((flags >> ST_PREV_SHIFT) & 3u) == PREV_SENSOR;    // camera rays start at Camera::position()
     V3 o = primary ? mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]) : load3(ps, F_OX);
@@ -364,8 +366,8 @@ RL_DEV void extend_slot(const DeviceScene& sc, const SceneRecs& recs, const Trav
     PF(F_T) = hit.t; PF(F_U) = hit.u; PF(F_V) = hit.v;
     PU(U_PRIM) = (unsigned)hit.prim;
 }
-template <class PS>
-RL_DEV void shadow_slot(const DeviceScene& sc, const SceneRecs& recs, const TravStack& stack, PS& ps) {
+template <class PS, class Stack>
+RL_DEV void shadow_slot(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, PS& ps) {
     // Acceleration::visible(p0, p1) (accel.rs:316-343)
     V3 p0 = load3(ps, F_OX), p1 = load3(ps, F_SX);
     V3 d = p1 - p0;
@@ -391,7 +393,7 @@ RL_DEV void trace_kernel_body(const DeviceScene& sc, const Pool& pool, const Sta
     float4* after_scene = LDS_SCENE ? smem + 4 * (sc.n_nodes + sc.n_prims) : smem;
     unsigned* list = reinterpret_cast<unsigned*>(after_scene);
     unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const TravStack stack = make_stack(stc, list + 272, slot);
+    const TravStackT<LDS_SCENE> stack = make_stack<LDS_SCENE>(stc, list + 272, slot);
     const unsigned flags = slot < pool.P ? pool.u[(size_t)U_FLAGS * pool.P + slot] : 0u;
     const unsigned n_live = block_compact((flags & (SHADOW ? ST_SHADOW : ST_RAY)) != 0u, slot, list);
     if (n_live == 0u) return;          // whole tile idle (finished pixels): skip the scene staging too
@@ -690,6 +692,9 @@ __global__ void __launch_bounds__(256) k_shade_sorted(RenderConst rc, DeviceScen
 // (raygen -> extend -> shade -> shadow) with the whole path state in registers (RegState) and the scene +
 // traversal stacks in LDS.  Same functions, same order of operations, same results as the wavefront kernels;
 // what disappears is ~1.4 KB/sample of state traffic through HBM and ~2000 kernel boundaries per render.
+#ifdef RL_STAGE_TIMERS
+__device__ unsigned long long g_stage_timers[16];
+#endif
 template <int MAT, bool MEDIUM, bool LDS_SCENE>
 __global__ void __launch_bounds__(256, RL_FUSED_WAVES) k_path_fused(RenderConst rc, DeviceScene sc, StackConf stc) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
@@ -708,7 +713,7 @@ __global__ void __launch_bounds__(256, RL_FUSED_WAVES) k_path_fused(RenderConst 
     unsigned long long* cold_q = reinterpret_cast<unsigned long long*>(after_scene);
     float* cold_f = reinterpret_cast<float*>(cold_q + 256 * FusedState::kColdQ);
     unsigned* cold_u = reinterpret_cast<unsigned*>(cold_f + 256 * FusedState::kColdF);
-    const TravStack stack = make_stack(stc, cold_u + 256 * FusedState::kColdU, tid);
+    const TravStackT<LDS_SCENE> stack = make_stack<LDS_SCENE>(stc, cold_u + 256 * FusedState::kColdU, tid);
     FusedState ps;
     ps.cold_q = cold_q + threadIdx.x; ps.cold_f = cold_f + threadIdx.x; ps.cold_u = cold_u + threadIdx.x;
 #pragma unroll
@@ -723,14 +728,41 @@ __global__ void __launch_bounds__(256, RL_FUSED_WAVES) k_path_fused(RenderConst 
     PU(U_PRIM) = 0xffffffffu;
     PU(U_FLAGS) = tid < rc.n_items ? (ST_REGEN | ST_FRESH) : ST_FINISHED;
     unsigned n_samples = 0, n_draws = 0, n_vertices = 0, n_shadow = 0, n_ext = 0;
+#ifdef RL_STAGE_TIMERS
+    unsigned long long tm[4] = {0, 0, 0, 0}, ln[5] = {0, 0, 0, 0, 0};
+#define RL_T0 { t0 = __builtin_readcyclecounter(); }
+#define RL_T1(K, COND) { unsigned long long t1 = __builtin_readcyclecounter(); tm[K] += t1 - t0; ln[K] += __popcll(__ballot(COND)); t0 = t1; }
+    unsigned long long t0;
+#else
+#define RL_T0
+#define RL_T1(K, COND)
+#endif
     while (!(PU(U_FLAGS) & ST_FINISHED)) {
+        RL_T0
+#ifdef RL_STAGE_TIMERS
+        ln[4] += 64;
+        const bool c0 = PU(U_FLAGS) & ST_REGEN;
+#endif
         if (PU(U_FLAGS) & ST_REGEN) raygen_slot<false>(rc, sc, ps, n_samples, n_draws);
+        RL_T1(0, c0)
+#ifdef RL_STAGE_TIMERS
+        const bool c1 = PU(U_FLAGS) & ST_RAY;
+#endif
         if (PU(U_FLAGS) & ST_RAY) {
             extend_slot(sc, recs, stack, ps);
+            RL_T1(1, c1)
             shade_slot<MAT, MEDIUM>(rc, sc, ps, PU(U_FLAGS), n_vertices, n_draws, n_shadow, n_ext);
         }
+        RL_T1(2, c1)
+#ifdef RL_STAGE_TIMERS
+        const bool c3 = PU(U_FLAGS) & ST_SHADOW;
+#endif
         if (PU(U_FLAGS) & ST_SHADOW) shadow_slot(sc, recs, stack, ps);
+        RL_T1(3, c3)
     }
+#ifdef RL_STAGE_TIMERS
+    if ((threadIdx.x & 63u) == 0u) { for (int k = 0; k < 4; k++) { atomicAdd(&g_stage_timers[k], tm[k]); atomicAdd(&g_stage_timers[4 + k], ln[k]); } atomicAdd(&g_stage_timers[8], ln[4]); }
+#endif
     {
         const int which[5] = {STAT_SAMPLES, STAT_VERTICES, STAT_DRAWS, STAT_SHADOW_RAYS, STAT_EXT_RAYS};
         const unsigned vals[5] = {n_samples, n_vertices, n_draws, n_shadow, n_ext};
@@ -753,13 +785,15 @@ RL_DEV float mis_weight_power(float pdf_a, float pdf_b) {
     float w = div_rn(pdf_a * pdf_a, pdf_a * pdf_a + pdf_b * pdf_b);
     return finite_f(w) ? w : 0.0f;
 }
-RL_DEV bool trace_closest(const DeviceScene& sc, const SceneRecs& recs, const TravStack& stack, V3 o, V3 d, Hit& hit) {
+template <class Stack>
+RL_DEV bool trace_closest(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, V3 o, V3 d, Hit& hit) {
     hit.t = kF32Max; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
     traverse<false>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
                     o, d, kEps, kF32Max, hit, stack);
     return hit.prim >= 0;
 }
-RL_DEV bool trace_visible(const DeviceScene& sc, const SceneRecs& recs, const TravStack& stack, V3 p0, V3 p1) {
+template <class Stack>
+RL_DEV bool trace_visible(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, V3 p0, V3 p1) {
     V3 d = p1 - p0;
     float len = length(d);
     d = d / len;
@@ -772,8 +806,8 @@ RL_DEV bool trace_visible(const DeviceScene& sc, const SceneRecs& recs, const Tr
                            p0, d, kEps, tfar, hit, stack);
 }
 
-template <int KIND>
-RL_DEV Col mc_compute_pixel(const DeviceScene& sc, const SceneRecs& recs, const TravStack& stack, const McConst& mp, unsigned px, unsigned py, Rng& rng,
+template <int KIND, class Stack>
+RL_DEV Col mc_compute_pixel(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, const McConst& mp, unsigned px, unsigned py, Rng& rng,
                             unsigned& n_draws, unsigned& n_ext, unsigned& n_shadow, unsigned& n_vertices) {
     float u = (float)px + rng_next_f32(rng);
     float v = (float)py + rng_next_f32(rng);
@@ -865,7 +899,7 @@ __global__ void __launch_bounds__(256) k_pixel_mc(RenderConst rc, DeviceScene sc
         recs.tris = reinterpret_cast<const float4*>(sc.tris);
     }
     const unsigned item = blockIdx.x * blockDim.x + threadIdx.x;
-    const TravStack stack = make_stack(stc, reinterpret_cast<unsigned*>(after_scene), item);
+    const TravStackT<LDS_SCENE> stack = make_stack<LDS_SCENE>(stc, reinterpret_cast<unsigned*>(after_scene), item);
     unsigned n_samples = 0, n_draws = 0, n_ext = 0, n_shadow = 0, n_vertices = 0;
     if (item < rc.n_items) {
         const float inv = rc.inv_spp;
@@ -1084,7 +1118,8 @@ extern "C" int rl_context_create(const rl_scene* scene, int device, rl_context**
         for (const Material& m : flat.materials) if (m.type != ctx->bsdf_type) ctx->single_bsdf = false;
         // stage the scene in LDS when nodes + triangles are small (<= 48 KiB leaves room for the stacks)
         ctx->scene_lds_bytes = 64 * ((size_t)ds.n_nodes + ds.n_prims);
-        ctx->lds_scene = ctx->scene_lds_bytes <= 48 * 1024;
+        // LDS-staged scenes also keep their whole traversal stack in LDS (TravStackT<true>)
+        ctx->lds_scene = ctx->scene_lds_bytes <= 48 * 1024 && ds.stack_depth <= (uint32_t)kLdsStackLevels;
         if (hipMalloc((void**)&ctx->d_counters, sizeof(Counters)) != hipSuccess) { rl_set_error("hipMalloc counters"); rc = RL_ERR_HIP; break; }
         if (hipHostMalloc((void**)&ctx->h_counters, sizeof(Counters)) != hipSuccess) { rl_set_error("hipHostMalloc counters"); rc = RL_ERR_HIP; break; }
     } while (0);
@@ -1116,7 +1151,6 @@ static int ensure(T** p, size_t* cap, size_t n) {
     return RL_OK;
 }
 
-static constexpr int kLdsStackLevels = 12;
 static int lds_levels_of(const rl_context* ctx) { return std::min<int>((int)ctx->ds.stack_depth, kLdsStackLevels); }
 static size_t traversal_lds_bytes(const rl_context* ctx, bool lds_scene, unsigned block, bool with_list) {
     size_t stack = (size_t)2 * lds_levels_of(ctx) * block * sizeof(int);
@@ -1306,6 +1340,16 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         if (timing) hipEventRecord(ctx->events[1], st);
         HIP_OK(hipStreamSynchronize(st));
         if (timing) { float t = 0.0f; HIP_OK(hipEventElapsedTime(&t, ctx->events[0], ctx->events[1])); ms_fused = t; }
+#ifdef RL_STAGE_TIMERS
+        {   // dev-only build: per-stage cycle shares and active-lane fractions of the fused loop
+            unsigned long long h[16];
+            hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stage_timers), sizeof(h));
+            const double tot = (double)(h[0] + h[1] + h[2] + h[3]);
+            const char* names[4] = {"raygen", "extend", "shade", "shadow"};
+            for (int k = 0; k < 4; k++) std::fprintf(stderr, "[stage] %-7s cycles %5.1f %%  lanes %5.1f %%\n", names[k], 100.0 * h[k] / tot, 100.0 * h[4 + k] / (double)h[8]);
+            std::memset(h, 0, sizeof(h)); hipMemcpyToSymbol(HIP_SYMBOL(g_stage_timers), h, sizeof(h));
+        }
+#endif
         launches += 1;
         iterations = 1;
     } else for (;;) {
