@@ -196,7 +196,11 @@ typedef struct rl_path_params {
      * 2 = persistent fused kernel (same stages in one launch, state in registers; single-BSDF scenes).
      * Does not change results. */
     uint32_t pipeline;
-    uint32_t reserved[2];
+    /* per-sample stream mode: lanes working on one pixel at a time (sample s of a pixel runs on lane s % sample_split; the
+     * per-sample radiances are parked in HBM and added up in sample order afterwards, so the sum keeps the reference's
+     * association). 0 = auto, 1 = one lane per pixel. Does not change results. */
+    uint32_t sample_split;
+    uint32_t reserved[1];
 } rl_path_params;
 
 void rl_path_params_default(rl_path_params* params);   /* CLI defaults: examples/cli.rs:53-61,167-168 */

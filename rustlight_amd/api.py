@@ -218,7 +218,7 @@ class Scene:
 
 
 def path_params(spp=1, min_depth=0, max_depth=None, rr_depth=0, strategy=STRATEGY_ALL, single_scattering=False,
-                stream_mode=STREAM_PER_SAMPLE, seed_variant=0, shard_index=0, shard_count=1, pool_slots=0, pipeline=0) -> abi.PathParams:
+                stream_mode=STREAM_PER_SAMPLE, seed_variant=0, shard_index=0, shard_count=1, pool_slots=0, pipeline=0, sample_split=0) -> abi.PathParams:
     p = abi.PathParams()
     lib().rl_path_params_default(C.byref(p))
     p.spp = spp
@@ -232,6 +232,7 @@ def path_params(spp=1, min_depth=0, max_depth=None, rr_depth=0, strategy=STRATEG
     p.shard_index, p.shard_count = shard_index, shard_count
     p.pool_slots = pool_slots
     p.pipeline = pipeline
+    p.sample_split = sample_split
     return p
 
 

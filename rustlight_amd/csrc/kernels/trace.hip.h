@@ -17,7 +17,7 @@
 
 namespace rl {
 
-struct Hit { float t, u, v; int prim; };
+struct Hit { float t, u, v; int prim; int steps = 0, tris = 0; };   // steps / tris: dev-only traversal statistics (dead code unless read)
 
 // AABB::intersect (src/structure.rs:849-869) with 1/d hoisted out of the loop, restated without its per-axis
 // early exit and compare/select chains — same value, same verdict, a third fewer VALU instructions:
@@ -143,6 +143,7 @@ RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3
     while (cur != RL_CHILD_NONE) {
         // ---- phase 1: inner nodes
         while (cur >= 0) {
+            hit.steps++;
             const float4* q = recs.nodes + 4 * cur;
             float4 a = q[0], b = q[1], c = q[2], e = q[3];
             V3 llo = mk3(a.x, a.y, a.z), lhi = mk3(a.w, b.x, b.y);
@@ -162,6 +163,7 @@ RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3
             unsigned int code = (unsigned int)(~cur);
             int first = (int)(code >> 2), count = (int)(code & 3u);
             for (int k = 0; k < count; k++) {
+                hit.tris++;
                 const float4* q = recs.tris + 4 * (first + k);
                 if (tri_test(q[0], q[1], q[2], q[3], o, d, hit, first + k)) {
                     found = true;

@@ -87,6 +87,7 @@ struct Counters {
 };
 
 static constexpr int kLdsStackLevels = 12;   // stack levels kept in LDS per lane
+static constexpr size_t kSampleBufBudget = (size_t)16 << 30;   // bytes of HBM the per-sample parking buffer may take
 // traversal stack configuration (see TravStack)
 struct StackConf { int lds_levels; int* overflow; size_t overflow_stride; };
 
@@ -112,6 +113,8 @@ struct RenderConst {
     // image / work decomposition
     unsigned W, H, nby;
     unsigned n_items;
+    unsigned split;                     // per-sample mode: lanes per pixel (sample s of a pixel runs on lane s % split)
+    float* sample_buf;                  // split > 1: [spp][n_items / split][3] per-sample radiance, folded in order by k_fold_samples
     const unsigned* owned_blocks;       // block ids of this shard, in creation order
     const unsigned* block_item_base;    // per owned block: first pixel item (per-sample mode)
     unsigned n_owned;
@@ -274,7 +277,17 @@ RL_DEV void raygen_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, un
     bool need_item = fresh;
     unsigned bx = 0, by = 0, bw = 1, bh = 1;
     if (rc.stream_mode == RL_STREAM_REFERENCE_ORDER && item < rc.n_items) block_geometry(rc, rc.owned_blocks[item], &bx, &by, &bw, &bh);
-    if (!fresh) {
+    const unsigned split = rc.stream_mode == RL_STREAM_PER_SAMPLE ? rc.split : 1u;
+    const unsigned pitem = split > 1u ? item / split : item;         // pixel item of this lane
+    if (!fresh && split > 1u) {
+        // sample-parallel pixels: this lane owns samples s, s + split, ...; each sample's radiance is parked in
+        // sample_buf[s][pixel item] and k_fold_samples adds them up in sample order, as mod.rs:431 does
+        const Col L = loadc(ps, F_LR);
+        float* dst = rc.sample_buf + 3 * ((size_t)s * (rc.n_items / split) + pitem);
+        dst[0] = L.r; dst[1] = L.g; dst[2] = L.b;
+        s += split;
+        if (s >= rc.spp) need_item = true;
+    } else if (!fresh) {
         // im_block.accumulate(.., c, "primal") in sample order (mod.rs:431)
         acc = acc + loadc(ps, F_LR);
         s++;
@@ -298,7 +311,9 @@ RL_DEV void raygen_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, un
         }
         cursor = 0;
         if (rc.stream_mode == RL_STREAM_PER_SAMPLE) {
-            Rng item_rng = rng_seed(rc.item_seed[item], rc.seed_variant);   // pixel sampler = block_sampler.clone_box()
+            const unsigned pi = split > 1u ? item / split : item;
+            Rng item_rng = rng_seed(rc.item_seed[pi], rc.seed_variant);     // pixel sampler = block_sampler.clone_box()
+            if (split > 1u) { s = item % split; for (unsigned k = 0; k < s; k++) rng_next_u64(item_rng); }   // forks of the samples before ours
             rng = rng_seed(rng_next_u64(item_rng), rc.seed_variant);        // sample sampler = pixel_sampler.clone_box()
             store_rng(ps, Q_I0, item_rng);
         } else {
@@ -309,13 +324,14 @@ RL_DEV void raygen_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, un
         PU(U_ITEM) = item;
     } else if (rc.stream_mode == RL_STREAM_PER_SAMPLE) {
         Rng item_rng = load_rng(ps, Q_I0);
+        for (unsigned k = 1; k < split; k++) rng_next_u64(item_rng);        // the forks taken by the other lanes of this pixel
         rng = rng_seed(rng_next_u64(item_rng), rc.seed_variant);
         store_rng(ps, Q_I0, item_rng);
     } else {
         rng = load_rng(ps, Q_R0);
     }
     unsigned px, py;
-    if (rc.stream_mode == RL_STREAM_PER_SAMPLE) { unsigned pix = rc.item_pixel[item]; px = pix % rc.W; py = pix / rc.W; }
+    if (rc.stream_mode == RL_STREAM_PER_SAMPLE) { unsigned pix = rc.item_pixel[split > 1u ? item / split : item]; px = pix % rc.W; py = pix / rc.W; }
     else { px = bx + cursor % bw; py = by + cursor / bw; }
     // Path::from_sensor: uv = (ix + next(), iy + next())
     float u = (float)px + rng_next_f32(rng);
@@ -352,10 +368,31 @@ __global__ void __launch_bounds__(256) k_raygen(RenderConst rc, DeviceScene sc, 
     { const int which[2] = {STAT_SAMPLES, STAT_DRAWS}; const unsigned vals[2] = {n_samples, n_draws}; block_stats<2>(rc.partials, which, vals); }
 }
 
+// k_fold_samples — sample-parallel pixels (split > 1): add the parked per-sample radiances of each pixel in sample
+// order and scale by 1 / spp, i.e. exactly the accumulate / scale sequence of compute_mc (mod.rs:431-436).
+__global__ void __launch_bounds__(256) k_fold_samples(RenderConst rc) {
+    const unsigned n_pix = rc.n_items / rc.split;
+    const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pix) return;
+    Col acc = czero();
+    for (unsigned s = 0; s < rc.spp; s++) {
+        const float* src = rc.sample_buf + 3 * ((size_t)s * n_pix + p);
+        acc = acc + mkc(src[0], src[1], src[2]);
+    }
+    const Col px = scale_unguarded(acc, rc.inv_spp);
+    const size_t pix = rc.item_pixel[p];
+    rc.out[3 * pix] = px.r; rc.out[3 * pix + 1] = px.g; rc.out[3 * pix + 2] = px.b;
+}
+
+#ifdef RL_TRAV_STATS
+// dev-only: traversal statistics of k_extend, totals over the render: [0] rays, [1] node steps, [2] triangle tests,
+// [3] sum over waves of 64 * (max node steps in the wave) = what the wave pays, [4] waves, [5] rays with zero steps
+__device__ unsigned long long g_trav_stats[8];
+#endif
 // ------------------------------------------------------------------------------------------
 // extend_slot / shadow_slot — Acceleration::trace and Acceleration::visible for one slot.
 template <class PS, class Stack>
-RL_DEV void extend_slot(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, PS& ps) {
+RL_DEV void extend_slot(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, PS& ps, int* dbg = nullptr) {
     const unsigned flags = PU(U_FLAGS);
     const bool primary = ((flags >> ST_PREV_SHIFT) & 3u) == PREV_SENSOR;    // camera rays start at Camera::position()
     V3 o = primary ? mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]) : load3(ps, F_OX);
@@ -365,6 +402,7 @@ RL_DEV void extend_slot(const DeviceScene& sc, const SceneRecs& recs, const Stac
                     o, d, kEps, kF32Max, hit, stack);
     PF(F_T) = hit.t; PF(F_U) = hit.u; PF(F_V) = hit.v;
     PU(U_PRIM) = (unsigned)hit.prim;
+    if (dbg) { dbg[0] = hit.steps; dbg[1] = hit.tris; }
 }
 template <class PS, class Stack>
 RL_DEV void shadow_slot(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, PS& ps) {
@@ -405,11 +443,26 @@ RL_DEV void trace_kernel_body(const DeviceScene& sc, const Pool& pool, const Sta
         recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
         recs.tris = reinterpret_cast<const float4*>(sc.tris);
     }
+#ifdef RL_TRAV_STATS
+    int dbg[2] = {-1, 0};
+    if (threadIdx.x < n_live) {
+        PoolState ps{pool, list[threadIdx.x]};
+        if (SHADOW) shadow_slot(sc, recs, stack, ps);
+        else extend_slot(sc, recs, stack, ps, dbg);
+    }
+    if (!SHADOW) {
+        int mx = dbg[0];
+        for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+        if (dbg[0] >= 0) { atomicAdd(&g_trav_stats[0], 1ull); atomicAdd(&g_trav_stats[1], (unsigned long long)dbg[0]); atomicAdd(&g_trav_stats[2], (unsigned long long)dbg[1]); if (dbg[0] == 0) atomicAdd(&g_trav_stats[5], 1ull); }
+        if ((threadIdx.x & 63u) == 0u && mx >= 0) { atomicAdd(&g_trav_stats[3], 64ull * (unsigned long long)mx); atomicAdd(&g_trav_stats[4], 1ull); }
+    }
+#else
     if (threadIdx.x < n_live) {
         PoolState ps{pool, list[threadIdx.x]};
         if (SHADOW) shadow_slot(sc, recs, stack, ps);
         else extend_slot(sc, recs, stack, ps);
     }
+#endif
 }
 
 template <bool LDS_SCENE>
@@ -1040,6 +1093,7 @@ struct rl_context {
     Counters* h_counters = nullptr;   // pinned
     unsigned long long* d_partials = nullptr; size_t partials_capacity = 0;
     int* d_overflow = nullptr; size_t overflow_capacity = 0;
+    float* d_sample_buf = nullptr; size_t sample_buf_capacity = 0;   // sample-parallel pixels: [spp][pixel item][3]
     std::vector<hipEvent_t> events;
     BvhBuild bvh_dump;                // kept for rl_debug_bvh
 };
@@ -1133,7 +1187,7 @@ extern "C" void rl_context_destroy(rl_context* ctx) {
     hipSetDevice(ctx->device);
     for (void* p : ctx->allocs) hipFree(p);
     void* scratch[] = {ctx->pool.f, ctx->pool.u, ctx->pool.q, ctx->d_owned, ctx->d_item_base, ctx->d_block_seeds, ctx->d_item_seed,
-                       ctx->d_item_pixel, ctx->d_queues, ctx->d_qcounts, ctx->d_out, ctx->d_counters, ctx->d_partials, ctx->d_overflow};
+                       ctx->d_item_pixel, ctx->d_queues, ctx->d_qcounts, ctx->d_out, ctx->d_counters, ctx->d_partials, ctx->d_overflow, ctx->d_sample_buf};
     for (void* p : scratch) if (p) hipFree(p);
     if (ctx->h_counters) hipHostFree(ctx->h_counters);
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
@@ -1233,12 +1287,25 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         n_pixels += bw * bh;
     }
     const bool per_sample = params->stream_mode == RL_STREAM_PER_SAMPLE;
-    const unsigned n_items = per_sample ? n_pixels : (unsigned)owned.size();
     // pipeline: 1 = wavefront stage kernels, 2 = persistent fused kernel (single-BSDF scenes), 0 = auto
     if (params->pipeline > 2) return RL_ERR_INVALID_ARGUMENT;
     if (params->pipeline == 2 && !ctx->single_bsdf) { rl_set_error("the fused pipeline needs a scene with a single BSDF type"); return RL_ERR_UNSUPPORTED; }
     const bool fused = params->pipeline == 2 || (params->pipeline == 0 && ctx->single_bsdf && per_sample && params->pool_slots == 0);
-    unsigned P = params->pool_slots ? params->pool_slots : std::min<unsigned>(n_items, 4u << 20);
+    // sample-parallel pixels: `split` lanes per pixel, per-sample radiances parked in HBM ([spp][pixel][3] floats) and folded
+    // in order.  Auto: scenes that traverse out of L2 / HBM want ~8 M paths in flight per wavefront launch (measured on the
+    // 508 k-triangle living-room scene at 1080p: 1 lane/pixel 935 ms, 4 lanes 787 ms, 8 lanes 836 ms); LDS-staged scenes and
+    // the persistent kernel are VALU-bound and only pay for the extra state, so they stay at one lane per pixel.
+    // The parking buffer is capped (kSampleBufBudget), beyond it one lane per pixel.
+    unsigned split = 1;
+    if (per_sample && n_pixels > 0) {
+        const unsigned want = params->sample_split ? params->sample_split
+                            : ((fused || ctx->lds_scene) ? 1u : std::max(1u, (8u << 20) / std::max(1u, n_pixels)));
+        split = std::max(1u, std::min(want, params->spp));
+        if ((size_t)n_pixels * params->spp * 3 * sizeof(float) > kSampleBufBudget) split = 1;
+        while (split > 1 && (size_t)n_pixels * split > (size_t)0x7fffff00u) split--;
+    }
+    const unsigned n_items = per_sample ? n_pixels * split : (unsigned)owned.size();
+    unsigned P = params->pool_slots ? params->pool_slots : std::min<unsigned>(n_items, 16u << 20);
     P = std::max(256u, (P + 255u) / 256u * 256u);
     if (fused) P = std::max(256u, (n_items + 255u) / 256u * 256u);   // one lane per item; no HBM pool is allocated
 
@@ -1260,6 +1327,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         HIP_OK(hipMalloc((void**)&ctx->pool.q, (size_t)Q_COUNT * P * sizeof(unsigned long long)));
         ctx->pool_capacity = P;
     }
+    if (split > 1 && (rcode = ensure(&ctx->d_sample_buf, &ctx->sample_buf_capacity, (size_t)n_pixels * params->spp * 3)) != RL_OK) return rcode;
     Pool pool = ctx->pool;
     pool.P = P;
     const bool use_sort = !ctx->single_bsdf;
@@ -1291,6 +1359,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     rc.inv_spp = 1.0f / (float)params->spp;
     rc.W = W; rc.H = H; rc.nby = (unsigned)nby;
     rc.n_items = n_items;
+    rc.split = split; rc.sample_buf = ctx->d_sample_buf;
     rc.owned_blocks = ctx->d_owned; rc.block_item_base = ctx->d_item_base; rc.n_owned = (unsigned)owned.size();
     rc.block_seeds = ctx->d_block_seeds;
     rc.item_seed = ctx->d_item_seed; rc.item_pixel = ctx->d_item_pixel;
@@ -1382,7 +1451,18 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         }
         if (iterations > (uint64_t)1 << 28) { rl_set_error("render did not terminate"); return RL_ERR_HIP; }
     }
+#ifdef RL_TRAV_STATS
+    if (!fused) {
+        unsigned long long h[8];
+        HIP_OK(hipStreamSynchronize(st));
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trav_stats), sizeof(h));
+        std::fprintf(stderr, "[trav] rays %llu (zero-step %.1f %%)  steps/ray %.1f  tris/ray %.1f  waves %llu  lanes/wave %.1f  paid steps/ray %.1f  step utilisation %.1f %%\n",
+                     h[0], 100.0 * h[5] / (double)h[0], (double)h[1] / h[0], (double)h[2] / h[0], h[4], (double)h[0] / h[4], (double)h[3] / h[0], 100.0 * h[1] / (double)h[3]);
+        std::memset(h, 0, sizeof(h)); hipMemcpyToSymbol(HIP_SYMBOL(g_trav_stats), h, sizeof(h));
+    }
+#endif
     // one more raygen pass is never needed: `active` reaches 0 inside k_raygen after the last fold.
+    if (split > 1) { hipLaunchKernelGGL(k_fold_samples, dim3((n_pixels + 255) / 256), block, 0, st, rc); launches += 1; }
     if (!out_is_device) HIP_OK(hipMemcpyAsync(out_rgb, d_out, (size_t)3 * W * H * sizeof(float), hipMemcpyDeviceToHost, st));
     std::vector<unsigned long long> partials(n_partial_rows * STAT_COUNT);
     HIP_OK(hipMemcpyAsync(partials.data(), ctx->d_partials, partials.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -1460,6 +1540,7 @@ static int render_mc(rl_context* ctx, int kind, const rl_mc_params* params, cons
     rc.inv_spp = 1.0f / (float)params->spp;
     rc.W = W; rc.H = H; rc.nby = (unsigned)nby;
     rc.n_items = n_items;
+    rc.split = 1; rc.sample_buf = nullptr;
     rc.owned_blocks = ctx->d_owned; rc.block_item_base = ctx->d_item_base; rc.n_owned = (unsigned)owned.size();
     rc.block_seeds = ctx->d_block_seeds;
     rc.item_seed = ctx->d_item_seed; rc.item_pixel = ctx->d_item_pixel;

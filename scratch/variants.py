@@ -33,11 +33,12 @@ def run_one(libpath, scene, pipeline, spp):
     W, H = 1920, 1080
     sd = {"cbox": lambda: scenes.cbox(W, H), "cbox_medium": lambda: scenes.cbox_medium(W, H, 0.5), "living_room": lambda: scenes.living_room(W, H)}[scene]()
     ctx = api.Context(api.Scene(sd), 0); seeds = api.IndependentSampler(0).block_seeds(W, H)
-    best = 1e9
-    for r in range(3):
-        t = time.perf_counter(); img, st = ctx.render(seeds, api.path_params(spp=spp, pipeline=pipeline)); best = min(best, time.perf_counter() - t)
     import zlib
-    print(f"{os.path.basename(libpath):28s} {scene} pl{pipeline} {best*1e3:8.1f} ms {W*H*spp/best/1e6:8.0f} Msamples/s crc {zlib.crc32(img.tobytes()):08x}", flush=True)
+    for split in [int(x) for x in os.environ.get("SPLITS", "0").split(",")]:
+        best = 1e9
+        for r in range(3):
+            t = time.perf_counter(); img, st = ctx.render(seeds, api.path_params(spp=spp, pipeline=pipeline, sample_split=split)); best = min(best, time.perf_counter() - t)
+        print(f"{os.path.basename(libpath):28s} {scene} pl{pipeline} split{split} {best*1e3:8.1f} ms {W*H*spp/best/1e6:8.0f} Msamples/s iters {st['iterations']} crc {zlib.crc32(img.tobytes()):08x}", flush=True)
 
 if __name__ == "__main__":
     if sys.argv[1] == "build": build(sys.argv[2:])

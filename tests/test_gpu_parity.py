@@ -84,7 +84,7 @@ def test_visible_batch_matches_oracle(built, cbox64, ctx_cbox, orc_cbox64):
 def _render_pair(sd, ctx=None, osc=None, seed=0, **kw):
     ctx = ctx or api.Context(api.Scene(sd), 0)
     osc = osc or orc.Scene(sd)
-    okw = {k: v for k, v in kw.items() if k not in ("pool_slots", "pipeline")}
+    okw = {k: v for k, v in kw.items() if k not in ("pool_slots", "pipeline", "sample_split")}
     img, st = ctx.render(api.IndependentSampler(seed, kw.get("seed_variant", 0)).block_seeds(sd.width, sd.height), api.path_params(**kw))
     ref_fwd, ost = osc.render(master_seed=seed, eval_order=1, **okw)
     ref_rec, _ = osc.render(master_seed=seed, eval_order=0, **okw)
@@ -128,6 +128,17 @@ def test_ragged_image_and_pool_smaller_than_image(built):
     a = _render_pair(sd, ctx, osc, spp=3, pool_slots=256)[0]
     b = _render_pair(sd, ctx, osc, spp=3, pool_slots=0)[0]
     np.testing.assert_array_equal(a, b)       # launch geometry never changes results
+
+
+@pytest.mark.parametrize("pipeline", [api.PIPELINE_WAVEFRONT, api.PIPELINE_FUSED])
+@pytest.mark.parametrize("split", [2, 3, 8, 64])
+def test_sample_parallel_pixels_keep_the_sum_order(built, split, pipeline):
+    """`sample_split` lanes per pixel: samples run concurrently, their radiances are parked and added in sample order, so the
+    image (and every counter) is the one-lane-per-pixel image bit for bit; spp not a multiple of the split, split > spp,
+    ragged blocks and a pool smaller than the item count included."""
+    sd = scenes.cbox(70, 41)
+    out = _render_pair(sd, spp=7, pipeline=pipeline, sample_split=split, pool_slots=0 if pipeline == api.PIPELINE_FUSED else 1024)
+    _assert_parity(*out)
 
 
 def test_shards_sum_to_full_image(built, cbox64, ctx_cbox):
