@@ -129,8 +129,12 @@ int rl_scene_add_point_light(rl_scene* scene, const float position[3], const flo
 int rl_scene_add_directional_light(rl_scene* scene, const float direction[3], const float intensity[3]);
 /* scene.emitter_environment = EnvironmentLight { luminance: EnvironmentLightColor::Constant(rgb) }
  * (src/emitter.rs:300-568, src/scene_loader.rs:205-224).  Not combinable with a medium (the reference
- * asserts, src/paths/edge.rs:94); lat-long texture environments are not supported yet. */
+ * asserts, src/paths/edge.rs:94). */
 int rl_scene_set_environment(rl_scene* scene, const float rgb[3]);
+/* EnvironmentLightColor::Texture { image, image_cdf } = EnvironmentLightColor::new_texture(image) (src/emitter.rs:340-353,
+ * src/scene_loader.rs:259-271): lat-long image, z up, w x h RGB f32 row-major (row 0 = theta 0), importance sampled by
+ * luminance x sin(theta) through a Distribution2D (src/math.rs:489-532); nearest-texel lookups as in the reference. */
+int rl_scene_set_environment_map(rl_scene* scene, uint32_t w, uint32_t h, const float* rgb);
 
 /* Scene::build_emitters(false) (src/scene.rs:53-123): scene bounding sphere, emitter list
  * (emissive meshes in mesh order), CDF over flux().channel_max().  The ATS light tree
@@ -282,6 +286,9 @@ int rl_trace_batch(rl_context* ctx, size_t n, const float* origins, const float*
 int rl_visible_batch(rl_context* ctx, size_t n, const float* p0, const float* p1,
                      uint8_t* visible_out);
 
+/* Bitmap::read_pfm (src/structure.rs:563-607): colour PFM, little endian ("-1.0"), rows stored bottom-up and returned
+ * top-down, RGB f32.  `rgb == NULL` only reports the size; otherwise `capacity_floats >= 3 * w * h`. */
+int rl_load_pfm(const char* path, uint32_t* width, uint32_t* height, float* rgb, size_t capacity_floats);
 /* Bitmap::save_pfm (src/structure.rs:547-560): bottom-up rows, |value|, little-endian, "-1.0" scale. */
 int rl_save_pfm(const char* path, const float* rgb, uint32_t width, uint32_t height);
 

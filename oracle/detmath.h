@@ -217,11 +217,20 @@ static inline float atan2f_det(float y, float x) {
     }
     return (float)r;
 }
+// sqrt on f64 from the correctly rounded f32 square root and two Newton steps (+,-,*,/ only, so the GPU's f64 sqrt
+// rounding never enters)
+static inline double sqrt_d(double a) {
+    if (!(a > 0.0)) return 0.0;
+    double s = (double)std::sqrt((float)a);
+    s = 0.5 * (s + a / s);
+    s = 0.5 * (s + a / s);
+    return s;
+}
 static inline float acosf_det(float x) {
     if (x != x) return x;
     if (x > 1.0f || x < -1.0f) return (float)bits_to_f64(0x7ff8000000000000ull);
     double xd = x;
-    double s = std::sqrt((1.0 - xd) * (1.0 + xd));
+    double s = sqrt_d((1.0 - xd) * (1.0 + xd));
     // acos(x) = atan2(sqrt(1-x^2), x)
     const double PI = 3.14159265358979311600;
     double r;

@@ -70,6 +70,8 @@ def lib():
         L.orc_scene_add_point_light.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_scene_add_directional_light.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_scene_set_environment.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.orc_env_probe.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_scene_set_environment_map.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
         L.orc_rng_seed.argtypes = [C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
         L.orc_rng_next_u64.argtypes = [C.POINTER(C.c_uint64)]
         L.orc_rng_next_u64.restype = C.c_uint64
@@ -171,7 +173,15 @@ class Scene:
         if sd.environment is not None:
             e = np.asarray(sd.environment, np.float32)
             L.orc_scene_set_environment(self.h, abi.fptr(e))
+        if sd.environment_map is not None:
+            em = np.ascontiguousarray(sd.environment_map, np.float32)
+            L.orc_scene_set_environment_map(self.h, em.shape[1], em.shape[0], abi.fptr(em))
         L.orc_scene_build(self.h)
+
+    def env_probe(self, kind, values):
+        a = np.asarray(values, np.float32); out = np.zeros(8, np.float32)
+        assert lib().orc_env_probe(self.h, kind, abi.fptr(a), abi.fptr(out)) == 0
+        return out
 
     def __del__(self):
         try:

@@ -92,6 +92,7 @@ struct Color {
     static Color value(float v) { return {v, v, v}; }
     bool is_zero() const { return r == 0.0f && g == 0.0f && b == 0.0f; }
     float channel_max() const { return rmax(r, rmax(g, b)); }
+    float luminance() const { return r * 0.212671f + g * 0.715160f + b * 0.072169f; }   // structure.rs:173-176
     float avg() const { return (r + g + b) / 3.0f; }
     float get(int c) const { return c == 0 ? r : (c == 1 ? g : b); }
     Color safe_sqrt() const { return {std::sqrt(rmax(r, 0.f)), std::sqrt(rmax(g, 0.f)), std::sqrt(rmax(b, 0.f))}; }
@@ -271,6 +272,14 @@ struct Distribution1D {
     }
     float pdf(size_t i) const { return cdf[i + 1] - cdf[i]; }
     float total() const { return func_int * (float)(cdf.size() - 1); }
+    // sample_continuous (math.rs:461-478): index + position inside the bin, in [0, n]
+    float sample_continuous(float v) const {
+        size_t i = sample_discrete(v);
+        float dv = v - cdf[i];
+        float p = pdf(i);
+        if (p > 0.0f) dv = dv / p;
+        return (float)i + dv;
+    }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -279,6 +288,83 @@ struct Bitmap { uint32_t w = 0, h = 0; std::vector<Color> colors; };
 static inline float modulo1(float a) { return std::fmod(std::fmod(a, 1.0f) + 1.0f, 1.0f); }  // tools.rs:32-45
 static inline size_t as_usize(float f) { if (!(f > 0.0f)) return 0; if (f >= 1.8446744e19f) return SIZE_MAX; return (size_t)f; }
 static inline int32_t as_i32(float f) { if (f != f) return 0; if (f >= 2147483648.0f) return INT32_MAX; if (f <= -2147483648.0f) return INT32_MIN; return (int32_t)f; }
+
+static inline float powi(float a, int b) { float r = 1.0f; for (;;) { if (b & 1) r *= a; b /= 2; if (b == 0) break; a *= a; } return r; }
+static inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }   // lib.rs:59-67
+static const float ONE_MINUS_EPSILON = 0.9999999403953552f;                                            // lib.rs:52
+
+// Distribution2D (src/math.rs:489-532)
+struct Distribution2D {
+    Distribution1D marginal;
+    std::vector<Distribution1D> conditionals;
+    static Distribution2D from_bitmap(const Bitmap& image) {
+        Distribution2D d;
+        std::vector<float> marg;
+        for (uint32_t y = 0; y < image.h; y++) {
+            std::vector<float> row;
+            for (uint32_t x = 0; x < image.w; x++) row.push_back(image.colors[(size_t)y * image.w + x].luminance());
+            d.conditionals.push_back(Distribution1D::normalize(row));
+            marg.push_back(d.conditionals.back().func_int);
+        }
+        d.marginal = Distribution1D::normalize(marg);
+        return d;
+    }
+    V2 sample_continuous(V2 uv) const {
+        float y = marginal.sample_continuous(uv.y);
+        float x = conditionals[as_usize(y)].sample_continuous(uv.x);
+        return {x, y};
+    }
+    float pdf(size_t x, size_t y) const { return conditionals[y].func[x] / marginal.func_int; }
+};
+
+// EnvironmentLightColor::Texture (src/emitter.rs:300-425): lat-long image, z up, importance sampled by luminance * sin(theta)
+struct EnvTexture {
+    Bitmap image;
+    Distribution2D cdf;
+    void build() {   // new_texture (emitter.rs:340-353)
+        Bitmap image_pdf = image;
+        for (uint32_t y = 0; y < image.h; y++) {
+            float w = detmath::sinf_det(((float)y + 0.5f) * PI_F / (float)image.h);
+            for (uint32_t x = 0; x < image.w; x++) { Color& c = image_pdf.colors[(size_t)y * image.w + x]; c.r *= w; c.g *= w; c.b *= w; }
+        }
+        cdf = Distribution2D::from_bitmap(image_pdf);
+    }
+    static V2 to_spherical_coordinates(V3 d) {   // emitter.rs:320-338
+        float p = detmath::atan2f_det(d.y, d.x);
+        if (p < 0.0f) p = p + 2.0f * PI_F;
+        V2 uv{p * FRAC_1_PI * 0.5f, detmath::acosf_det(clampf(d.z, -1.0f, 1.0f)) * FRAC_1_PI};
+        uv.x = clampf(uv.x, 0.0f, ONE_MINUS_EPSILON);
+        uv.y = clampf(uv.y, 0.0f, ONE_MINUS_EPSILON);
+        return uv;
+    }
+    Color pixel_uv(V2 uv) const {   // Bitmap::pixel_uv (structure.rs:434-453)
+        float ux = modulo1(uv.x), uy = modulo1(uv.y);
+        size_t x = as_usize(ux * (float)image.w), y = as_usize(uy * (float)image.h);
+        size_t i = (size_t)image.w * y + x;
+        return i >= image.colors.size() ? Color::zero() : image.colors[i];
+    }
+    void sample_direction(V2 u, V3* d, Color* value, float* pdf) const {   // emitter.rs:355-394
+        V2 uv = cdf.sample_continuous(u);
+        uv.x = clampf(uv.x, 0.0f, (float)image.w - 1.0f);
+        uv.y = clampf(uv.y, 0.0f, (float)image.h - 1.0f);
+        size_t px = as_usize(uv.x), py = as_usize(uv.y);
+        Color v = image.colors[py * image.w + px];
+        float p = cdf.pdf(px, py);
+        float sp, cp, st, ct;
+        detmath::sincosf_det((2.0f * PI_F / (float)image.w) * uv.x, &sp, &cp);
+        detmath::sincosf_det((PI_F / (float)image.h) * uv.y, &st, &ct);
+        *d = {st * cp, st * sp, ct};
+        if (st == 0.0f) { *value = Color::zero(); *pdf = 0.0f; }
+        else { *value = v; *pdf = p / (2.0f * powi(PI_F, 2) * st); }
+    }
+    Color eval(V3 d) const { return pixel_uv(to_spherical_coordinates(d)); }
+    float pdf(V3 d) const {   // emitter.rs:407-424
+        V2 uv = to_spherical_coordinates(d);
+        float p = cdf.pdf(as_usize(uv.x * (float)image.w), as_usize(uv.y * (float)image.h));
+        float st = detmath::sinf_det(PI_F * uv.y);
+        return st == 0.0f ? 0.0f : p / (2.0f * powi(PI_F, 2) * st);
+    }
+};
 
 struct Scene;
 struct BSDFColor {
@@ -343,7 +429,6 @@ static inline bool check_reflection_condition(V3 wi, V3 wo) {
     return std::fabs(wi.z * wo.z - wi.x * wo.x - wi.y * wo.y - 1.0f) < 0.0001f;
 }
 // f32::powi = llvm.powi.f32 -> compiler-rt __powisf2 / SelectionDAG ExpandPowI: binary exponentiation
-static inline float powi(float a, int b) { float r = 1.0f; for (;;) { if (b & 1) r *= a; b /= 2; if (b == 0) break; a *= a; } return r; }
 static Color fresnel_conductor(float cos_t, Color eta, Color k) {
     float c2 = cos_t * cos_t;
     float s2 = 1.0f - c2;
@@ -995,6 +1080,7 @@ struct Scene {
     std::vector<EmitterRec> emitters;
     std::vector<EmitterRec> other_emitters;   // EmittersState::Unbuild(..): point / directional lights in insertion order
     bool has_env = false; Color env_color = Color::zero();
+    std::unique_ptr<EnvTexture> env_tex;      // EnvironmentLightColor::Texture when set, else Constant(env_color)
     int env_emitter = -1;
     std::vector<int> mesh_to_emitter;
     Distribution1D emitters_cdf;
@@ -1033,7 +1119,10 @@ struct Scene {
                 case EM_MESH: f = mesh_flux(meshes[e.mesh]); break;
                 case EM_POINT: f = e.c * 4.0f * PI_F; break;                                  // emitter.rs:238-240
                 case EM_DIRECTIONAL: f = (PI_F * powi(e.bsphere.radius, 2)) * e.c; break;      // emitter.rs:163-167
-                default: f = PI_F * powi(e.bsphere.radius, 2) * e.c; break;                    // emitter.rs:520-523
+                default:                                                                        // emitter.rs:519-531
+                    if (env_tex) f = Color::value(PI_F * powi(e.bsphere.radius, 2) * env_tex->cdf.marginal.func_int);
+                    else f = PI_F * powi(e.bsphere.radius, 2) * e.c;
+                    break;
             }
             flux.push_back(f.channel_max());
         }
@@ -1042,8 +1131,8 @@ struct Scene {
     float emitter_pdf(int mesh_id) const { return emitters_cdf.pdf((size_t)mesh_to_emitter[mesh_id]); }  // emitter.rs:1510-1526
     // EmitterSampler::direct_pdf (emitter.rs:1566-1575)
     PDF direct_pdf(int mesh_id, const LightSamplingPDF& ls) const { return mesh_direct_pdf(meshes[mesh_id], ls).mul(emitter_pdf(mesh_id)); }
-    PDF direct_pdf_env() const { return PDF::solid_angle(1.0f / (PI_F * 4.0f)).mul(emitters_cdf.pdf((size_t)env_emitter)); }
-    Color environment_luminance() const { return has_env ? env_color : Color::zero(); }   // scene.rs:125-130
+    PDF direct_pdf_env(V3 d) const { return PDF::solid_angle(env_tex ? env_tex->pdf(d) : 1.0f / (PI_F * 4.0f)).mul(emitters_cdf.pdf((size_t)env_emitter)); }
+    Color environment_luminance(V3 d) const { return !has_env ? Color::zero() : (env_tex ? env_tex->eval(d) : env_color); }   // scene.rs:125-130
     // EmitterSampler::sample_light (emitter.rs:1604-1620); LightSampling.emitter = index into `emitters`
     LightSampling sample_light(V3 p, float r_sel, float r, V2 uv) const {
         size_t id = emitters_cdf.sample_discrete(r_sel);
@@ -1059,15 +1148,16 @@ struct Scene {
         } else if (e.kind == EM_DIRECTIONAL) {                             // emitter.rs:116-134
             V3 lp = p - e.bsphere.radius * e.v;
             res = {-1, PDF::discrete(1.0f), lp, e.v, -e.v, e.c};
-        } else {                                                           // emitter.rs:482-518 (Constant)
-            V3 d = sample_uniform_sphere(uv);
-            float pdf = 1.0f / (PI_F * 4.0f);
+        } else {                                                           // emitter.rs:473-518
+            V3 d; float pdf; Color lum = e.c;
+            if (env_tex) env_tex->sample_direction(uv, &d, &lum, &pdf);
+            else { d = sample_uniform_sphere(uv); pdf = 1.0f / (PI_F * 4.0f); }
             float t;
             if (!bsphere_intersect(e.bsphere, Ray::make(p, d), &t)) res = {-1, PDF::solid_angle(pdf), {0, 0, 0}, {0, 0, 0}, d, Color::zero()};
             else {
                 V3 lp = p + d * t;
                 V3 n = normalize(e.bsphere.center - lp);
-                res = {-1, PDF::solid_angle(pdf), lp, n, d, e.c / pdf};
+                res = {-1, PDF::solid_angle(pdf), lp, n, d, lum / pdf};
             }
         }
         res.emitter = (int)id;
@@ -1283,7 +1373,7 @@ struct PathTracer {
             if (e.has_contrib) return e.contrib * e.weight * e.rr_weight;
             return e.weight * e.rr_weight * vertex_contribution(e.v1, e);
         }
-        return e.weight * e.rr_weight * scene.environment_luminance();  // scene.enviroment_luminance(self.d)
+        return e.weight * e.rr_weight * scene.environment_luminance(e.d);  // scene.enviroment_luminance(self.d)
     }
 
     // Edge::from_ray (edge.rs:65-189)
@@ -1448,7 +1538,7 @@ struct PathTracer {
         V3 o = v.position();
         if (e.v1 < 0) {   // pdf_emitter with no next vertex: the environment (emitters.rs:18-46)
             if (!scene.has_env) return false;
-            *out = scene.direct_pdf_env().value();
+            *out = scene.direct_pdf_env(e.d).value();   // LightSamplingPDF.dir = edge.d
             return true;
         }
         const Vertex& nx = path.vertices[e.v1];
@@ -1626,7 +1716,7 @@ static Color direct_compute_pixel(const Scene& scene, const DirectParams& dp, ui
     Color l_i = Color::zero();
     Intersection its;
     cnt.extension_rays++;
-    if (!scene.trace(ray, &its)) return scene.environment_luminance();
+    if (!scene.trace(ray, &its)) return scene.environment_luminance(ray.d);
     if (its.wi.z <= 0.0f) return l_i;
     const Mesh& mesh = scene.meshes[its.mesh];
     add_assign(l_i, mesh.emit());
@@ -1669,9 +1759,9 @@ static Color direct_compute_pixel(const Scene& scene, const DirectParams& dp, ui
             }
         } else if (scene.has_env) {
             float weight_bsdf;
-            if (sd.pdf.kind == PDF::SolidAngle) weight_bsdf = mis_weight(sd.pdf.v * w_nb_bsdf, scene.direct_pdf_env().value() * w_nb_light);
+            if (sd.pdf.kind == PDF::SolidAngle) weight_bsdf = mis_weight(sd.pdf.v * w_nb_bsdf, scene.direct_pdf_env(r2.d).value() * w_nb_light);
             else weight_bsdf = 1.0f;
-            add_assign(l_i, weight_bsdf * sd.weight * scene.environment_luminance() * w_nb_bsdf);
+            add_assign(l_i, weight_bsdf * sd.weight * scene.environment_luminance(r2.d) * w_nb_bsdf);
         }
     }
     return l_i;
@@ -1767,6 +1857,17 @@ int orc_scene_set_environment(orc_scene* sc, const float* rgb) {
     return 0;
 }
 
+int orc_scene_set_environment_map(orc_scene* sc, uint32_t w, uint32_t h, const float* rgb) {   // EnvironmentLightColor::new_texture
+    if (w == 0 || h == 0) return -1;
+    sc->s.has_env = true;
+    sc->s.env_tex.reset(new EnvTexture());
+    sc->s.env_tex->image.w = w; sc->s.env_tex->image.h = h;
+    sc->s.env_tex->image.colors.resize((size_t)w * h);
+    for (size_t i = 0; i < (size_t)w * h; i++) sc->s.env_tex->image.colors[i] = {rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
+    sc->s.env_tex->build();
+    return 0;
+}
+
 int orc_scene_build(orc_scene* sc) {
     sc->s.build_emitters();
     sc->s.build_bvh();
@@ -1808,6 +1909,18 @@ void orc_math_batch(int fn, size_t n, const float* a, const float* b, float* out
             default: out[i] = 0.0f;
         }
     }
+}
+
+// ---- textured-environment probe: kind 0 sample_direction(u) -> out[0..2] d, [3..5] value, [6] pdf;
+//      kind 1 eval(d) -> out[0..2]; kind 2 pdf(d) -> out[0]; kind 3 -> marginal.func_int
+int orc_env_probe(const orc_scene* sc, int kind, const float* in, float* out) {
+    const EnvTexture* t = sc->s.env_tex.get();
+    if (!t) return -1;
+    if (kind == 0) { V3 d; Color v; float pdf; t->sample_direction({in[0], in[1]}, &d, &v, &pdf); out[0] = d.x; out[1] = d.y; out[2] = d.z; out[3] = v.r; out[4] = v.g; out[5] = v.b; out[6] = pdf; }
+    else if (kind == 1) { Color v = t->eval({in[0], in[1], in[2]}); out[0] = v.r; out[1] = v.g; out[2] = v.b; }
+    else if (kind == 2) out[0] = t->pdf({in[0], in[1], in[2]});
+    else out[0] = t->cdf.marginal.func_int;
+    return 0;
 }
 
 // ---- camera / sampling probes (for unit tests)

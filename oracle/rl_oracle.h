@@ -46,6 +46,8 @@ int orc_scene_set_medium(orc_scene* sc, const float* sigma_a, const float* sigma
 int orc_scene_add_point_light(orc_scene* sc, const float* position, const float* intensity);
 int orc_scene_add_directional_light(orc_scene* sc, const float* direction, const float* intensity);
 int orc_scene_set_environment(orc_scene* sc, const float* rgb);
+int orc_scene_set_environment_map(orc_scene* sc, uint32_t w, uint32_t h, const float* rgb);   /* lat-long texture, emitter.rs:300-425 */
+int orc_env_probe(const orc_scene* sc, int kind, const float* in, float* out);
 int orc_scene_build(orc_scene* sc);
 
 void orc_rng_seed(uint64_t seed, int variant, uint64_t* state_out);

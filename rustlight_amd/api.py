@@ -29,10 +29,10 @@ PIPELINE_AUTO, PIPELINE_WAVEFRONT, PIPELINE_FUSED = 0, 1, 2
 PUBLIC_SYMBOLS = [
     "rl_scene_create", "rl_scene_destroy", "rl_scene_set_camera", "rl_scene_scale_image", "rl_scene_add_mesh",
     "rl_scene_add_bitmap", "rl_scene_set_medium", "rl_scene_add_point_light", "rl_scene_add_directional_light",
-    "rl_scene_set_environment", "rl_scene_build_emitters", "rl_scene_load_pbrt",
+    "rl_scene_set_environment", "rl_scene_set_environment_map", "rl_scene_build_emitters", "rl_scene_load_pbrt",
     "rl_scene_image_size", "rl_scene_counts", "rl_sampler_seed", "rl_sampler_next_u64", "rl_sampler_next_f32",
     "rl_path_params_default", "rl_context_create", "rl_context_destroy", "rl_last_error", "rl_block_count",
-    "rl_generate_block_seeds", "rl_render_path", "rl_render_ao", "rl_render_direct", "rl_trace_batch", "rl_visible_batch", "rl_save_pfm", "rl_save_png", "rl_save_exr", "rl_save_image", "rl_build_info",
+    "rl_generate_block_seeds", "rl_render_path", "rl_render_ao", "rl_render_direct", "rl_trace_batch", "rl_visible_batch", "rl_load_pfm", "rl_save_pfm", "rl_save_png", "rl_save_exr", "rl_save_image", "rl_build_info",
 ]
 
 
@@ -70,6 +70,7 @@ def lib():
     L.rl_scene_add_point_light.argtypes = [vp, f32p, f32p]
     L.rl_scene_add_directional_light.argtypes = [vp, f32p, f32p]
     L.rl_scene_set_environment.argtypes = [vp, f32p]
+    L.rl_scene_set_environment_map.argtypes = [vp, C.c_uint32, C.c_uint32, f32p]
     L.rl_scene_load_pbrt.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
     L.rl_scene_image_size.argtypes = [vp, u32p, u32p]
     L.rl_scene_counts.argtypes = [vp, u64p, u64p, u64p]
@@ -168,6 +169,9 @@ class Scene:
             if sd.environment is not None:
                 e = np.asarray(sd.environment, np.float32)
                 _check(L.rl_scene_set_environment(self.h, abi.fptr(e)))
+            if sd.environment_map is not None:
+                em = np.ascontiguousarray(sd.environment_map, np.float32)
+                _check(L.rl_scene_set_environment_map(self.h, em.shape[1], em.shape[0], abi.fptr(em)))
         _check(L.rl_scene_build_emitters(self.h))
 
     @classmethod
@@ -209,6 +213,15 @@ class Scene:
         _check(lib().rl_debug_bvh(self.h, C.byref(nn), C.byref(npr), abi.fptr(boxes), abi.u64ptr(info), abi.u64ptr(count),
                                   pm.ctypes.data_as(C.POINTER(C.c_int32)), pt.ctypes.data_as(C.POINTER(C.c_int32))))
         return boxes, info, count, pm, pt
+
+    def debug_emitters_cdf(self):
+        n = C.c_uint64(0)
+        L = lib()
+        L.rl_debug_emitters_cdf.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+        _check(L.rl_debug_emitters_cdf(self.h, C.byref(n), None))
+        out = np.zeros(n.value, np.float32)
+        _check(L.rl_debug_emitters_cdf(self.h, C.byref(n), abi.fptr(out)))
+        return out
 
     def camera_ray(self, px, py):
         o = (C.c_float * 3)()
@@ -340,6 +353,17 @@ class IntegratorPathTracing:
         return img
 
 
+def load_pfm(path: str) -> np.ndarray:
+    """Bitmap::read_pfm (src/structure.rs:563-607) -> H x W x 3 float32, top row first."""
+    w, h = C.c_uint32(), C.c_uint32()
+    L = lib()
+    L.rl_load_pfm.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.c_size_t]
+    _check(L.rl_load_pfm(path.encode(), C.byref(w), C.byref(h), None, 0))
+    out = np.zeros((h.value, w.value, 3), np.float32)
+    _check(L.rl_load_pfm(path.encode(), C.byref(w), C.byref(h), abi.fptr(out), out.size))
+    return out
+
+
 def save_pfm(path: str, img: np.ndarray):
     a = np.ascontiguousarray(img, dtype=np.float32)
     _check(lib().rl_save_pfm(path.encode(), abi.fptr(a), a.shape[1], a.shape[0]))
@@ -411,6 +435,6 @@ class IntegratorEqualTime:
 def numerics_probe(a: np.ndarray, b: np.ndarray, device: int = 0) -> np.ndarray:
     a = np.ascontiguousarray(a, np.float32)
     b = np.ascontiguousarray(b, np.float32)
-    out = np.zeros((8, a.shape[0]), np.float32)
+    out = np.zeros((10, a.shape[0]), np.float32)
     _check(lib().rl_debug_numerics(device, a.shape[0], abi.fptr(a), abi.fptr(b), abi.fptr(out)))
     return out

@@ -128,6 +128,14 @@ struct DeviceScene {
     int32_t env_emitter;           // index of the environment emitter or -1
     float env_color[3];
     float env_pdf;                 // direct_pdf of the constant environment: 1/(4 pi) * p_sel
+    // EnvironmentLightColor::Texture (emitter.rs:300-425): lat-long image + Distribution2D over luminance * sin(theta)
+    uint32_t env_w, env_h;         // 0 x 0: constant environment
+    const float* env_texels;       // 3 per pixel, row-major
+    const float* env_cond_cdf;     // env_h rows of (env_w + 1)
+    const float* env_cond_func;    // env_h rows of env_w
+    const float* env_marg_cdf;     // env_h + 1
+    float env_marg_func_int;
+    float env_sel_pdf;             // p_sel of the environment emitter (EmitterSampler::pdf)
     const float* mesh_cdf;         // concatenated per-mesh area cdfs
     uint32_t n_meshes;
     CameraRecord camera;

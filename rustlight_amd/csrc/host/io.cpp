@@ -8,9 +8,45 @@
 #include "../kernels/wavefront.h"
 #include "scene.h"
 
+// Bitmap::read_pfm (src/structure.rs:563-607): "PF\n", "W H\n", "-1.0\n" (little endian only), rows stored bottom-up
+namespace rl {
+int read_pfm(const char* path, uint32_t* w, uint32_t* h, std::vector<float>* rgb) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return RL_ERR_IO;
+    char line[128];
+    unsigned ww = 0, hh = 0; float enc = 0.0f;
+    bool ok = std::fgets(line, sizeof(line), f) && std::strcmp(line, "PF\n") == 0
+           && std::fgets(line, sizeof(line), f) && std::sscanf(line, "%u %u", &ww, &hh) == 2
+           && std::fgets(line, sizeof(line), f) && std::sscanf(line, "%f", &enc) == 1 && enc == -1.0f && ww && hh;
+    if (!ok) { std::fclose(f); return RL_ERR_PARSE; }
+    rgb->assign((size_t)3 * ww * hh, 0.0f);
+    std::vector<float> row(3 * (size_t)ww);
+    for (unsigned y = 0; y < hh && ok; y++) {
+        ok = std::fread(row.data(), sizeof(float), row.size(), f) == row.size();
+        if (ok) std::memcpy(&(*rgb)[3 * (size_t)(hh - y - 1) * ww], row.data(), row.size() * sizeof(float));
+    }
+    std::fclose(f);
+    if (!ok) return RL_ERR_IO;
+    *w = ww; *h = hh;
+    return RL_OK;
+}
+}  // namespace rl
+
 using namespace rl;
 
 extern "C" {
+
+int rl_load_pfm(const char* path, uint32_t* width, uint32_t* height, float* rgb, size_t capacity_floats) {
+    if (!path || !width || !height) return RL_ERR_INVALID_ARGUMENT;
+    std::vector<float> data;
+    int rc = rl::read_pfm(path, width, height, &data);
+    if (rc != RL_OK) return rc;
+    if (rgb) {   // rgb == NULL: size query
+        if (capacity_floats < data.size()) return RL_ERR_INVALID_ARGUMENT;
+        std::memcpy(rgb, data.data(), data.size() * sizeof(float));
+    }
+    return RL_OK;
+}
 
 // Bitmap::save_pfm (src/structure.rs:547-560): "PF\nW H\n-1.0\n", rows bottom-up, |r| |g| |b| as LE f32
 int rl_save_pfm(const char* path, const float* rgb, uint32_t width, uint32_t height) {
@@ -149,6 +185,14 @@ int rl_debug_bvh(const rl_scene* scene, uint64_t* n_nodes, uint64_t* n_prims, fl
     if (count) std::memcpy(count, b.ref_count.data(), b.ref_count.size() * sizeof(uint64_t));
     if (prim_mesh) std::memcpy(prim_mesh, b.ref_prim_mesh.data(), b.ref_prim_mesh.size() * sizeof(int32_t));
     if (prim_tri) std::memcpy(prim_tri, b.ref_prim_tri.data(), b.ref_prim_tri.size() * sizeof(int32_t));
+    return RL_OK;
+}
+
+// EmitterSampler's cdf over flux().channel_max() (scene.rs:103-111), for loader / emitter tests
+int rl_debug_emitters_cdf(const rl_scene* scene, uint64_t* n_entries, float* cdf) {
+    if (!scene || !n_entries || !scene->emitters_built) return RL_ERR_INVALID_ARGUMENT;
+    if (cdf) { if (*n_entries < scene->emitters_cdf.size()) return RL_ERR_INVALID_ARGUMENT; std::memcpy(cdf, scene->emitters_cdf.data(), scene->emitters_cdf.size() * sizeof(float)); }
+    *n_entries = scene->emitters_cdf.size();
     return RL_OK;
 }
 

@@ -197,6 +197,11 @@ int load_pbrt(const char* path, bool use_shading_normals, rl_scene** out, std::s
     ss << f.rdbuf();
     Lexer lx;
     lx.src = ss.str();
+    // files named by the scene are relative to its directory (`wk` in scene_loader.rs:164-166)
+    const std::string scene_path(path);
+    const size_t slash = scene_path.find_last_of('/');
+    const std::string base_dir = slash == std::string::npos ? std::string(".") : scene_path.substr(0, slash);
+    auto join_path = [](const std::string& dir, const std::string& name) { return (!name.empty() && name[0] == '/') ? name : dir + "/" + name; };
     std::vector<GState> stack;
     GState gs;
     std::map<std::string, rl_bsdf_desc> named;
@@ -299,7 +304,17 @@ int load_pbrt(const char* path, bool use_shading_normals, rl_scene** out, std::s
                 float d3[3] = {dir.x, dir.y, dir.z}, i3[3] = {Lc.color0[0] * sc.color0[0], Lc.color0[1] * sc.color0[1], Lc.color0[2] * sc.color0[2]};
                 rl_scene_add_directional_light(scene, d3, i3);
             } else if (ty.text == "infinite") {
-                if (find(ps, "mapname")) return fail(RL_ERR_UNSUPPORTED, "LightSource infinite with a mapname (texture environment) is not supported");
+                if (const Param* mp = find(ps, "mapname")) {
+                    // Spectrum::Mapname: Bitmap::read(wk.join(name)) -> EnvironmentLightColor::new_texture; scale must be 1 (scene_loader.rs:259-271)
+                    if (mp->strs.empty()) return fail(RL_ERR_PARSE, "LightSource infinite: mapname needs a file name");
+                    if (sc.color0[0] != 1.0f || sc.color0[1] != 1.0f || sc.color0[2] != 1.0f) return fail(RL_ERR_UNSUPPORTED, "LightSource infinite: scale must be 1 with a mapname");
+                    const std::string file = join_path(base_dir, mp->strs[0]);
+                    if (file.size() < 4 || file.substr(file.size() - 4) != ".pfm") return fail(RL_ERR_UNSUPPORTED, "LightSource infinite: only .pfm environment maps are read");
+                    uint32_t ew = 0, eh = 0; std::vector<float> texels;
+                    if (read_pfm(file.c_str(), &ew, &eh, &texels) != RL_OK) return fail(RL_ERR_IO, "cannot read environment map " + file);
+                    rl_scene_set_environment_map(scene, ew, eh, texels.data());
+                    continue;
+                }
                 rl_color_desc Lc = color_param(ps, "L", 1, 1, 1);
                 float e3[3] = {Lc.color0[0] * sc.color0[0], Lc.color0[1] * sc.color0[1], Lc.color0[2] * sc.color0[2]};
                 rl_scene_set_environment(scene, e3);

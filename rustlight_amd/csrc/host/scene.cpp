@@ -1,5 +1,6 @@
 // scene.cpp — host-side scene construction (untimed prologue of the render).
 #include "scene.h"
+#include "../detmath_shared.h"
 
 #include <algorithm>
 #include <cstring>
@@ -264,7 +265,33 @@ int rl_scene_build_emitters(rl_scene* scene) {
         std::memset(&e, 0, sizeof(e));
         e.kind = EMITTER_ENV; e.mesh = -1;
         for (int k = 0; k < 3; k++) e.c[k] = scene->env_color[k];
-        finish(e);
+        if (scene->env_map.w) {
+            // EnvironmentLightColor::new_texture + Distribution2D::from_bitmap (emitter.rs:340-353, math.rs:494-521):
+            // rows weighted by sin(theta) at the pixel centre, one conditional cdf per row, marginal over the row means
+            const HostBitmap& im = scene->env_map;
+            scene->env_cond_cdf.clear(); scene->env_cond_func.clear();
+            std::vector<float> marg, row(im.w), cdf;
+            for (uint32_t y = 0; y < im.h; y++) {
+                const float w = dm::sinf_det(((float)y + 0.5f) * kPi / (float)im.h);
+                for (uint32_t x = 0; x < im.w; x++) {
+                    const float* px = &im.rgb[3 * ((size_t)y * im.w + x)];
+                    const float r = px[0] * w, g = px[1] * w, b = px[2] * w;
+                    row[x] = (r * 0.212671f + g * 0.715160f) + b * 0.072169f;      // Color::luminance (structure.rs:173-176)
+                }
+                float fi;
+                build_cdf(row, &cdf, &fi);
+                scene->env_cond_cdf.insert(scene->env_cond_cdf.end(), cdf.begin(), cdf.end());
+                scene->env_cond_func.insert(scene->env_cond_func.end(), row.begin(), row.end());
+                marg.push_back(fi);
+            }
+            build_cdf(marg, &scene->env_marg_cdf, &scene->env_marg_func_int);
+            // flux = Color::value(PI * radius^2 * marginal.func_int) (emitter.rs:524-530); finish() multiplies c by PI * r^2
+            for (int k = 0; k < 3; k++) e.c[k] = 0.0f;
+            for (int k = 0; k < 3; k++) e.center[k] = scene->bsphere_center[k];
+            e.radius = big_radius;
+            scene->emitters.push_back(e);
+            flux.push_back((kPi * (big_radius * big_radius)) * scene->env_marg_func_int);
+        } else finish(e);
     }
     for (const EmitterRecord& o : scene->other_emitters) finish(o);
     scene->emitters_cdf.clear();
@@ -300,6 +327,15 @@ int rl_scene_set_environment(rl_scene* scene, const float rgb[3]) {
     if (!scene || !rgb) return RL_ERR_INVALID_ARGUMENT;
     scene->has_env = true;
     for (int k = 0; k < 3; k++) scene->env_color[k] = rgb[k];
+    scene->emitters_built = false;
+    return RL_OK;
+}
+
+int rl_scene_set_environment_map(rl_scene* scene, uint32_t w, uint32_t h, const float* rgb) {
+    if (!scene || !rgb || w == 0 || h == 0) return RL_ERR_INVALID_ARGUMENT;
+    scene->has_env = true;
+    scene->env_map.w = w; scene->env_map.h = h;
+    scene->env_map.rgb.assign(rgb, rgb + (size_t)3 * w * h);
     scene->emitters_built = false;
     return RL_OK;
 }

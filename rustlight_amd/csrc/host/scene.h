@@ -50,6 +50,10 @@ struct rl_scene {
     bool emitters_built = false;
     std::vector<rl::EmitterRecord> other_emitters;   // point / directional lights, insertion order
     bool has_env = false; float env_color[3] = {0, 0, 0};
+    // EnvironmentLightColor::Texture: the image and its Distribution2D (built by rl_scene_build_emitters)
+    rl::HostBitmap env_map{0, 0, {}};
+    std::vector<float> env_cond_cdf, env_cond_func, env_marg_cdf;
+    float env_marg_func_int = 0.0f;
     std::vector<rl::EmitterRecord> emitters;          // emissive meshes (mesh order), environment, others
     std::vector<float> emitters_cdf;        // n + 1
     float bsphere_center[3] = {0, 0, 0};
@@ -91,6 +95,7 @@ struct FlatScene {
 };
 void flatten_scene(const rl_scene& scene, FlatScene* out);
 
+int read_pfm(const char* path, uint32_t* w, uint32_t* h, std::vector<float>* rgb);   // Bitmap::read_pfm
 int load_pbrt(const char* path, bool use_shading_normals, rl_scene** out, std::string* err);
 
 }  // namespace rl

@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../detmath_shared.h"
+
 #pragma clang fp contract(off)
 
 #define RL_DEV __device__ __forceinline__
@@ -76,43 +78,7 @@ RL_DEV float cget(Col c, int i) { return i == 0 ? c.r : (i == 1 ? c.g : c.b); }
 // ------------------------------------------------------------------------------------------
 // deterministic transcendentals (f64 evaluation, one rounding to f32)
 namespace dm {
-RL_DEV double bits_f64(unsigned long long u) { return __longlong_as_double((long long)u); }
-RL_DEV unsigned long long f64_bits(double d) { return (unsigned long long)__double_as_longlong(d); }
-
-RL_DEV double k_sin(double r) {
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
-                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    double z = r * r;
-    double p = S5 + z * S6;
-    p = S4 + z * p; p = S3 + z * p; p = S2 + z * p; p = S1 + z * p;
-    return r + (r * z) * p;
-}
-RL_DEV double k_cos(double r) {
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
-                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    double z = r * r;
-    double p = C5 + z * C6;
-    p = C4 + z * p; p = C3 + z * p; p = C2 + z * p; p = C1 + z * p;
-    return (1.0 - 0.5 * z) + (z * z) * p;
-}
-RL_DEV void sincos_d(double x, double* s, double* c) {
-    const double INV_PIO2 = 6.36619772367581382433e-01, PIO2_HI = 1.57079632673412561417e+00, PIO2_LO = 6.07710050650619224932e-11;
-    double kd = floor(x * INV_PIO2 + 0.5);
-    double r = (x - kd * PIO2_HI) - kd * PIO2_LO;
-    long long k = (long long)kd;
-    double sr = k_sin(r), cr = k_cos(r);
-    int q = (int)(k & 3);
-    *s = q == 0 ? sr : (q == 1 ? cr : (q == 2 ? -sr : -cr));
-    *c = q == 0 ? cr : (q == 1 ? -sr : (q == 2 ? -cr : sr));
-}
-RL_DEV void sincosf_det(float x, float* s, float* c) {
-    if (!(x - x == 0.0f)) { *s = *c = x - x; return; }
-    double sd, cd;
-    sincos_d((double)x, &sd, &cd);
-    *s = (float)sd; *c = (float)cd;
-}
-RL_DEV float sinf_det(float x) { float s, c; sincosf_det(x, &s, &c); return s; }
-RL_DEV float cosf_det(float x) { float s, c; sincosf_det(x, &s, &c); return c; }
+// bits_f64 / f64_bits / sincosf_det / sinf_det / cosf_det: ../detmath_shared.h
 
 RL_DEV double exp_d(double x) {
     const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10, INV_LN2 = 1.44269504088896338700e+00;
@@ -173,6 +139,60 @@ RL_DEV float powf_det(float x, float y) {
     if (x - x != 0.0f) return y > 0.0f ? x : 0.0f;
     double a = (double)y * log_d((double)x);
     return (float)exp_d(a);
+}
+// atan on f64: argument reduction to |t| <= tan(pi/16) + odd series up to t^25; used by acos / atan2
+RL_DEV double atan_d(double x) {
+    bool neg = x < 0.0; if (neg) x = -x;
+    bool inv = x > 1.0; if (inv) x = 1.0 / x;
+    const double C = 0.41421356237309503;        // tan(pi/8)
+    double base = 0.0, t = x;
+    if (x > 0.66817863791929890) { base = 0.78539816339744827900; t = (x - 1.0) / (1.0 + x); }
+    else if (x > 0.19891236737965800) { base = 0.39269908169872413950; t = (x - C) / (1.0 + x * C); }
+    bool red = base != 0.0;
+    double z = t * t;
+    double p = 1.0 / 25.0;
+    p = 1.0 / 23.0 - z * p; p = 1.0 / 21.0 - z * p; p = 1.0 / 19.0 - z * p; p = 1.0 / 17.0 - z * p;
+    p = 1.0 / 15.0 - z * p; p = 1.0 / 13.0 - z * p; p = 1.0 / 11.0 - z * p; p = 1.0 / 9.0 - z * p;
+    p = 1.0 / 7.0 - z * p; p = 1.0 / 5.0 - z * p; p = 1.0 / 3.0 - z * p; p = 1.0 - z * p;
+    double r = t * p;
+    if (red) r = base + r;
+    if (inv) r = 1.57079632679489655800 - r;
+    return neg ? -r : r;
+}
+// sqrt on f64 from the correctly rounded f32 square root and two Newton steps (+,-,*,/ only: no reliance on how
+// the f64 sqrt instruction rounds)
+RL_DEV double sqrt_d(double a) {
+    if (!(a > 0.0)) return 0.0;
+    double s = (double)__builtin_sqrtf((float)a);
+    s = 0.5 * (s + a / s);
+    s = 0.5 * (s + a / s);
+    return s;
+}
+RL_DEV float atan2f_det(float y, float x) {
+    if (x != x || y != y) return x + y;
+    const double PI = 3.14159265358979311600;
+    double yd = y, xd = x;
+    if (xd == 0.0 && yd == 0.0) return __builtin_signbit(x) ? (__builtin_signbit(y) ? (float)-PI : (float)PI) : y;
+    double r;
+    if (__builtin_fabs(xd) >= __builtin_fabs(yd)) {
+        r = atan_d(yd / xd);
+        if (xd < 0.0) r = (yd >= 0.0 && !__builtin_signbit(y)) ? r + PI : r - PI;
+    } else {
+        r = atan_d(xd / yd);
+        r = (yd > 0.0 ? 0.5 * PI : -0.5 * PI) - r;
+    }
+    return (float)r;
+}
+RL_DEV float acosf_det(float x) {
+    if (x != x) return x;
+    if (x > 1.0f || x < -1.0f) return f32_nan();
+    double xd = x;
+    double s = sqrt_d((1.0 - xd) * (1.0 + xd));
+    const double PI = 3.14159265358979311600;
+    double r;
+    if (__builtin_fabs(xd) >= s) { r = atan_d(s / xd); if (xd < 0.0) r = r + PI; }   // acos(x) = atan2(sqrt(1 - x^2), x)
+    else { r = 0.5 * PI - atan_d(xd / s); }
+    return (float)r;
 }
 }  // namespace dm
 

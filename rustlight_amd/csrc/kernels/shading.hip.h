@@ -392,6 +392,65 @@ RL_DEV unsigned int cdf_sample(const float* cdf, unsigned int n_entries, float v
 
 struct LightSample { float pdf; int pdf_kind; V3 p, n, d; Col weight; int kind; };
 
+// ------------------------------------------------------------------------------------------
+// EnvironmentLightColor (src/emitter.rs:300-425): constant colour or lat-long texture with a Distribution2D
+RL_DEV float clamp_f(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }          // lib.rs:59-67
+// Distribution1D::sample_continuous (math.rs:461-478) over `n` bins
+RL_DEV float cdf_sample_continuous(const float* cdf, unsigned int n, float v) {
+    unsigned int i = cdf_sample(cdf, n + 1, v);
+    float dv = v - cdf[i];
+    float p = cdf[i + 1] - cdf[i];
+    if (p > 0.0f) dv = div_rn(dv, p);
+    return (float)i + dv;
+}
+RL_DEV float env_bin_pdf(const DeviceScene& sc, unsigned long long x, unsigned long long y) {          // Distribution2D::pdf
+    return div_rn(sc.env_cond_func[y * sc.env_w + x], sc.env_marg_func_int);
+}
+RL_DEV V2 env_to_spherical(V3 d) {                                                                     // emitter.rs:320-338
+    float p = dm::atan2f_det(d.y, d.x);
+    if (p < 0.0f) p = p + 2.0f * kPi;
+    V2 uv; uv.x = p * kInvPi * 0.5f; uv.y = dm::acosf_det(clamp_f(d.z, -1.0f, 1.0f)) * kInvPi;
+    uv.x = clamp_f(uv.x, 0.0f, 0.9999999403953552f);
+    uv.y = clamp_f(uv.y, 0.0f, 0.9999999403953552f);
+    return uv;
+}
+// Emitter::eval of the environment = scene.enviroment_luminance(d) (scene.rs:125-130)
+RL_DEV Col env_eval(const DeviceScene& sc, V3 d) {
+    if (sc.env_w == 0u) return mkc(sc.env_color[0], sc.env_color[1], sc.env_color[2]);
+    V2 uv = env_to_spherical(d);
+    float ux = modulo1(uv.x), uy = modulo1(uv.y);                                                      // Bitmap::pixel_uv
+    unsigned long long x = f32_as_usize(ux * (float)sc.env_w), y = f32_as_usize(uy * (float)sc.env_h);
+    unsigned long long i = (unsigned long long)sc.env_w * y + x;
+    if (i >= (unsigned long long)sc.env_w * sc.env_h) return czero();
+    return mkc(sc.env_texels[3 * i], sc.env_texels[3 * i + 1], sc.env_texels[3 * i + 2]);
+}
+// EnvironmentLight::direct_pdf (solid angle) times the emitter-selection probability (emitter.rs:407-424, 1566-1575)
+RL_DEV float env_direct_pdf(const DeviceScene& sc, V3 d) {
+    if (sc.env_w == 0u) return sc.env_pdf;
+    V2 uv = env_to_spherical(d);
+    float p = env_bin_pdf(sc, f32_as_usize(uv.x * (float)sc.env_w), f32_as_usize(uv.y * (float)sc.env_h));
+    float st = dm::sinf_det(kPi * uv.y);
+    float v = st == 0.0f ? 0.0f : div_rn(p, (2.0f * powi_f(kPi, 2)) * st);
+    return v * sc.env_sel_pdf;
+}
+// EnvironmentLightColor::sample_direction, Texture (emitter.rs:362-393)
+RL_DEV void env_sample_direction(const DeviceScene& sc, V2 u, V3* d, Col* value, float* pdf) {
+    float y = cdf_sample_continuous(sc.env_marg_cdf, sc.env_h, u.y);
+    unsigned long long row = f32_as_usize(y);
+    float x = cdf_sample_continuous(sc.env_cond_cdf + row * (sc.env_w + 1u), sc.env_w, u.x);
+    x = clamp_f(x, 0.0f, (float)sc.env_w - 1.0f);
+    y = clamp_f(y, 0.0f, (float)sc.env_h - 1.0f);
+    unsigned long long px = f32_as_usize(x), py = f32_as_usize(y);
+    const float* t = sc.env_texels + 3ull * (py * sc.env_w + px);
+    float p = env_bin_pdf(sc, px, py);
+    float sp, cp, st, ct;
+    dm::sincosf_det(div_rn(2.0f * kPi, (float)sc.env_w) * x, &sp, &cp);
+    dm::sincosf_det(div_rn(kPi, (float)sc.env_h) * y, &st, &ct);
+    *d = mk3(st * cp, st * sp, ct);
+    if (st == 0.0f) { *value = czero(); *pdf = 0.0f; }
+    else { *value = mkc(t[0], t[1], t[2]); *pdf = div_rn(p, (2.0f * powi_f(kPi, 2)) * st); }
+}
+
 // solve_quadratic (src/math.rs:324-352) + BoundingSphere::intersect (src/structure.rs:894-917)
 RL_DEV bool bsphere_intersect(V3 center, float radius, V3 o, V3 d, float tnear, float tfar, float* t_out) {
     V3 d_p = center - o;
@@ -469,9 +528,10 @@ RL_DEV LightSample sample_light(const DeviceScene& sc, V3 p, float r_sel, float 
         ls.pdf = 1.0f; ls.pdf_kind = PDF_DISCRETE;
         ls.p = p - em.radius * dir; ls.n = dir; ls.d = -dir;
         ls.weight = mkc(em.c[0], em.c[1], em.c[2]);
-    } else {                                               // EnvironmentLight::direct_sample, Constant (emitter.rs:482-518)
-        V3 d = sample_uniform_sphere(uv);
-        float pdf = div_rn(1.0f, kPi * 4.0f);
+    } else {                                               // EnvironmentLight::direct_sample (emitter.rs:473-518)
+        V3 d; float pdf; Col lum = mkc(em.c[0], em.c[1], em.c[2]);
+        if (sc.env_w) env_sample_direction(sc, uv, &d, &lum, &pdf);
+        else { d = sample_uniform_sphere(uv); pdf = div_rn(1.0f, kPi * 4.0f); }
         float t;
         ls.pdf = pdf; ls.pdf_kind = PDF_SOLID_ANGLE; ls.d = d;
         if (!bsphere_intersect(mk3(em.center[0], em.center[1], em.center[2]), em.radius, p, d, kEps, kF32Max, &t)) {
@@ -479,7 +539,7 @@ RL_DEV LightSample sample_light(const DeviceScene& sc, V3 p, float r_sel, float 
         } else {
             ls.p = p + d * t;
             ls.n = normalize(mk3(em.center[0], em.center[1], em.center[2]) - ls.p);
-            ls.weight = mkc(em.c[0], em.c[1], em.c[2]) / pdf;
+            ls.weight = lum / pdf;
         }
     }
     ls.weight = div_unguarded(ls.weight, pdf_sel);         // res.weight /= pdf_sel

@@ -16,5 +16,6 @@ int rl_debug_bvh_sizes(const rl_context* ctx, uint64_t* n_ref_nodes, uint64_t* n
 int rl_debug_bvh(const rl_scene* scene, uint64_t* n_nodes, uint64_t* n_prims, float* boxes, uint64_t* info, uint64_t* count,
                  int32_t* prim_mesh, int32_t* prim_tri);
 // host-only: Camera::generate for one pixel position
+int rl_debug_emitters_cdf(const rl_scene* scene, uint64_t* n_entries, float* cdf);
 int rl_debug_camera_ray(const rl_scene* scene, float px, float py, float* origin, float* direction);
 }

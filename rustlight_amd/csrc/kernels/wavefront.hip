@@ -505,7 +505,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
         // edge without a next vertex: Edge::contribution = weight * rr * scene.enviroment_luminance(d) (edge.rs:201-210)
         ended = true;
         if (sc.env_emitter >= 0) {
-            Col contrib = (w_edge * rr) * mkc(sc.env_color[0], sc.env_color[1], sc.env_color[2]);
+            Col contrib = (w_edge * rr) * env_eval(sc, rd);
             const bool add_contrib = rc.has_min ? (depth - 1u) >= rc.min_depth : true;
             if (prev == PREV_SENSOR) {
                 if (!is_zero(contrib) && add_contrib) L = L + contrib;
@@ -515,7 +515,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
                     float wmis = 1.0f;
                     if (rc.strategy == RL_STRATEGY_ALL && (flags & ST_PDF_SA)) {
                         // pdf_emitter, `None` next vertex: direct_pdf of the environment (emitters.rs:18-46)
-                        float p2 = (prev == PREV_SURFACE || prev == PREV_VOLUME) ? sc.env_pdf : 0.0f;
+                        float p2 = (prev == PREV_SURFACE || prev == PREV_VOLUME) ? env_direct_pdf(sc, rd) : 0.0f;
                         float total = (0.0f + pdf_edge) + p2;
                         wmis = div_rn(pdf_edge, total);
                     }
@@ -870,7 +870,7 @@ RL_DEV Col mc_compute_pixel(const DeviceScene& sc, const SceneRecs& recs, const 
     Hit hit;
     n_ext++;
     if (!trace_closest(sc, recs, stack, o, d, hit)) {
-        if (KIND == 1 && sc.env_emitter >= 0) return mkc(sc.env_color[0], sc.env_color[1], sc.env_color[2]);   // scene.enviroment_luminance(ray.d)
+        if (KIND == 1 && sc.env_emitter >= 0) return env_eval(sc, d);   // scene.enviroment_luminance(ray.d)
         return czero();
     }
     const SurfacePoint sp = fill_intersection(sc, hit.prim, hit.u, hit.v, o, d, hit.t);
@@ -931,8 +931,8 @@ RL_DEV Col mc_compute_pixel(const DeviceScene& sc, const SceneRecs& recs, const 
                 l_i = l_i + weight_bsdf * bs.weight * mkc(nm.emission[0], nm.emission[1], nm.emission[2]) * w_nb_bsdf;
             }
         } else if (sc.env_emitter >= 0) {
-            float weight_bsdf = bs.pdf_kind == PDF_SOLID_ANGLE ? mis_weight_power(bs.pdf * w_nb_bsdf, sc.env_pdf * w_nb_light) : 1.0f;
-            l_i = l_i + weight_bsdf * bs.weight * mkc(sc.env_color[0], sc.env_color[1], sc.env_color[2]) * w_nb_bsdf;
+            float weight_bsdf = bs.pdf_kind == PDF_SOLID_ANGLE ? mis_weight_power(bs.pdf * w_nb_bsdf, env_direct_pdf(sc, d_out_world) * w_nb_light) : 1.0f;
+            l_i = l_i + weight_bsdf * bs.weight * env_eval(sc, d_out_world) * w_nb_bsdf;
         }
     }
     return l_i;
@@ -1036,7 +1036,7 @@ __global__ void __launch_bounds__(256) k_visible_batch(DeviceScene sc, StackConf
 
 // device self-test of the numerics contract: IEEE divide / sqrt, denormals, no contraction
 __global__ void k_numerics_probe(unsigned n, const float* a, const float* b, float* out_div, float* out_sqrt, float* out_mad, float* out_sin,
-                                 float* out_cos, float* out_exp, float* out_log, float* out_pow) {
+                                 float* out_cos, float* out_exp, float* out_log, float* out_pow, float* out_acos, float* out_atan2) {
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     out_div[i] = div_rn(a[i], b[i]);
@@ -1047,6 +1047,8 @@ __global__ void k_numerics_probe(unsigned n, const float* a, const float* b, flo
     out_exp[i] = dm::expf_det(a[i]);
     out_log[i] = dm::logf_det(fabsf(a[i]));
     out_pow[i] = dm::powf_det(fabsf(a[i]), b[i]);
+    out_acos[i] = dm::acosf_det(a[i] * 0.15f);
+    out_atan2[i] = dm::atan2f_det(a[i], b[i]);
 }
 
 }  // namespace rl
@@ -1158,7 +1160,17 @@ extern "C" int rl_context_create(const rl_scene* scene, int device, rl_context**
                 for (int k = 0; k < 3; k++) ds.env_color[k] = scene->emitters[e].c[k];
                 // EnvironmentLight::direct_pdf = SolidAngle(1 / (4 pi)) * EmitterSampler::pdf(env)
                 ds.env_pdf = (1.0f / (3.14159265358979323846f * 4.0f)) * (scene->emitters_cdf[e + 1] - scene->emitters_cdf[e]);
+                ds.env_sel_pdf = scene->emitters_cdf[e + 1] - scene->emitters_cdf[e];
             }
+        ds.env_w = ds.env_h = 0;
+        if (ds.env_emitter >= 0 && scene->env_map.w) {
+            ds.env_w = scene->env_map.w; ds.env_h = scene->env_map.h;
+            ds.env_marg_func_int = scene->env_marg_func_int;
+            if ((rc = upload(ctx, scene->env_map.rgb, &ds.env_texels)) != RL_OK) break;
+            if ((rc = upload(ctx, scene->env_cond_cdf, &ds.env_cond_cdf)) != RL_OK) break;
+            if ((rc = upload(ctx, scene->env_cond_func, &ds.env_cond_func)) != RL_OK) break;
+            if ((rc = upload(ctx, scene->env_marg_cdf, &ds.env_marg_cdf)) != RL_OK) break;
+        }
         if (ds.env_emitter >= 0 && scene->medium.enabled) { rl_set_error("an environment emitter cannot be combined with a medium (paths/edge.rs:94)"); rc = RL_ERR_UNSUPPORTED; break; }
         if ((rc = upload(ctx, flat.mesh_cdf, &ds.mesh_cdf)) != RL_OK) break;
         ds.n_meshes = (uint32_t)flat.meshes.size();
@@ -1626,12 +1638,12 @@ extern "C" int rl_debug_numerics(int device, size_t n, const float* a, const flo
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return RL_ERR_NO_DEVICE;
     HIP_OK(hipSetDevice(device));
     float *d_a, *d_b, *d_out;
-    HIP_OK(hipMalloc((void**)&d_a, n * 4)); HIP_OK(hipMalloc((void**)&d_b, n * 4)); HIP_OK(hipMalloc((void**)&d_out, 8 * n * 4));
+    HIP_OK(hipMalloc((void**)&d_a, n * 4)); HIP_OK(hipMalloc((void**)&d_b, n * 4)); HIP_OK(hipMalloc((void**)&d_out, 10 * n * 4));
     HIP_OK(hipMemcpy(d_a, a, n * 4, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(d_b, b, n * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_numerics_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (unsigned)n, d_a, d_b, d_out, d_out + n, d_out + 2 * n,
-                       d_out + 3 * n, d_out + 4 * n, d_out + 5 * n, d_out + 6 * n, d_out + 7 * n);
+                       d_out + 3 * n, d_out + 4 * n, d_out + 5 * n, d_out + 6 * n, d_out + 7 * n, d_out + 8 * n, d_out + 9 * n);
     HIP_OK(hipDeviceSynchronize());
-    HIP_OK(hipMemcpy(out8, d_out, 8 * n * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(out8, d_out, 10 * n * 4, hipMemcpyDeviceToHost));
     hipFree(d_a); hipFree(d_b); hipFree(d_out);
     return RL_OK;
 }

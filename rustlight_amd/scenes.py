@@ -18,6 +18,8 @@ import math
 from dataclasses import dataclass, field
 from typing import List, Optional
 
+import os
+
 import numpy as np
 
 # rl_bsdf_type / rl_tex_type / rl_microfacet_type (include/rustlight_amd.h)
@@ -84,6 +86,7 @@ class SceneData:
     bitmaps: list = field(default_factory=list)
     lights: list = field(default_factory=list)           # [{"type": "point"|"directional", "a": position|direction, "intensity": rgb}]
     environment: Optional[tuple] = None                  # EnvironmentLightColor::Constant(rgb)
+    environment_map: Optional[np.ndarray] = None         # EnvironmentLightColor::Texture: H x W x 3 lat-long image (z up)
 
     @property
     def n_triangles(self) -> int:
@@ -193,6 +196,31 @@ def cbox_other_lights(width: int = 64, height: int = 64, point=True, directional
         sd.lights.append({"type": "directional", "a": tuple(float(np.float32(x)) for x in d), "intensity": (1.0, 1.0, 1.2)})
     if environment:
         sd.environment = (0.3, 0.4, 0.6)
+    return sd
+
+
+def sky_map(w: int = 32, h: int = 16) -> np.ndarray:
+    """A small procedural lat-long environment (H x W x 3, row 0 = +z): blue-ish gradient, a bright 2 x 2 'sun',
+    one exactly black row and a black column so the zero-probability bins of the Distribution2D are exercised."""
+    img = np.zeros((h, w, 3), np.float32)
+    for y in range(h):
+        t = np.float32(y) / np.float32(h - 1)
+        img[y, :, 0] = np.float32(0.15) + np.float32(0.25) * t
+        img[y, :, 1] = np.float32(0.25) + np.float32(0.2) * t
+        img[y, :, 2] = np.float32(0.6) - np.float32(0.3) * t
+    img[h // 4: h // 4 + 2, w // 3: w // 3 + 2] = (40.0, 36.0, 30.0)
+    img[h - 3, :] = 0.0
+    img[:, w - 5] = 0.0
+    return img
+
+
+def sky_scene(width: int = 64, height: int = 64, keep_area_light: bool = False) -> SceneData:
+    """The Cornell floor and boxes under a textured environment (SURVEY.md a24, EnvironmentLightColor::Texture).
+    The lat-long parameterisation is z-up while the fixture is y-up; the reference applies no transform, neither do we."""
+    sd = cbox(width, height)
+    keep = {"Floor", "ShortBox", "TallBox"} | ({"Light"} if keep_area_light else set())
+    sd.meshes = [m for m in sd.meshes if m.name in keep]
+    sd.environment_map = sky_map()
     return sd
 
 
@@ -344,6 +372,22 @@ def write_pbrt(scene: SceneData, path: str) -> None:
                       f'NamedMaterial "{m.name}"', shape, "AttributeEnd"]
         else:
             lines += [f'NamedMaterial "{m.name}"', shape]
+    for lt in scene.lights:
+        i = lt["intensity"]
+        if lt["type"] == "point":
+            lines.append(f'LightSource "point" "rgb I" [ {i[0]!r} {i[1]!r} {i[2]!r} ] "point from" [ {lt["a"][0]!r} {lt["a"][1]!r} {lt["a"][2]!r} ]')
+        else:   # DirectionalLight.direction = (to - from).normalize(): write the direction itself as `to`
+            lines.append(f'LightSource "distant" "rgb L" [ {i[0]!r} {i[1]!r} {i[2]!r} ] "point from" [ 0 0 0 ] "point to" [ {lt["a"][0]!r} {lt["a"][1]!r} {lt["a"][2]!r} ]')
+    if scene.environment is not None:
+        e = scene.environment
+        lines.append(f'LightSource "infinite" "rgb L" [ {e[0]!r} {e[1]!r} {e[2]!r} ]')
+    if scene.environment_map is not None:   # Spectrum::Mapname: a PFM next to the scene file (rows bottom-up, little endian)
+        em = np.ascontiguousarray(scene.environment_map, np.float32)
+        name = os.path.splitext(os.path.basename(path))[0] + "_env.pfm"
+        with open(os.path.join(os.path.dirname(path) or ".", name), "wb") as f:
+            f.write(f"PF\n{em.shape[1]} {em.shape[0]}\n-1.0\n".encode())
+            f.write(em[::-1].astype("<f4").tobytes())
+        lines.append(f'LightSource "infinite" "string mapname" [ "{name}" ]')
     lines.append("WorldEnd")
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")

@@ -82,6 +82,24 @@ def test_pbrt_loader_round_trip(built, tmp_path):
     np.testing.assert_array_equal(loaded.camera_ray(5.5, 7.25)[1], direct.camera_ray(5.5, 7.25)[1])
 
 
+def test_pbrt_loader_lights_and_environment_map(built, tmp_path):
+    """LightSource point / distant / infinite (rgb L and mapname -> Bitmap::read_pfm + new_texture), scene_loader.rs:205-275."""
+    sd = scenes.cbox_other_lights(64, 48)
+    p = str(tmp_path / "lights.pbrt")
+    scenes.write_pbrt(sd, p)
+    assert api.Scene.load_pbrt(p).counts() == api.Scene(sd).counts() == {"meshes": 8, "triangles": 36, "emitters": 4}
+    sky = scenes.sky_scene(64, 48, keep_area_light=True)
+    p = str(tmp_path / "sky.pbrt")
+    scenes.write_pbrt(sky, p)
+    np.testing.assert_array_equal(api.load_pfm(str(tmp_path / "sky_env.pfm")), sky.environment_map)
+    loaded, direct = api.Scene.load_pbrt(p), api.Scene(sky)
+    assert loaded.counts() == direct.counts() == {"meshes": 4, "triangles": 28, "emitters": 2}
+    np.testing.assert_array_equal(loaded.debug_emitters_cdf(), direct.debug_emitters_cdf())
+    with pytest.raises(api.RustlightError):
+        open(str(tmp_path / "bad.pbrt"), "w").write('WorldBegin\nLightSource "infinite" "string mapname" [ "missing.pfm" ]\nWorldEnd\n')
+        api.Scene.load_pbrt(str(tmp_path / "bad.pbrt"))
+
+
 def test_repo_cbox_scene_file_matches_fixture(built):
     loaded = api.Scene.load_pbrt(os.path.join(ROOT, "data", "cbox.pbrt"))
     direct = api.Scene(scenes.cbox(512, 512))

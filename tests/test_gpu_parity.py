@@ -39,6 +39,8 @@ def test_numerics_contract_on_device(built):
     np.testing.assert_array_equal(out[5], batch(2, a))
     np.testing.assert_array_equal(out[6], batch(3, np.abs(a)))
     np.testing.assert_array_equal(out[7], batch(4, np.abs(a), b))
+    np.testing.assert_array_equal(out[8], batch(5, a * np.float32(0.15)))
+    np.testing.assert_array_equal(out[9], batch(6, a, b))
     assert out[0][-3] != 0.0          # 1e-39 / 0.5 stays a denormal
 
 
@@ -186,10 +188,22 @@ def test_point_directional_environment_emitters_parity(built, combo):
         _assert_parity(*_render_pair(sd, **kw))
 
 
+@pytest.mark.parametrize("pipeline", [api.PIPELINE_WAVEFRONT, api.PIPELINE_FUSED])
+@pytest.mark.parametrize("keep_area_light", [False, True])
+def test_textured_environment_parity(built, keep_area_light, pipeline):
+    """SURVEY.md a24 remainder: EnvironmentLightColor::Texture (lat-long image, Distribution2D importance sampling, MIS
+    through direct_pdf of the hit direction), alone and next to the mesh light, all three strategies."""
+    sd = scenes.sky_scene(48, 40, keep_area_light=keep_area_light)
+    for kw in (dict(spp=4), dict(spp=2, strategy=api.STRATEGY_EMITTER), dict(spp=2, strategy=api.STRATEGY_BSDF, max_depth=6), dict(spp=2, min_depth=1, stream_mode=api.STREAM_REFERENCE_ORDER)):
+        out = _render_pair(sd, pipeline=pipeline, **kw)
+        _assert_parity(*out)
+        assert out[0].mean() > 0.02
+
+
 @pytest.mark.parametrize("mode", [api.STREAM_PER_SAMPLE, api.STREAM_REFERENCE_ORDER])
 def test_ao_and_direct_integrators_parity(built, mode):
     """`ao` and `direct` through the same tiling driver, bit-exact vs the oracle."""
-    for sd in (scenes.cbox(48, 40), scenes.cbox_other_lights(40, 40), scenes.living_room(48, 32, n_spheres=20, tess=8)):
+    for sd in (scenes.cbox(48, 40), scenes.cbox_other_lights(40, 40), scenes.sky_scene(40, 40, keep_area_light=True), scenes.living_room(48, 32, n_spheres=20, tess=8)):
         ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
         seeds = api.IndependentSampler(4).block_seeds(sd.width, sd.height)
         for kw in (dict(max_distance=1.0), dict(max_distance=None), dict(max_distance=0.3, normal_correction=True)):
