@@ -145,6 +145,12 @@ int rl_scene_build_emitters(rl_scene* scene);
  * PBRT loader consumes (src/scene_loader.rs:77-315): Transform/LookAt/Camera perspective/Film,
  * MakeNamedMaterial matte|..., NamedMaterial, Shape trianglemesh, AreaLightSource diffuse. */
 int rl_scene_load_pbrt(const char* path, int use_shading_normals, rl_scene** out);
+/* MTSSceneLoader::load (src/scene_loader.rs:318-795): the Mitsuba 0.5/0.6 XML subset the reference consumes — one perspective
+ * sensor (flip = true), shapes obj | ply | serialized | rectangle | sphere with bsdf / area emitter / toWorld, bsdf_mts
+ * materials (src/bsdfs/mod.rs:499-612), point emitters, the first homogeneous medium.  Needs rl_scene_build_emitters(). */
+int rl_scene_load_mitsuba(const char* path, int use_shading_normals, rl_scene** out);
+/* SceneLoaderManager::load (src/scene_loader.rs:27-58): picks the loader by extension (.pbrt | .xml). */
+int rl_scene_load(const char* path, int use_shading_normals, rl_scene** out);
 
 int rl_scene_image_size(const rl_scene* scene, uint32_t* width, uint32_t* height);
 int rl_scene_counts(const rl_scene* scene, uint64_t* n_meshes, uint64_t* n_triangles,
@@ -289,6 +295,8 @@ int rl_visible_batch(rl_context* ctx, size_t n, const float* p0, const float* p1
 /* Bitmap::read_pfm (src/structure.rs:563-607): colour PFM, little endian ("-1.0"), rows stored bottom-up and returned
  * top-down, RGB f32.  `rgb == NULL` only reports the size; otherwise `capacity_floats >= 3 * w * h`. */
 int rl_load_pfm(const char* path, uint32_t* width, uint32_t* height, float* rgb, size_t capacity_floats);
+/* Bitmap::read (src/structure.rs:670-683): by extension — .pfm, or .png (8/16-bit, value / 255 as read_ldr_image does). */
+int rl_load_image(const char* path, uint32_t* width, uint32_t* height, float* rgb, size_t capacity_floats);
 /* Bitmap::save_pfm (src/structure.rs:547-560): bottom-up rows, |value|, little-endian, "-1.0" scale. */
 int rl_save_pfm(const char* path, const float* rgb, uint32_t width, uint32_t height);
 

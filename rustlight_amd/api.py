@@ -29,10 +29,10 @@ PIPELINE_AUTO, PIPELINE_WAVEFRONT, PIPELINE_FUSED = 0, 1, 2
 PUBLIC_SYMBOLS = [
     "rl_scene_create", "rl_scene_destroy", "rl_scene_set_camera", "rl_scene_scale_image", "rl_scene_add_mesh",
     "rl_scene_add_bitmap", "rl_scene_set_medium", "rl_scene_add_point_light", "rl_scene_add_directional_light",
-    "rl_scene_set_environment", "rl_scene_set_environment_map", "rl_scene_build_emitters", "rl_scene_load_pbrt",
+    "rl_scene_set_environment", "rl_scene_set_environment_map", "rl_scene_build_emitters", "rl_scene_load_pbrt", "rl_scene_load_mitsuba", "rl_scene_load",
     "rl_scene_image_size", "rl_scene_counts", "rl_sampler_seed", "rl_sampler_next_u64", "rl_sampler_next_f32",
     "rl_path_params_default", "rl_context_create", "rl_context_destroy", "rl_last_error", "rl_block_count",
-    "rl_generate_block_seeds", "rl_render_path", "rl_render_ao", "rl_render_direct", "rl_trace_batch", "rl_visible_batch", "rl_load_pfm", "rl_save_pfm", "rl_save_png", "rl_save_exr", "rl_save_image", "rl_build_info",
+    "rl_generate_block_seeds", "rl_render_path", "rl_render_ao", "rl_render_direct", "rl_trace_batch", "rl_visible_batch", "rl_load_pfm", "rl_load_image", "rl_save_pfm", "rl_save_png", "rl_save_exr", "rl_save_image", "rl_build_info",
 ]
 
 
@@ -72,6 +72,8 @@ def lib():
     L.rl_scene_set_environment.argtypes = [vp, f32p]
     L.rl_scene_set_environment_map.argtypes = [vp, C.c_uint32, C.c_uint32, f32p]
     L.rl_scene_load_pbrt.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.rl_scene_load_mitsuba.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.rl_scene_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
     L.rl_scene_image_size.argtypes = [vp, u32p, u32p]
     L.rl_scene_counts.argtypes = [vp, u64p, u64p, u64p]
     L.rl_sampler_seed.argtypes = [C.POINTER(abi.Sampler), C.c_uint64, C.c_int]
@@ -178,6 +180,19 @@ class Scene:
     def load_pbrt(cls, path: str, use_shading_normals: bool = True) -> "Scene":
         h = C.c_void_p()
         _check(lib().rl_scene_load_pbrt(path.encode(), int(use_shading_normals), C.byref(h)))
+        return cls(None, handle=h)
+
+    @classmethod
+    def load_mitsuba(cls, path: str, use_shading_normals: bool = True) -> "Scene":
+        h = C.c_void_p()
+        _check(lib().rl_scene_load_mitsuba(path.encode(), int(use_shading_normals), C.byref(h)))
+        return cls(None, handle=h)
+
+    @classmethod
+    def load(cls, path: str, use_shading_normals: bool = True) -> "Scene":
+        """SceneLoaderManager::load: .pbrt or .xml by extension (src/scene_loader.rs:27-58)."""
+        h = C.c_void_p()
+        _check(lib().rl_scene_load(path.encode(), int(use_shading_normals), C.byref(h)))
         return cls(None, handle=h)
 
     def set_medium(self, sigma_a, sigma_s, phase=S.PHASE_ISOTROPIC, g=0.0):
@@ -353,15 +368,24 @@ class IntegratorPathTracing:
         return img
 
 
+def _load_with(fn_name: str, path: str) -> np.ndarray:
+    w, h = C.c_uint32(), C.c_uint32()
+    fn = getattr(lib(), fn_name)
+    fn.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.c_size_t]
+    _check(fn(path.encode(), C.byref(w), C.byref(h), None, 0))
+    out = np.zeros((h.value, w.value, 3), np.float32)
+    _check(fn(path.encode(), C.byref(w), C.byref(h), abi.fptr(out), out.size))
+    return out
+
+
 def load_pfm(path: str) -> np.ndarray:
     """Bitmap::read_pfm (src/structure.rs:563-607) -> H x W x 3 float32, top row first."""
-    w, h = C.c_uint32(), C.c_uint32()
-    L = lib()
-    L.rl_load_pfm.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.c_size_t]
-    _check(L.rl_load_pfm(path.encode(), C.byref(w), C.byref(h), None, 0))
-    out = np.zeros((h.value, w.value, 3), np.float32)
-    _check(L.rl_load_pfm(path.encode(), C.byref(w), C.byref(h), abi.fptr(out), out.size))
-    return out
+    return _load_with("rl_load_pfm", path)
+
+
+def load_image(path: str) -> np.ndarray:
+    """Bitmap::read (src/structure.rs:670-683): .pfm / .png -> H x W x 3 float32."""
+    return _load_with("rl_load_image", path)
 
 
 def save_pfm(path: str, img: np.ndarray):

@@ -1,6 +1,6 @@
 // cli.cpp — `rustlight-amd`: the reference CLI's flags for the `path` subcommand (examples/cli.rs:
 // global flags 106-145, `path` 162-169, medium 355-399, sampler 876-896, run/save 898-923).
-//   rustlight-amd <scene.pbrt> -n SPP -o out.pfm [-r independent:SEED] [-m s[:a[:g]]] [-s SCALE] [-t N]
+//   rustlight-amd <scene.pbrt|scene.xml> -n SPP -o out.pfm [-r independent:SEED] [-m s[:a[:g]]] [-s SCALE] [-t N]
 //                 [--device D] [--stream-mode reference|per-sample]
 //                 path [-m MAX|inf] [-n MIN] [-r RR|inf] [-x] [-s all|bsdf|emitter]
 //               | ao [-d DIST|inf] [-n]            (examples/cli.rs:149-154)
@@ -75,7 +75,7 @@ int main(int argc, char** argv) {
         }
     }
     if (scene_path.empty() || output.empty() || !have_cmd) {
-        std::fprintf(stderr, "usage: rustlight-amd <scene.pbrt> -n SPP -o out.pfm [-r independent:SEED] [-m s[:a[:g]]] path [-m max] [-n min] [-r rr] [-x] [-s all|bsdf|emitter]\n");
+        std::fprintf(stderr, "usage: rustlight-amd <scene.pbrt|scene.xml> -n SPP -o out.pfm [-r independent:SEED] [-m s[:a[:g]]] path [-m max] [-n min] [-r rr] [-x] [-s all|bsdf|emitter]\n");
         return 2;
     }
     try {

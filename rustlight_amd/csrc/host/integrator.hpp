@@ -37,7 +37,7 @@ struct Scene {
     ~Scene() { rl_scene_destroy(handle); }
     static Scene* load(const std::string& path, bool use_shading_normals = true) {
         rl_scene* h = nullptr;
-        int rc = rl_scene_load_pbrt(path.c_str(), use_shading_normals ? 1 : 0, &h);
+        int rc = rl_scene_load(path.c_str(), use_shading_normals ? 1 : 0, &h);   // SceneLoaderManager: .pbrt | .xml
         if (rc != RL_OK) throw std::runtime_error(std::string("error on loading the scene: ") + rl_last_error());
         return new Scene(h);
     }

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../kernels/wavefront.h"
+#include "meshio.h"
 #include "scene.h"
 
 // Bitmap::read_pfm (src/structure.rs:563-607): "PF\n", "W H\n", "-1.0\n" (little endian only), rows stored bottom-up
@@ -44,6 +45,21 @@ int rl_load_pfm(const char* path, uint32_t* width, uint32_t* height, float* rgb,
     if (rgb) {   // rgb == NULL: size query
         if (capacity_floats < data.size()) return RL_ERR_INVALID_ARGUMENT;
         std::memcpy(rgb, data.data(), data.size() * sizeof(float));
+    }
+    return RL_OK;
+}
+
+// Bitmap::read (src/structure.rs:670-683): .pfm or .png by extension, same calling convention as rl_load_pfm
+int rl_load_image(const char* path, uint32_t* width, uint32_t* height, float* rgb, size_t capacity_floats) {
+    if (!path || !width || !height) return RL_ERR_INVALID_ARGUMENT;
+    rl::HostBitmap img;
+    std::string err;
+    int rc = rl::read_image(path, &img, &err);
+    if (rc != RL_OK) { rl_set_error(err); return rc; }
+    *width = img.w; *height = img.h;
+    if (rgb) {
+        if (capacity_floats < img.rgb.size()) return RL_ERR_INVALID_ARGUMENT;
+        std::memcpy(rgb, img.rgb.data(), img.rgb.size() * sizeof(float));
     }
     return RL_OK;
 }

@@ -1,0 +1,385 @@
+// meshio.cpp — mesh and image file readers behind the scene loaders.
+//
+// rustlight delegates these formats to un-vendored crates (tobj 4 for OBJ, pbrt_rs::ply / mitsuba_rs::ply for PLY,
+// mitsuba_rs::serialized, image for LDR bitmaps; Cargo.toml:19-30), so each reader restates the published format and
+// produces what the reference's call sites consume (geometry.rs:13-96, scene_loader.rs:88-93, 392-440, 497-535,
+// structure.rs:563-683):
+//   * OBJ   — `o`/`g` (and a material change) start a model, polygons are fan-triangulated, vertices are re-indexed
+//             per model in order of first use; the MTL gives `Kd` / `map_Kd` for a BSDFDiffuse (missing -> black);
+//   * PLY   — ascii / binary_little_endian / binary_big_endian; vertex x y z [nx ny nz] [u v | s t], face lists
+//             (fan-triangulated);
+//   * serialized — Mitsuba 0.5 `.serialized` (format 0x041C, versions 3 and 4, zlib stream per mesh, offset table);
+//   * images — .pfm (Bitmap::read_pfm) and 8/16-bit non-interlaced .png (value / 255, no gamma: read_ldr_image).
+#include <zlib.h>
+
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+
+#include "meshio.h"
+
+namespace rl {
+namespace {
+
+bool slurp(const std::string& path, std::string* out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::stringstream ss;
+    ss << f.rdbuf();
+    *out = ss.str();
+    return true;
+}
+std::string dir_of(const std::string& path) {
+    size_t s = path.find_last_of('/');
+    return s == std::string::npos ? std::string(".") : path.substr(0, s);
+}
+
+// ---------------------------------------------------------------------------------------------- OBJ / MTL
+struct MtlEntry { bool has_kd = false; float kd[3] = {0, 0, 0}; std::string map_kd; };
+
+void read_mtl(const std::string& path, std::map<std::string, MtlEntry>* out) {
+    std::string src;
+    if (!slurp(path, &src)) return;
+    std::istringstream is(src);
+    std::string line, cur;
+    while (std::getline(is, line)) {
+        std::istringstream ls(line);
+        std::string key;
+        if (!(ls >> key) || key[0] == '#') continue;
+        if (key == "newmtl") { ls >> cur; (*out)[cur] = MtlEntry(); }
+        else if (key == "Kd" && !cur.empty()) { MtlEntry& m = (*out)[cur]; if (ls >> m.kd[0] >> m.kd[1] >> m.kd[2]) m.has_kd = true; }
+        else if (key == "map_Kd" && !cur.empty()) { std::string rest; std::getline(ls, rest); size_t b = rest.find_first_not_of(" \t"); size_t e = rest.find_last_not_of(" \t\r"); if (b != std::string::npos) (*out)[cur].map_kd = rest.substr(b, e - b + 1); }
+    }
+}
+
+struct ObjBuilder {
+    LoadedMesh mesh;
+    std::map<std::tuple<int, int, int>, uint32_t> remap;
+    bool any_vt = false, any_vn = false, all_vt = true, all_vn = true;
+};
+
+}  // namespace
+
+int read_obj(const std::string& path, std::vector<LoadedMesh>* out, std::string* err) {
+    std::string src;
+    if (!slurp(path, &src)) { *err = "cannot open " + path; return RL_ERR_IO; }
+    std::vector<float> V, VT, VN;
+    std::map<std::string, MtlEntry> mtl;
+    std::vector<ObjBuilder> models;
+    std::string cur_name = "unnamed_object", cur_mtl;
+    bool cur_has_mtl = false;
+    auto start_model = [&]() {
+        models.emplace_back();
+        models.back().mesh.name = cur_name;
+        if (cur_has_mtl) {
+            auto it = mtl.find(cur_mtl);
+            LoadedMesh& m = models.back().mesh;
+            m.has_material = true;
+            if (it != mtl.end()) { m.has_kd = it->second.has_kd; std::memcpy(m.kd, it->second.kd, sizeof(m.kd)); if (!it->second.map_kd.empty()) m.kd_map = dir_of(path) + "/" + it->second.map_kd; }
+        }
+    };
+    std::istringstream is(src);
+    std::string line;
+    while (std::getline(is, line)) {
+        std::istringstream ls(line);
+        std::string key;
+        if (!(ls >> key) || key[0] == '#') continue;
+        if (key == "v") { float a, b, c; ls >> a >> b >> c; V.insert(V.end(), {a, b, c}); }
+        else if (key == "vt") { float a = 0, b = 0; ls >> a >> b; VT.insert(VT.end(), {a, b}); }
+        else if (key == "vn") { float a, b, c; ls >> a >> b >> c; VN.insert(VN.end(), {a, b, c}); }
+        else if (key == "mtllib") { std::string f; ls >> f; read_mtl(dir_of(path) + "/" + f, &mtl); }
+        else if (key == "o" || key == "g") {
+            std::string n; std::getline(ls, n);
+            size_t b = n.find_first_not_of(" \t"), e = n.find_last_not_of(" \t\r");
+            cur_name = b == std::string::npos ? std::string("unnamed_object") : n.substr(b, e - b + 1);
+            if (models.empty() || !models.back().mesh.idx.empty()) start_model(); else models.back().mesh.name = cur_name;
+        } else if (key == "usemtl") {
+            ls >> cur_mtl; cur_has_mtl = true;
+            if (models.empty() || !models.back().mesh.idx.empty()) start_model();
+            else { models.pop_back(); start_model(); }
+        } else if (key == "f") {
+            if (models.empty()) start_model();
+            ObjBuilder& mb = models.back();
+            std::vector<uint32_t> poly;
+            std::string tok;
+            while (ls >> tok) {
+                int vi = 0, ti = 0, ni = 0;
+                const char* p = tok.c_str();
+                vi = (int)std::strtol(p, const_cast<char**>(&p), 10);
+                if (*p == '/') { p++; if (*p != '/') ti = (int)std::strtol(p, const_cast<char**>(&p), 10); if (*p == '/') { p++; ni = (int)std::strtol(p, const_cast<char**>(&p), 10); } }
+                if (vi < 0) vi = (int)(V.size() / 3) + vi + 1;
+                if (ti < 0) ti = (int)(VT.size() / 2) + ti + 1;
+                if (ni < 0) ni = (int)(VN.size() / 3) + ni + 1;
+                if (vi <= 0 || (size_t)vi > V.size() / 3 || (size_t)ti > VT.size() / 2 || (size_t)ni > VN.size() / 3) { *err = "OBJ index out of range in " + path; return RL_ERR_PARSE; }
+                auto key3 = std::make_tuple(vi, ti, ni);
+                auto it = mb.remap.find(key3);
+                uint32_t id;
+                if (it == mb.remap.end()) {
+                    id = (uint32_t)(mb.mesh.pos.size() / 3);
+                    mb.remap[key3] = id;
+                    mb.mesh.pos.insert(mb.mesh.pos.end(), {V[3 * (vi - 1)], V[3 * (vi - 1) + 1], V[3 * (vi - 1) + 2]});
+                    if (ti) { mb.any_vt = true; mb.mesh.uv.insert(mb.mesh.uv.end(), {VT[2 * (ti - 1)], VT[2 * (ti - 1) + 1]}); } else { mb.all_vt = false; mb.mesh.uv.insert(mb.mesh.uv.end(), {0.0f, 0.0f}); }
+                    if (ni) { mb.any_vn = true; mb.mesh.nrm.insert(mb.mesh.nrm.end(), {VN[3 * (ni - 1)], VN[3 * (ni - 1) + 1], VN[3 * (ni - 1) + 2]}); } else { mb.all_vn = false; mb.mesh.nrm.insert(mb.mesh.nrm.end(), {0.0f, 0.0f, 0.0f}); }
+                } else id = it->second;
+                poly.push_back(id);
+            }
+            for (size_t k = 1; k + 1 < poly.size(); k++) mb.mesh.idx.insert(mb.mesh.idx.end(), {poly[0], poly[k], poly[k + 1]});
+        }
+    }
+    for (ObjBuilder& mb : models) {
+        if (mb.mesh.idx.empty()) continue;
+        if (!(mb.any_vt && mb.all_vt)) mb.mesh.uv.clear();
+        if (!(mb.any_vn && mb.all_vn)) mb.mesh.nrm.clear();
+        out->push_back(std::move(mb.mesh));
+    }
+    if (out->empty()) { *err = "no faces in " + path; return RL_ERR_PARSE; }
+    return RL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- PLY
+namespace {
+struct PlyProp { std::string name; int type = 0; bool is_list = false; int count_type = 0; };   // type: bytes, sign encodes float
+int ply_type(const std::string& t) {   // size in bytes; floats are negative
+    if (t == "char" || t == "int8" || t == "uchar" || t == "uint8") return 1;
+    if (t == "short" || t == "int16" || t == "ushort" || t == "uint16") return 2;
+    if (t == "int" || t == "int32" || t == "uint" || t == "uint32") return 4;
+    if (t == "float" || t == "float32") return -4;
+    if (t == "double" || t == "float64") return -8;
+    return 0;
+}
+bool ply_signed(const std::string& t) { return t == "char" || t == "int8" || t == "short" || t == "int16" || t == "int" || t == "int32"; }
+struct PlyReader {
+    const std::string& src; size_t pos; int fmt;   // 0 ascii, 1 little, 2 big
+    bool ok = true;
+    double read(int type, bool sgn) {
+        if (fmt == 0) {
+            while (pos < src.size() && std::isspace((unsigned char)src[pos])) pos++;
+            char* e = nullptr;
+            double v = std::strtod(src.c_str() + pos, &e);
+            if (e == src.c_str() + pos) { ok = false; return 0.0; }
+            pos = (size_t)(e - src.c_str());
+            return v;
+        }
+        int n = type < 0 ? -type : type;
+        if (pos + (size_t)n > src.size()) { ok = false; return 0.0; }
+        unsigned char b[8];
+        for (int i = 0; i < n; i++) b[i] = (unsigned char)src[pos + (fmt == 1 ? i : n - 1 - i)];
+        pos += (size_t)n;
+        if (type == -4) { float f; std::memcpy(&f, b, 4); return f; }
+        if (type == -8) { double d; std::memcpy(&d, b, 8); return d; }
+        unsigned long long u = 0;
+        for (int i = n - 1; i >= 0; i--) u = (u << 8) | b[i];
+        if (sgn) { if (n == 1) return (double)(signed char)u; if (n == 2) return (double)(short)u; return (double)(int)u; }
+        return (double)u;
+    }
+};
+}  // namespace
+
+int read_ply(const std::string& path, LoadedMesh* out, std::string* err) {
+    std::string src;
+    if (!slurp(path, &src)) { *err = "cannot open " + path; return RL_ERR_IO; }
+    size_t pos = 0;
+    auto next_line = [&](std::string* l) { size_t e = src.find('\n', pos); if (e == std::string::npos) return false; *l = src.substr(pos, e - pos); if (!l->empty() && l->back() == '\r') l->pop_back(); pos = e + 1; return true; };
+    std::string line;
+    if (!next_line(&line) || line != "ply") { *err = path + ": not a PLY file"; return RL_ERR_PARSE; }
+    struct Elem { std::string name; size_t count; std::vector<PlyProp> props; std::vector<bool> sgn; };
+    std::vector<Elem> elems;
+    int fmt = -1;
+    while (next_line(&line)) {
+        std::istringstream ls(line);
+        std::string key;
+        ls >> key;
+        if (key == "format") { std::string f; ls >> f; fmt = f == "ascii" ? 0 : (f == "binary_little_endian" ? 1 : (f == "binary_big_endian" ? 2 : -1)); }
+        else if (key == "element") { Elem e; ls >> e.name >> e.count; elems.push_back(e); }
+        else if (key == "property" && !elems.empty()) {
+            PlyProp p; std::string t; ls >> t;
+            bool sg;
+            if (t == "list") { std::string ct, it; ls >> ct >> it >> p.name; p.is_list = true; p.count_type = ply_type(ct); p.type = ply_type(it); sg = ply_signed(it); }
+            else { ls >> p.name; p.type = ply_type(t); sg = ply_signed(t); }
+            if (p.type == 0) { *err = path + ": unknown PLY property type"; return RL_ERR_PARSE; }
+            elems.back().props.push_back(p); elems.back().sgn.push_back(sg);
+        } else if (key == "end_header") break;
+    }
+    if (fmt < 0) { *err = path + ": unsupported PLY format"; return RL_ERR_PARSE; }
+    PlyReader rd{src, pos, fmt};
+    out->name = "";
+    for (const Elem& e : elems) {
+        int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1, iu = -1, iv = -1;
+        for (size_t k = 0; k < e.props.size(); k++) {
+            const std::string& n = e.props[k].name;
+            if (n == "x") ix = (int)k; else if (n == "y") iy = (int)k; else if (n == "z") iz = (int)k;
+            else if (n == "nx") inx = (int)k; else if (n == "ny") iny = (int)k; else if (n == "nz") inz = (int)k;
+            else if (n == "u" || n == "s") iu = (int)k; else if (n == "v" || n == "t") iv = (int)k;
+        }
+        const bool is_vertex = e.name == "vertex", is_face = e.name == "face";
+        if (is_vertex && (ix < 0 || iy < 0 || iz < 0)) { *err = path + ": vertex element without x y z"; return RL_ERR_PARSE; }
+        std::vector<double> vals(e.props.size());
+        for (size_t i = 0; i < e.count && rd.ok; i++) {
+            for (size_t k = 0; k < e.props.size() && rd.ok; k++) {
+                const PlyProp& p = e.props[k];
+                if (!p.is_list) { vals[k] = rd.read(p.type, e.sgn[k]); continue; }
+                size_t n = (size_t)rd.read(p.count_type, false);
+                std::vector<uint32_t> poly(n);
+                for (size_t j = 0; j < n && rd.ok; j++) poly[j] = (uint32_t)rd.read(p.type, e.sgn[k]);
+                if (is_face && (p.name == "vertex_indices" || p.name == "vertex_index"))
+                    for (size_t j = 1; j + 1 < n; j++) out->idx.insert(out->idx.end(), {poly[0], poly[j], poly[j + 1]});
+            }
+            if (is_vertex) {
+                out->pos.insert(out->pos.end(), {(float)vals[ix], (float)vals[iy], (float)vals[iz]});
+                if (inx >= 0 && iny >= 0 && inz >= 0) out->nrm.insert(out->nrm.end(), {(float)vals[inx], (float)vals[iny], (float)vals[inz]});
+                if (iu >= 0 && iv >= 0) out->uv.insert(out->uv.end(), {(float)vals[iu], (float)vals[iv]});
+            }
+        }
+    }
+    if (!rd.ok || out->pos.empty() || out->idx.empty()) { *err = path + ": truncated or empty PLY"; return RL_ERR_PARSE; }
+    for (uint32_t i : out->idx) if (i >= out->pos.size() / 3) { *err = path + ": PLY face index out of range"; return RL_ERR_PARSE; }
+    return RL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- zlib helper
+namespace {
+bool inflate_all(const unsigned char* data, size_t n, std::vector<unsigned char>* out) {
+    z_stream zs;
+    std::memset(&zs, 0, sizeof(zs));
+    if (inflateInit(&zs) != Z_OK) return false;
+    zs.next_in = const_cast<unsigned char*>(data);
+    zs.avail_in = (uInt)n;
+    unsigned char buf[1 << 16];
+    int rc;
+    do {
+        zs.next_out = buf; zs.avail_out = sizeof(buf);
+        rc = inflate(&zs, Z_NO_FLUSH);
+        if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&zs); return false; }
+        out->insert(out->end(), buf, buf + (sizeof(buf) - zs.avail_out));
+    } while (rc != Z_STREAM_END);
+    inflateEnd(&zs);
+    return true;
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------- Mitsuba .serialized
+int read_serialized(const std::string& path, int shape_index, LoadedMesh* out, std::string* err) {
+    std::string src;
+    if (!slurp(path, &src)) { *err = "cannot open " + path; return RL_ERR_IO; }
+    auto u16 = [&](size_t o) { return (unsigned)(unsigned char)src[o] | ((unsigned)(unsigned char)src[o + 1] << 8); };
+    auto rd = [&](size_t o, int n) { unsigned long long v = 0; for (int i = n - 1; i >= 0; i--) v = (v << 8) | (unsigned char)src[o + i]; return v; };
+    if (src.size() < 8 || u16(0) != 0x041C) { *err = path + ": not a Mitsuba serialized file"; return RL_ERR_PARSE; }
+    const unsigned version = u16(2);
+    if (version != 3 && version != 4) { *err = path + ": unsupported serialized version"; return RL_ERR_PARSE; }
+    const unsigned n_meshes = (unsigned)rd(src.size() - 4, 4);
+    const int osz = version == 4 ? 8 : 4;
+    if (shape_index < 0 || (unsigned)shape_index >= n_meshes || src.size() < 4 + (size_t)osz * n_meshes) { *err = path + ": shape index out of range"; return RL_ERR_PARSE; }
+    const size_t table = src.size() - 4 - (size_t)osz * n_meshes;
+    const size_t begin = (size_t)rd(table + (size_t)osz * shape_index, osz);
+    const size_t end = (unsigned)shape_index + 1 < n_meshes ? (size_t)rd(table + (size_t)osz * (shape_index + 1), osz) : table;
+    if (begin + 4 > end || end > src.size() || u16(begin) != 0x041C) { *err = path + ": corrupt offset table"; return RL_ERR_PARSE; }
+    std::vector<unsigned char> raw;
+    if (!inflate_all(reinterpret_cast<const unsigned char*>(src.data()) + begin + 4, end - begin - 4, &raw)) { *err = path + ": zlib stream error"; return RL_ERR_PARSE; }
+    size_t p = 0;
+    auto need = [&](size_t n) { return p + n <= raw.size(); };
+    if (!need(4)) { *err = path + ": truncated mesh"; return RL_ERR_PARSE; }
+    unsigned flags; std::memcpy(&flags, &raw[p], 4); p += 4;
+    if (version == 4) { while (p < raw.size() && raw[p]) out->name.push_back((char)raw[p++]); p++; }
+    if (!need(16)) { *err = path + ": truncated mesh"; return RL_ERR_PARSE; }
+    unsigned long long nv, nt; std::memcpy(&nv, &raw[p], 8); std::memcpy(&nt, &raw[p + 8], 8); p += 16;
+    const bool dbl = (flags & 0x2000u) != 0;
+    const size_t fs = dbl ? 8 : 4;
+    auto read_floats = [&](size_t count, std::vector<float>* dst) {
+        if (!need(count * fs)) return false;
+        dst->resize(count);
+        for (size_t i = 0; i < count; i++) { if (dbl) { double d; std::memcpy(&d, &raw[p + i * 8], 8); (*dst)[i] = (float)d; } else std::memcpy(&(*dst)[i], &raw[p + i * 4], 4); }
+        p += count * fs;
+        return true;
+    };
+    std::vector<float> skip;
+    bool ok = read_floats((size_t)nv * 3, &out->pos);
+    if (ok && (flags & 0x0001u)) ok = read_floats((size_t)nv * 3, &out->nrm);
+    if (ok && (flags & 0x0002u)) ok = read_floats((size_t)nv * 2, &out->uv);
+    if (ok && (flags & 0x0008u)) ok = read_floats((size_t)nv * 3, &skip);
+    const size_t is = nv > 0xFFFFFFFFull ? 8 : 4;
+    if (!ok || !need((size_t)nt * 3 * is)) { *err = path + ": truncated mesh"; return RL_ERR_PARSE; }
+    out->idx.resize((size_t)nt * 3);
+    for (size_t i = 0; i < (size_t)nt * 3; i++) { unsigned long long v = 0; std::memcpy(&v, &raw[p + i * is], is); if (v >= nv) { *err = path + ": index out of range"; return RL_ERR_PARSE; } out->idx[i] = (uint32_t)v; }
+    return RL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- images
+namespace {
+int read_png(const std::string& path, HostBitmap* out, std::string* err) {
+    std::string src;
+    if (!slurp(path, &src)) { *err = "cannot open " + path; return RL_ERR_IO; }
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (src.size() < 8 || std::memcmp(src.data(), sig, 8) != 0) { *err = path + ": not a PNG"; return RL_ERR_PARSE; }
+    auto be32 = [&](size_t o) { return ((unsigned)(unsigned char)src[o] << 24) | ((unsigned)(unsigned char)src[o + 1] << 16) | ((unsigned)(unsigned char)src[o + 2] << 8) | (unsigned)(unsigned char)src[o + 3]; };
+    unsigned w = 0, h = 0, depth = 0, ctype = 0, interlace = 0;
+    std::vector<unsigned char> idat, palette;
+    for (size_t p = 8; p + 12 <= src.size();) {
+        unsigned len = be32(p);
+        std::string type = src.substr(p + 4, 4);
+        if (p + 12 + len > src.size()) break;
+        const unsigned char* d = reinterpret_cast<const unsigned char*>(src.data()) + p + 8;
+        if (type == "IHDR" && len >= 13) { w = be32(p + 8); h = be32(p + 12); depth = d[8]; ctype = d[9]; interlace = d[12]; }
+        else if (type == "PLTE") palette.assign(d, d + len);
+        else if (type == "IDAT") idat.insert(idat.end(), d, d + len);
+        else if (type == "IEND") break;
+        p += 12 + len;
+    }
+    const int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!w || !h || !channels || interlace || (depth != 8 && depth != 16) || (ctype == 3 && depth != 8)) { *err = path + ": unsupported PNG variant (8/16-bit non-interlaced only)"; return RL_ERR_UNSUPPORTED; }
+    std::vector<unsigned char> raw;
+    if (!inflate_all(idat.data(), idat.size(), &raw)) { *err = path + ": zlib stream error"; return RL_ERR_PARSE; }
+    const size_t bpp = (size_t)channels * depth / 8, stride = bpp * w;
+    if (raw.size() < (stride + 1) * h) { *err = path + ": truncated PNG"; return RL_ERR_PARSE; }
+    std::vector<unsigned char> img(stride * h);
+    for (unsigned y = 0; y < h; y++) {
+        const unsigned char* in = &raw[(stride + 1) * y];
+        unsigned char* cur = &img[stride * y];
+        const unsigned char* up = y ? &img[stride * (y - 1)] : nullptr;
+        for (size_t x = 0; x < stride; x++) {
+            int a = x >= bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0, v = in[1 + x];
+            switch (in[0]) {
+                case 1: v += a; break;
+                case 2: v += b; break;
+                case 3: v += (a + b) / 2; break;
+                case 4: { int pa = std::abs(b - c), pb = std::abs(a - c), pc = std::abs(a + b - 2 * c); v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+                default: break;
+            }
+            cur[x] = (unsigned char)v;
+        }
+    }
+    out->w = w; out->h = h;
+    out->rgb.assign((size_t)3 * w * h, 0.0f);
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        unsigned char px[4] = {0, 0, 0, 255};
+        for (int c = 0; c < channels; c++) px[c] = img[i * bpp + (size_t)c * depth / 8];   // 16-bit: the high byte, as image::to_rgb8 does
+        unsigned char r, g, b;
+        if (ctype == 3) { size_t k = (size_t)px[0] * 3; r = k + 2 < palette.size() ? palette[k] : 0; g = k + 2 < palette.size() ? palette[k + 1] : 0; b = k + 2 < palette.size() ? palette[k + 2] : 0; }
+        else if (channels <= 2) r = g = b = px[0];
+        else { r = px[0]; g = px[1]; b = px[2]; }
+        out->rgb[3 * i] = (float)r / 255.0f; out->rgb[3 * i + 1] = (float)g / 255.0f; out->rgb[3 * i + 2] = (float)b / 255.0f;   // read_ldr_image
+    }
+    return RL_OK;
+}
+}  // namespace
+
+// Bitmap::read (structure.rs:670-683): by extension
+int read_image(const std::string& path, HostBitmap* out, std::string* err) {
+    const size_t dot = path.find_last_of('.');
+    std::string ext = dot == std::string::npos ? std::string() : path.substr(dot + 1);
+    for (char& c : ext) c = (char)std::tolower((unsigned char)c);
+    if (ext == "pfm") {
+        int rc = read_pfm(path.c_str(), &out->w, &out->h, &out->rgb);
+        if (rc != RL_OK) *err = "cannot read " + path;
+        return rc;
+    }
+    if (ext == "png") return read_png(path, out, err);
+    *err = path + ": only .pfm and .png images are read (no EXR / JPEG decoder in this build)";
+    return RL_ERR_UNSUPPORTED;
+}
+
+}  // namespace rl

@@ -3,10 +3,13 @@
 // delegates parsing to the un-vendored `pbrt_rs` crate; this is a from-scratch tokenizer + a small
 // graphics-state machine that produces the same `Scene` content:
 //   * camera  = Camera::new(image_size, Fov::Y(fov), inverse(CTM at `Camera`), flip = false)
-//   * meshes  = every `Shape "trianglemesh"` in file order, points/normals transformed by the CTM
-//   * bsdf    = named / current material: matte, mirror, metal, glass, substrate (constant colours)
+//   * meshes  = every `Shape "trianglemesh"` / `Shape "plymesh"` in file order, then the shapes of every
+//               `ObjectInstance` (scene_loader.rs:170-204), points/normals transformed by instance matrix x shape CTM
+//   * bsdf    = named / current material: matte, mirror, metal, glass, substrate; colours are constants or
+//               `Texture "name" "spectrum" "imagemap"` bitmaps (Bitmap::read: .pfm / .png here)
 //   * emission= `AreaLightSource "diffuse" "rgb L"` active in the current attribute scope
-// Unsupported directives (Include, Texture, ply shapes, LightSource ...) return RL_ERR_UNSUPPORTED.
+//   * lights  = LightSource point / distant / infinite (rgb L or mapname)
+// `Include` is followed; other directives return RL_ERR_UNSUPPORTED.
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -16,6 +19,7 @@
 #include <sstream>
 
 #include "../kernels/wavefront.h"
+#include "meshio.h"
 #include "scene.h"
 
 namespace rl {
@@ -97,8 +101,14 @@ static rl_color_desc constant_color(float r, float g, float b) {
     c.bitmap_id = -1;
     return c;
 }
+// named `Texture ... "imagemap"` bitmaps of the scene being loaded: name -> id from rl_scene_add_bitmap
+static thread_local const std::map<std::string, int>* g_textures = nullptr;
 static rl_color_desc color_param(const std::vector<Param>& ps, const char* name, float dr, float dg, float db) {
     const Param* p = find(ps, name);
+    if (p && p->type == "texture" && !p->strs.empty() && g_textures) {   // Spectrum::Texture(name) -> BSDFColor::Bitmap (bsdfs/mod.rs:227-236)
+        auto it = g_textures->find(p->strs[0]);
+        if (it != g_textures->end()) { rl_color_desc c = constant_color(0, 0, 0); c.type = RL_TEX_BITMAP; c.bitmap_id = it->second; return c; }
+    }
     if (p && p->nums.size() >= 3) return constant_color((float)p->nums[0], (float)p->nums[1], (float)p->nums[2]);
     if (p && p->nums.size() == 1) return constant_color((float)p->nums[0], (float)p->nums[0], (float)p->nums[0]);
     return constant_color(dr, dg, db);
@@ -188,6 +198,38 @@ static Mat4 look_at(const double* v) {
     return w2c;
 }
 
+// a shape as parsed: object-space data + the CTM / material / emission in force at its `Shape` directive
+struct RawShape {
+    std::vector<float> P, N, UV;
+    std::vector<uint32_t> idx;
+    Mat4 ctm = Mat4::identity();
+    bool reverse_orientation = false;
+    rl_bsdf_desc bsdf;
+    bool has_emission = false; float emission[3] = {0, 0, 0};
+};
+
+// PBRTSceneLoader::transform_mesh (scene_loader.rs:88-157): mat = instance matrix * shape matrix
+static int emit_shape(rl_scene* scene, const RawShape& r, const Mat4& instance, bool use_shading_normals) {
+    const Mat4 mat = instance.times(r.ctm);
+    const size_t nv = r.P.size() / 3;
+    std::vector<float> pos(3 * nv), nrm;
+    for (size_t i = 0; i < nv; i++) {   // mat.transform_point(p) (scene_loader.rs:118-121)
+        Vec3 p = mat.xform_point({r.P[3 * i], r.P[3 * i + 1], r.P[3 * i + 2]});
+        pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
+    }
+    if (use_shading_normals && r.N.size() == 3 * nv) {
+        nrm.resize(3 * nv);
+        for (size_t i = 0; i < nv; i++) {   // mat.transform_vector(+-n) (scene_loader.rs:101-116)
+            Vec3 n{r.N[3 * i], r.N[3 * i + 1], r.N[3 * i + 2]};
+            if (r.reverse_orientation) n = {-n.x, -n.y, -n.z};
+            n = mat.xform_vector(n);
+            nrm[3 * i] = n.x; nrm[3 * i + 1] = n.y; nrm[3 * i + 2] = n.z;
+        }
+    }
+    return rl_scene_add_mesh(scene, pos.data(), nv, r.idx.data(), r.idx.size() / 3, nrm.empty() ? nullptr : nrm.data(),
+                             r.UV.size() == 2 * nv ? r.UV.data() : nullptr, &r.bsdf, r.has_emission ? r.emission : nullptr);
+}
+
 }  // namespace
 
 int load_pbrt(const char* path, bool use_shading_normals, rl_scene** out, std::string* err) {
@@ -205,13 +247,18 @@ int load_pbrt(const char* path, bool use_shading_normals, rl_scene** out, std::s
     std::vector<GState> stack;
     GState gs;
     std::map<std::string, rl_bsdf_desc> named;
+    std::map<std::string, int> textures;                       // Texture "name" ... "imagemap" -> bitmap id
+    std::map<std::string, std::vector<RawShape>> objects;      // ObjectBegin "name" ... ObjectEnd
+    std::vector<std::pair<std::string, Mat4>> instances;       // ObjectInstance "name" with the CTM in force
+    std::string cur_object; bool in_object = false;
+    g_textures = &textures;
     rl_scene* scene = new rl_scene();
     uint32_t width = 512, height = 512;
     float fov = 90.0f;
     bool have_camera = false;
     Mat4 world_to_camera = Mat4::identity();
     std::vector<Param> ps;
-    auto fail = [&](int code, const std::string& msg) { *err = msg; delete scene; return code; };
+    auto fail = [&](int code, const std::string& msg) { *err = msg; delete scene; g_textures = nullptr; return code; };
     for (;;) {
         Token t = lx.next();
         if (t.kind == Token::End) break;
@@ -322,39 +369,79 @@ int load_pbrt(const char* path, bool use_shading_normals, rl_scene** out, std::s
         } else if (d == "Shape") {
             Token ty = lx.next();
             if (!read_params(lx, &ps)) return fail(RL_ERR_PARSE, "Shape: bad parameters");
-            if (ty.text != "trianglemesh") return fail(RL_ERR_UNSUPPORTED, "Shape \"" + ty.text + "\" is not supported (trianglemesh only)");
-            const Param* P = find(ps, "P");
-            const Param* I = find(ps, "indices");
-            const Param* N = find(ps, "N");
-            const Param* UV = find(ps, "uv");
-            if (!UV) UV = find(ps, "st");
-            if (!P || !I || P->nums.size() % 3 || I->nums.size() % 3) return fail(RL_ERR_PARSE, "Shape trianglemesh: bad P / indices");
-            size_t nv = P->nums.size() / 3;
-            std::vector<float> pos(3 * nv), nrm, uv;
-            for (size_t i = 0; i < nv; i++) {   // mat.transform_point(p) (scene_loader.rs:118-121)
-                Vec3 p = gs.ctm.xform_point({(float)P->nums[3 * i], (float)P->nums[3 * i + 1], (float)P->nums[3 * i + 2]});
-                pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
-            }
-            if (N && use_shading_normals && N->nums.size() == 3 * nv) {
-                nrm.resize(3 * nv);
-                for (size_t i = 0; i < nv; i++) {   // mat.transform_vector(+-n) (scene_loader.rs:101-116)
-                    Vec3 n{(float)N->nums[3 * i], (float)N->nums[3 * i + 1], (float)N->nums[3 * i + 2]};
-                    if (gs.reverse_orientation) n = {-n.x, -n.y, -n.z};
-                    n = gs.ctm.xform_vector(n);
-                    nrm[3 * i] = n.x; nrm[3 * i + 1] = n.y; nrm[3 * i + 2] = n.z;
-                }
-            }
-            if (UV && UV->nums.size() == 2 * nv) { uv.resize(2 * nv); for (size_t i = 0; i < 2 * nv; i++) uv[i] = (float)UV->nums[i]; }
-            std::vector<uint32_t> idx(I->nums.size());
-            for (size_t i = 0; i < idx.size(); i++) idx[i] = (uint32_t)I->nums[i];
-            rl_bsdf_desc b = gs.has_material ? gs.material : default_material();
-            int rc = rl_scene_add_mesh(scene, pos.data(), nv, idx.data(), idx.size() / 3, nrm.empty() ? nullptr : nrm.data(),
-                                       uv.empty() ? nullptr : uv.data(), &b, gs.has_emission ? gs.emission : nullptr);
-            if (rc < 0) return fail(rc, "Shape trianglemesh: invalid mesh");
+            RawShape r;
+            if (ty.text == "trianglemesh") {
+                const Param* P = find(ps, "P");
+                const Param* I = find(ps, "indices");
+                const Param* N = find(ps, "N");
+                const Param* UV = find(ps, "uv");
+                if (!UV) UV = find(ps, "st");
+                if (!P || !I || P->nums.size() % 3 || I->nums.size() % 3) return fail(RL_ERR_PARSE, "Shape trianglemesh: bad P / indices");
+                const size_t nv = P->nums.size() / 3;
+                r.P.assign(P->nums.begin(), P->nums.end());
+                if (N && N->nums.size() == 3 * nv) r.N.assign(N->nums.begin(), N->nums.end());
+                if (UV && UV->nums.size() == 2 * nv) r.UV.assign(UV->nums.begin(), UV->nums.end());
+                r.idx.resize(I->nums.size());
+                for (size_t i = 0; i < r.idx.size(); i++) r.idx[i] = (uint32_t)I->nums[i];
+            } else if (ty.text == "plymesh") {   // Shape::Ply -> read_ply(..).to_trimesh() (scene_loader.rs:88-93)
+                const Param* fn = find(ps, "filename");
+                if (!fn || fn->strs.empty()) return fail(RL_ERR_PARSE, "Shape plymesh: filename missing");
+                LoadedMesh m;
+                std::string e2;
+                if (int rc = read_ply(join_path(base_dir, fn->strs[0]), &m, &e2)) return fail(rc, e2);
+                r.P = std::move(m.pos); r.N = std::move(m.nrm); r.UV = std::move(m.uv); r.idx = std::move(m.idx);
+            } else return fail(RL_ERR_UNSUPPORTED, "Shape \"" + ty.text + "\" is not supported (trianglemesh, plymesh)");
+            r.ctm = gs.ctm;
+            r.reverse_orientation = gs.reverse_orientation;
+            r.bsdf = gs.has_material ? gs.material : default_material();
+            r.has_emission = gs.has_emission;
+            for (int k = 0; k < 3; k++) r.emission[k] = gs.emission[k];
+            if (in_object) objects[cur_object].push_back(std::move(r));
+            else if (emit_shape(scene, r, Mat4::identity(), use_shading_normals) < 0) return fail(RL_ERR_PARSE, "Shape: invalid mesh");
+        } else if (d == "Texture") {             // named imagemap textures (scene_info.textures; bsdfs/mod.rs:227-236)
+            Token name = lx.next(); Token kind = lx.next(); Token cls = lx.next();
+            (void)kind;
+            if (!read_params(lx, &ps)) return fail(RL_ERR_PARSE, "Texture: bad parameters");
+            if (cls.text != "imagemap") return fail(RL_ERR_UNSUPPORTED, "Texture class \"" + cls.text + "\" is not supported (imagemap only)");
+            const Param* fn = find(ps, "filename");
+            if (!fn || fn->strs.empty()) return fail(RL_ERR_PARSE, "Texture imagemap: filename missing");
+            HostBitmap img;
+            std::string e2;
+            if (int rc = read_image(join_path(base_dir, fn->strs[0]), &img, &e2)) return fail(rc, e2);
+            int id = rl_scene_add_bitmap(scene, img.w, img.h, img.rgb.data());
+            if (id < 0) return fail(id, "Texture imagemap: bitmap rejected");
+            textures[name.text] = id;
+        } else if (d == "Include") {             // the included text is parsed in place
+            Token file = lx.next();
+            std::ifstream inc(join_path(base_dir, file.text), std::ios::binary);
+            if (!inc) return fail(RL_ERR_IO, "cannot open Include " + file.text);
+            std::stringstream is2;
+            is2 << inc.rdbuf();
+            lx.has_peek = false;
+            lx.src.insert(lx.pos, "\n" + is2.str() + "\n");
+        } else if (d == "ObjectBegin") {
+            Token name = lx.next();
+            if (in_object) return fail(RL_ERR_PARSE, "nested ObjectBegin");
+            stack.push_back(gs);
+            in_object = true; cur_object = name.text; objects[cur_object];
+        } else if (d == "ObjectEnd") {
+            if (!in_object || stack.empty()) return fail(RL_ERR_PARSE, "ObjectEnd without ObjectBegin");
+            in_object = false;
+            gs = stack.back(); stack.pop_back();
+        } else if (d == "ObjectInstance") {
+            Token name = lx.next();
+            instances.emplace_back(name.text, gs.ctm);
         } else {
             return fail(RL_ERR_UNSUPPORTED, "directive '" + d + "' is not supported");
         }
     }
+    for (const auto& inst : instances) {   // scene_info.instances, after all plain shapes (scene_loader.rs:186-204)
+        auto it = objects.find(inst.first);
+        if (it == objects.end()) return fail(RL_ERR_PARSE, "ObjectInstance of unknown object " + inst.first);
+        for (const RawShape& r : it->second)
+            if (emit_shape(scene, r, inst.second, use_shading_normals) < 0) return fail(RL_ERR_PARSE, "ObjectInstance: invalid mesh");
+    }
+    g_textures = nullptr;
     if (!have_camera) return fail(RL_ERR_PARSE, "The camera is not set!");
     Mat4 to_world;
     if (!world_to_camera.inverse(&to_world)) return fail(RL_ERR_PARSE, "singular camera transform");

@@ -219,6 +219,29 @@ def test_ao_and_direct_integrators_parity(built, mode):
             assert img.mean() > 0
 
 
+@pytest.mark.parametrize("fmt", ["obj", "serialized"])
+def test_scene_files_render_like_the_fixture(built, tmp_path, fmt):
+    """a mixed-material scene written as Mitsuba XML (+ OBJ / serialized meshes) and read back by
+    rl_scene_load renders the image of the in-memory fixture bit for bit (all five BSDF families, area lights, a point light)."""
+    from rustlight_amd import export
+    sd = scenes.living_room(48, 32, n_spheres=12, tess=8)
+    sd.flip = True
+    sd.lights.append({"type": "point", "a": (0.5, 3.0, 1.0), "intensity": (4.0, 4.0, 3.0)})
+    f = np.float32
+    lum = lambda c: (f(c[0]) * f(0.212671) + f(c[1]) * f(0.715160)) + f(c[2]) * f(0.072169)
+    for m in sd.meshes:                      # bsdf_mts derives Phong's lobe weight from the two reflectances (bsdfs/mod.rs:521-526)
+        if m.bsdf.type == scenes.PHONG:
+            d, s = lum(m.bsdf.diffuse["color0"]), lum(m.bsdf.specular["color0"])
+            m.bsdf.weight_specular = float(s / (d + s))
+    p = str(tmp_path / "room.xml")
+    export.write_mitsuba(sd, p, fmt)
+    seeds = api.IndependentSampler(2).block_seeds(48, 32)
+    a, sta = api.Context(api.Scene.load(p), 0).render(seeds, api.path_params(spp=4))
+    b, stb = api.Context(api.Scene(sd), 0).render(seeds, api.path_params(spp=4))
+    np.testing.assert_array_equal(a, b)
+    assert sta["vertices"] == stb["vertices"] and a.mean() > 0.01
+
+
 def test_progressive_wrappers(built, cbox64, tmp_path):
     """IntegratorAverage / IntegratorEqualTime (avg.rs, equal_time.rs): every pass draws fresh block seeds from the same,
     advancing master sampler; pass k of the wrapper equals a plain render with the k-th batch of seeds."""
