@@ -140,6 +140,11 @@ int rl_scene_set_environment_map(rl_scene* scene, uint32_t w, uint32_t h, const 
  * (emissive meshes in mesh order), CDF over flux().channel_max().  The ATS light tree
  * (`-x ats`) is out of scope. */
 int rl_scene_build_emitters(rl_scene* scene);
+/* The `build_ats` argument of Scene::build_emitters (src/scene.rs:53,118-120; CLI `-x ats`): when set, the next
+ * rl_scene_build_emitters() also builds the LightSamplerATS light tree over the emissive triangles (src/emitter.rs:1117-1292)
+ * and light sampling / its MIS pdf descend that tree (importance_point, emitter.rs:1024-1086) instead of the flux cdf.
+ * Every emitter must then be an emissive mesh (the reference asserts is_surface()). */
+int rl_scene_enable_ats(rl_scene* scene, int build_ats);
 
 /* SceneLoaderManager::load(path, use_shading_normals) for the `.pbrt` subset the reference's
  * PBRT loader consumes (src/scene_loader.rs:77-315): Transform/LookAt/Camera perspective/Film,

@@ -226,6 +226,7 @@ static inline double sqrt_d(double a) {
     s = 0.5 * (s + a / s);
     return s;
 }
+static inline float asinf_det(float x);
 static inline float acosf_det(float x) {
     if (x != x) return x;
     if (x > 1.0f || x < -1.0f) return (float)bits_to_f64(0x7ff8000000000000ull);
@@ -239,4 +240,15 @@ static inline float acosf_det(float x) {
     return (float)r;
 }
 
+static inline float asinf_det(float x) {
+    if (x != x) return x;
+    if (x > 1.0f || x < -1.0f) return (float)bits_to_f64(0x7ff8000000000000ull);
+    double xd = x;
+    double c = sqrt_d((1.0 - xd) * (1.0 + xd));      // asin(x) = atan2(x, sqrt(1 - x^2))
+    const double PI = 3.14159265358979311600;
+    double r;
+    if (c >= std::fabs(xd)) r = atan_d(xd / c);
+    else { r = atan_d(c / xd); r = (xd > 0.0 ? 0.5 * PI : -0.5 * PI) - r; }
+    return (float)r;
+}
 }  // namespace detmath

@@ -70,6 +70,9 @@ def lib():
         L.orc_scene_add_point_light.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_scene_add_directional_light.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_scene_set_environment.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.orc_scene_set_ats.argtypes = [C.c_void_p, C.c_int]
+        L.orc_ats_probe.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_ats_dump.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.orc_env_probe.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_scene_set_environment_map.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
         L.orc_rng_seed.argtypes = [C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
@@ -176,7 +179,21 @@ class Scene:
         if sd.environment_map is not None:
             em = np.ascontiguousarray(sd.environment_map, np.float32)
             L.orc_scene_set_environment_map(self.h, em.shape[1], em.shape[0], abi.fptr(em))
+        L.orc_scene_set_ats(self.h, int(getattr(sd, "use_ats", False)))
         L.orc_scene_build(self.h)
+
+    def ats_dump(self):
+        """(nodes [n, 16] f32 with the 4 link words as int32 bit patterns, light_emitter, light_prim) of the light tree."""
+        nn, nl = C.c_uint64(), C.c_uint64()
+        lib().orc_ats_dump(self.h, C.byref(nn), None, C.byref(nl), None, None)
+        nodes = np.zeros((nn.value, 16), np.float32); le = np.zeros(nl.value, np.int32); lp = np.zeros(nl.value, np.int32)
+        lib().orc_ats_dump(self.h, C.byref(nn), abi.fptr(nodes), C.byref(nl), le.ctypes.data_as(C.POINTER(C.c_int32)), lp.ctypes.data_as(C.POINTER(C.c_int32)))
+        return nodes, le, lp
+
+    def ats_probe(self, kind, values):
+        a = np.asarray(values, np.float32); out = np.zeros(4, np.float32)
+        assert lib().orc_ats_probe(self.h, kind, abi.fptr(a), abi.fptr(out)) == 0
+        return out
 
     def env_probe(self, kind, values):
         a = np.asarray(values, np.float32); out = np.zeros(8, np.float32)

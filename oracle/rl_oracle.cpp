@@ -33,6 +33,7 @@
 #include <memory>
 #include <string>
 #include <thread>
+#include <map>
 #include <vector>
 
 #include "../include/rustlight_amd.h"  // POD descriptor structs only
@@ -1018,6 +1019,208 @@ struct Camera {
 };
 
 // ------------------------------------------------------------------------------------------
+// ATS — adaptive tree splitting light sampler, the `-x ats` option (src/emitter.rs:783-1488, 1540-1639): a BVH over the
+// emissive triangles whose nodes carry an orientation cone and a flux; a light is drawn by descending with probabilities
+// proportional to LightBounds::importance_point.  Only `sample` / `pdf` are on the path / direct integrators.
+struct DirectionCone { V3 w{0, 0, 1}; float cos_theta = -1.0f; bool empty = false; };
+static inline float safe_acos(float v) { return detmath::acosf_det(rmin(rmax(v, -1.0f), 1.0f)); }
+static inline float safe_asin(float v) { return detmath::asinf_det(rmin(rmax(v, -1.0f), 1.0f)); }
+static inline float angle_between(V3 v1, V3 v2) {   // emitter.rs:792-798
+    if (dot(v1, v2) < 0.0f) return PI_F - 2.0f * safe_asin(magnitude(v2 + v1) / 2.0f);
+    return 2.0f * safe_asin(magnitude(v2 - v1) / 2.0f);
+}
+static inline float to_degrees(float r) { return r * 57.2957795130823208767981548141051703f; }        // f32::to_degrees
+static inline float to_radians(float d) { const float k = PI_F / 180.0f; return d * k; }               // f32::to_radians
+static M4 rotate_sc(float sin_theta, float cos_theta, V3 axis) {   // emitter.rs:800-819 (built column-wise, then transposed)
+    V3 a = normalize(axis);
+    M4 m;
+    m.c[0] = {a.x * a.x + (1.0f - a.x * a.x) * cos_theta, a.x * a.y * (1.0f - cos_theta) - a.z * sin_theta, a.x * a.z * (1.0f - cos_theta) + a.y * sin_theta, 0.0f};
+    m.c[1] = {a.x * a.y * (1.0f - cos_theta) + a.z * sin_theta, a.y * a.y + (1.0f - a.y * a.y) * cos_theta, a.y * a.z * (1.0f - cos_theta) - a.x * sin_theta, 0.0f};
+    m.c[2] = {a.x * a.z * (1.0f - cos_theta) - a.y * sin_theta, a.y * a.z * (1.0f - cos_theta) + a.x * sin_theta, a.z * a.z + (1.0f - a.z * a.z) * cos_theta, 0.0f};
+    m.c[3] = {0.0f, 0.0f, 0.0f, 1.0f};
+    return m.transpose();
+}
+static M4 rotate_angle_axis(float theta_deg, V3 axis) {
+    return rotate_sc(detmath::sinf_det(to_radians(theta_deg)), detmath::cosf_det(to_radians(theta_deg)), axis);
+}
+static BoundingSphere aabb_to_sphere(const AABB& b) { V3 c = b.center(); return {c, magnitude(c - b.p_max)}; }   // structure.rs:871-877
+static DirectionCone cone_subtended(const AABB& b, V3 p) {   // emitter.rs:831-846
+    BoundingSphere s = aabb_to_sphere(b);
+    if (magnitude2(p - s.center) < s.radius * s.radius) return DirectionCone();
+    DirectionCone c;
+    c.w = normalize(s.center - p);
+    float sin2 = s.radius * s.radius / magnitude2(s.center - p);
+    c.cos_theta = std::sqrt(rmax(1.0f - sin2, 0.0f));
+    return c;
+}
+static DirectionCone cone_union(const DirectionCone& a, const DirectionCone& b) {   // emitter.rs:848-888
+    if (a.empty) return b;
+    if (b.empty) return a;
+    float theta_a = safe_acos(a.cos_theta), theta_b = safe_acos(b.cos_theta), theta_d = angle_between(a.w, b.w);
+    if (rmin(theta_d + theta_b, PI_F) <= theta_a) return a;
+    if (rmin(theta_d + theta_a, PI_F) <= theta_b) return b;
+    float theta_o = (theta_a + theta_d + theta_b) / 2.0f;
+    if (theta_o >= PI_F) return DirectionCone();
+    float theta_r = theta_o - theta_a;
+    V3 wr = cross(a.w, b.w);
+    if (magnitude2(wr) == 0.0f) return DirectionCone();
+    DirectionCone c;
+    c.w = rotate_angle_axis(to_degrees(theta_r), wr).transform_vector(a.w);
+    c.cos_theta = detmath::cosf_det(theta_o);
+    return c;
+}
+struct LightBounds {   // emitter.rs:901-935
+    AABB aabb;
+    V3 w{0, 0, 1};
+    float phi = 0, theta_o = 0, theta_e = 0, cos_theta_o = 1, cos_theta_e = 1;
+    bool two_sided = false;
+    size_t number_lights = 0;
+    float phi_sqr = 0;
+    static LightBounds merge(const LightBounds& a, const LightBounds& b) {   // LightBounds::union (emitter.rs:947-973)
+        if (a.phi == 0.0f) return b;
+        if (b.phi == 0.0f) return a;
+        DirectionCone ca; ca.w = a.w; ca.cos_theta = a.cos_theta_o;
+        DirectionCone cb; cb.w = b.w; cb.cos_theta = b.cos_theta_o;
+        DirectionCone c = cone_union(ca, cb);
+        LightBounds r;
+        r.theta_o = safe_acos(c.cos_theta);
+        r.theta_e = rmax(a.theta_e, b.theta_e);
+        r.aabb = a.aabb.union_aabb(b.aabb);
+        r.w = c.w;
+        r.phi = a.phi + b.phi;
+        r.cos_theta_o = detmath::cosf_det(r.theta_o);
+        r.cos_theta_e = detmath::cosf_det(r.theta_e);
+        r.two_sided = a.two_sided | b.two_sided;
+        r.number_lights = a.number_lights + b.number_lights;
+        r.phi_sqr = a.phi_sqr + b.phi_sqr;
+        return r;
+    }
+    // importance_point (emitter.rs:1024-1086)
+    float importance_point(V3 p, const V3* n) const {
+        V3 pc = aabb.center();
+        float d2 = rmax(magnitude2(p - pc), 0.0001f);
+        V3 wi = normalize(p - pc);
+        float cos_theta = dot(w, wi);
+        if (two_sided) cos_theta = std::fabs(cos_theta);
+        float sin_theta = std::sqrt(rmax(1.0f - cos_theta * cos_theta, 0.0f));
+        auto cos_sub = [](float sa, float ca, float sb, float cb) { return ca > cb ? 1.0f : ca * cb + sa * sb; };
+        auto sin_sub = [](float sa, float ca, float sb, float cb) { return ca > cb ? 1.0f : sa * cb - ca * sb; };
+        float cos_theta_u = cone_subtended(aabb, p).cos_theta;
+        float sin_theta_u = std::sqrt(rmax(1.0f - cos_theta_u * cos_theta_u, 0.0f));
+        float sin_theta_o = std::sqrt(rmax(1.0f - cos_theta_o * cos_theta_o, 0.0f));
+        float cos_theta_x = cos_sub(sin_theta, cos_theta, sin_theta_o, cos_theta_o);
+        float sin_theta_x = sin_sub(sin_theta, cos_theta, sin_theta_o, cos_theta_o);
+        float cos_theta_p = cos_sub(sin_theta_x, cos_theta_x, sin_theta_u, cos_theta_u);
+        if (cos_theta_p <= cos_theta_e) return 0.0f;
+        float imp = phi * cos_theta_p / d2;
+        if (n) {
+            float cos_theta_i = std::fabs(dot(wi, *n));
+            float sin_theta_i = std::sqrt(rmax(1.0f - cos_theta_i * cos_theta_i, 0.0f));
+            imp *= cos_sub(sin_theta_i, cos_theta_i, sin_theta_u, cos_theta_u);
+        }
+        return rmax(imp, 0.0f);
+    }
+};
+struct LightProxy { size_t emitter_id, primitive_idx; LightBounds bounds; };
+struct LightBVHNode { long left = -1, right = -1, parent = -1; LightBounds bounds; long light = -1; bool is_leaf() const { return left < 0 && right < 0; } };
+struct LightSamplerATS {
+    long root = -1;
+    std::vector<LightBVHNode> nodes;
+    std::vector<LightProxy> lights;
+    std::map<std::pair<size_t, size_t>, size_t> query_to_nodes;
+    static float max_component(V3 v) { return rmax(rmax(v.x, v.y), v.z); }
+    static V3 aabb_offset(const AABB& b, V3 v) {   // structure.rs:811-820
+        V3 o = v - b.p_min, s = b.size();
+        return {s.x != 0.0f ? o.x / s.x : 0.0f, s.y != 0.0f ? o.y / s.y : 0.0f, s.z != 0.0f ? o.z / s.z : 0.0f};
+    }
+    // build_bvh (emitter.rs:1117-1262)
+    size_t build(size_t index, LightProxy* lt, size_t n) {
+        if (n == 1) {
+            LightBVHNode nd; nd.bounds = lt[0].bounds; nd.light = (long)index;
+            nodes.push_back(nd);
+            query_to_nodes[{lt[0].emitter_id, lt[0].primitive_idx}] = nodes.size() - 1;
+            return nodes.size() - 1;
+        }
+        AABB bounds, centroid_bounds;
+        for (size_t i = 0; i < n; i++) { bounds = bounds.union_aabb(lt[i].bounds.aabb); centroid_bounds = centroid_bounds.union_vec(lt[i].bounds.aabb.center()); }
+        float min_cost = F32_MAX; int min_cost_bucket = -1, min_cost_dim = -1;
+        const size_t NB = 12;
+        auto bucket_of = [&](const LightProxy& l, int dim) { size_t i = as_usize((float)NB * aabb_offset(centroid_bounds, l.bounds.aabb.center())[dim]); return i < NB - 1 ? i : NB - 1; };
+        for (int dim = 0; dim < 3; dim++) {
+            if (centroid_bounds.p_max[dim] == centroid_bounds.p_min[dim]) continue;
+            std::vector<LightBounds> bb(NB);
+            for (size_t i = 0; i < n; i++) { size_t k = bucket_of(lt[i], dim); bb[k] = LightBounds::merge(bb[k], lt[i].bounds); }
+            for (size_t i = 0; i + 1 < NB; i++) {
+                LightBounds b0, b1;
+                for (size_t j = 0; j < i + 1; j++) b0 = LightBounds::merge(b0, bb[j]);
+                for (size_t j = i + 1; j < NB; j++) b1 = LightBounds::merge(b1, bb[j]);
+                auto momega = [](const LightBounds& b) {
+                    float theta_w = rmin(b.theta_o + b.theta_e, PI_F);
+                    return 2.0f * PI_F * (1.0f - detmath::cosf_det(b.theta_o))
+                         + 1.57079632679489661923f * (2.0f * theta_w * detmath::sinf_det(b.theta_o) - detmath::cosf_det(b.theta_o - 2.0f * theta_w)
+                                                      - 2.0f * b.theta_o * detmath::sinf_det(b.theta_o) + detmath::cosf_det(b.theta_o));
+                };
+                float kr = max_component(bounds.size()) / bounds.size()[dim];
+                float c = kr * (b0.phi * momega(b0) * b0.aabb.surface_area() + b1.phi * momega(b1) * b1.aabb.surface_area());
+                if (c > 0.0f && c < min_cost) { min_cost = c; min_cost_bucket = (int)i; min_cost_dim = dim; }
+            }
+        }
+        size_t mid;
+        if (min_cost_dim == -1) mid = n / 2;
+        else {   // itertools::partition: swap the first failing element with the last passing one, repeatedly
+            auto pred = [&](const LightProxy& l) { return bucket_of(l, min_cost_dim) <= (size_t)min_cost_bucket; };
+            size_t split = 0, front = 0, back = n;
+            for (;;) {
+                if (front == back) break;
+                size_t f = front++;
+                if (!pred(lt[f])) {
+                    bool found = false;
+                    while (back > front) { back--; if (pred(lt[back])) { std::swap(lt[f], lt[back]); found = true; break; } }
+                    if (!found) break;
+                }
+                split++;
+            }
+            mid = split;
+        }
+        size_t left = build(index, lt, mid);
+        size_t right = build(index + mid, lt + mid, n - mid);
+        LightBVHNode nd; nd.left = (long)left; nd.right = (long)right;
+        nd.bounds = LightBounds::merge(nodes[left].bounds, nodes[right].bounds);
+        nodes.push_back(nd);
+        size_t id = nodes.size() - 1;
+        nodes[left].parent = (long)id; nodes[right].parent = (long)id;
+        return id;
+    }
+    template <class F> float prob_left(const LightBVHNode& nd, F imp) const {
+        float il = imp(nodes[nd.left].bounds), ir = imp(nodes[nd.right].bounds);
+        return (il == 0.0f && ir == 0.0f) ? 0.5f : il / (il + ir);
+    }
+    // sample (emitter.rs:1330-1367)
+    template <class F> const LightProxy& sample(float r, F imp, float* pdf_sel) const {
+        float pdf = 1.0f; long ni = root;
+        for (;;) {
+            const LightBVHNode& nd = nodes[ni];
+            if (nd.is_leaf()) { *pdf_sel = pdf; return lights[nd.light]; }
+            float pl = prob_left(nd, imp);
+            if (r < pl) { r = r / pl; ni = nd.left; pdf *= pl; }
+            else { r = (r - pl) / (1.0f - pl); ni = nd.right; pdf *= 1.0f - pl; }
+        }
+    }
+    // pdf (emitter.rs:1294-1328)
+    template <class F> float pdf(size_t id_emitter, size_t id_primitive, F imp) const {
+        long id = (long)query_to_nodes.at({id_emitter, id_primitive});
+        float pdf = 1.0f;
+        while (nodes[id].parent >= 0) {
+            long ip = nodes[id].parent;
+            float pl = prob_left(nodes[ip], imp);
+            if (nodes[ip].left == id) pdf *= pl; else pdf *= 1.0f - pl;
+            id = ip;
+        }
+        return pdf;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
 // HomogenousVolume + PhaseFunction (src/volume.rs)
 struct SampledDistance { float t; Color w; float pdf; bool exited; };
 struct Volume {
@@ -1084,6 +1287,8 @@ struct Scene {
     int env_emitter = -1;
     std::vector<int> mesh_to_emitter;
     Distribution1D emitters_cdf;
+    bool want_ats = false;                    // build_emitters(build_ats) (scene.rs:53, cli `-x ats`)
+    std::unique_ptr<LightSamplerATS> ats;
     BoundingSphere bsphere;
     // BVHAccel (src/accel.rs:79-113)
     struct Node { AABB aabb; size_t info, count; bool is_leaf() const { return count != 0; } };
@@ -1127,14 +1332,70 @@ struct Scene {
             flux.push_back(f.channel_max());
         }
         emitters_cdf = Distribution1D::normalize(flux);
+        ats.reset();
+        if (want_ats) build_ats();
+    }
+    // EmitterSampler::build_ats -> LightSamplerATS::new (emitter.rs:1264-1292) with Mesh::convert_light_proxy (726-781)
+    void build_ats() {
+        ats.reset(new LightSamplerATS());
+        for (size_t e = 0; e < emitters.size(); e++) {
+            assert(emitters[e].kind == EM_MESH);      // assert!(e.is_surface())
+            const Mesh& m = meshes[emitters[e].mesh];
+            for (size_t i = 0; i < m.n_tris(); i++) {
+                V3 v0 = m.vertices[m.indices[3 * i]], v1 = m.vertices[m.indices[3 * i + 1]], v2 = m.vertices[m.indices[3 * i + 2]];
+                V3 n = cross(v1 - v0, v2 - v0);
+                LightProxy lp; lp.emitter_id = e; lp.primitive_idx = i;
+                LightBounds& b = lp.bounds;
+                b.w = normalize(n);
+                b.theta_o = 0.0f; b.theta_e = 1.57079632679489661923f;
+                b.phi = m.emit().channel_max() * magnitude(n) * 0.5f;
+                b.aabb = AABB().union_vec(v0).union_vec(v1).union_vec(v2);
+                b.cos_theta_o = detmath::cosf_det(b.theta_o); b.cos_theta_e = detmath::cosf_det(b.theta_e);
+                b.two_sided = false; b.number_lights = 1; b.phi_sqr = powi(b.phi, 2);
+                ats->lights.push_back(lp);
+            }
+        }
+        if (ats->lights.empty()) { ats.reset(); return; }
+        ats->root = (long)ats->build(0, ats->lights.data(), ats->lights.size());
     }
     float emitter_pdf(int mesh_id) const { return emitters_cdf.pdf((size_t)mesh_to_emitter[mesh_id]); }  // emitter.rs:1510-1526
     // EmitterSampler::direct_pdf (emitter.rs:1566-1575)
-    PDF direct_pdf(int mesh_id, const LightSamplingPDF& ls) const { return mesh_direct_pdf(meshes[mesh_id], ls).mul(emitter_pdf(mesh_id)); }
+    PDF direct_pdf(int mesh_id, const LightSamplingPDF& ls, const V3* n = nullptr, size_t id_primitive = 0) const {
+        if (!ats) return mesh_direct_pdf(meshes[mesh_id], ls).mul(emitter_pdf(mesh_id));
+        // with the light tree: pdf of the triangle x probability of reaching its leaf (emitter.rs:1595-1600)
+        const Mesh& m = meshes[mesh_id];
+        float cos_light = rmax(dot(ls.n, -ls.dir), 0.0f);
+        PDF tri = PDF::solid_angle(0.0f);
+        if (cos_light != 0.0f) {   // Mesh::direct_pdf_tri (emitter.rs:581-589), pdf_tri (geometry.rs:226-234)
+            float geom = cos_light / magnitude2(ls.p - ls.o);
+            V3 v0 = m.vertices[m.indices[3 * id_primitive]], v1 = m.vertices[m.indices[3 * id_primitive + 1]], v2 = m.vertices[m.indices[3 * id_primitive + 2]];
+            float area_tri = magnitude(cross(v1 - v0, v2 - v0)) * 0.5f;
+            tri = PDF::solid_angle((1.0f / area_tri) / geom);
+        }
+        V3 o = ls.o;
+        return tri.mul(ats->pdf((size_t)mesh_to_emitter[mesh_id], id_primitive, [&](const LightBounds& b) { return b.importance_point(o, n); }));
+    }
     PDF direct_pdf_env(V3 d) const { return PDF::solid_angle(env_tex ? env_tex->pdf(d) : 1.0f / (PI_F * 4.0f)).mul(emitters_cdf.pdf((size_t)env_emitter)); }
     Color environment_luminance(V3 d) const { return !has_env ? Color::zero() : (env_tex ? env_tex->eval(d) : env_color); }   // scene.rs:125-130
     // EmitterSampler::sample_light (emitter.rs:1604-1620); LightSampling.emitter = index into `emitters`
-    LightSampling sample_light(V3 p, float r_sel, float r, V2 uv) const {
+    LightSampling sample_light(V3 p, const V3* n, float r_sel, float r, V2 uv) const {
+        if (ats) {   // emitter.rs:1621-1639: the tree picks (emitter, triangle); Mesh::direct_sample_tri (emitter.rs:609-650)
+            float pdf_sel;
+            const LightProxy& lp = ats->sample(r_sel, [&](const LightBounds& b) { return b.importance_point(p, n); }, &pdf_sel);
+            const Mesh& m = meshes[emitters[lp.emitter_id].mesh];
+            Mesh::SampledPosition sp = m.sample_tri(lp.primitive_idx, uv);
+            V3 d = sp.p - p;
+            float dist = magnitude(d);
+            if (dist != 0.0f) d = d / dist;
+            float geom = dist != 0.0f ? rmax(dot(sp.n, -d), 0.0f) / (dist * dist) : 0.0f;
+            float pdf_area = sp.pdf.value();
+            PDF pdf = sp.pdf.as_solid_angle_geom(geom);
+            Color weight = pdf.is_zero() ? Color::zero() : m.emit() * geom / pdf_area;
+            LightSampling res = {(int)lp.emitter_id, pdf, sp.p, sp.n, d, weight};
+            div_assign(res.weight, pdf_sel);
+            res.pdf = res.pdf.mul(pdf_sel);
+            return res;
+        }
         size_t id = emitters_cdf.sample_discrete(r_sel);
         float pdf_sel = emitters_cdf.pdf(id);
         const EmitterRec& e = emitters[id];
@@ -1499,7 +1760,8 @@ struct PathTracer {
         float a = sampler.next();
         float b = sampler.next();
         V2 c = sampler.next2d();
-        LightSampling lr = scene.sample_light(p, a, b, c);
+        V3 n_s = kind == Vertex::Surface ? path.vertices[vid].its.n_s : V3{0, 0, 0};
+        LightSampling lr = scene.sample_light(p, kind == Vertex::Surface ? &n_s : nullptr, a, b, c);   // Some(&its.n_s) | None (emitters.rs:118-124, 186-192)
         cnt.shadow_rays++;
         bool vis = scene.visible(p, lr.p);
         if (!(lr.is_valid() && vis)) return;
@@ -1543,7 +1805,7 @@ struct PathTracer {
         }
         const Vertex& nx = path.vertices[e.v1];
         if (nx.kind == Vertex::Surface) {
-            PDF p = scene.direct_pdf(nx.its.mesh, {o, nx.its.p, nx.its.n_g, e.d});
+            PDF p = scene.direct_pdf(nx.its.mesh, {o, nx.its.p, nx.its.n_g, e.d}, nullptr, nx.its.primitive_id);   // n = None (emitters.rs:52-57)
             *out = p.value();
             return true;
         }
@@ -1727,7 +1989,7 @@ static Color direct_compute_pixel(const Scene& scene, const DirectParams& dp, ui
         float a = sampler.next();
         float b = sampler.next();
         V2 c = sampler.next2d();
-        LightSampling lr = scene.sample_light(its.p, a, b, c);
+        LightSampling lr = scene.sample_light(its.p, &its.n_s, a, b, c);   // Some(&its.n_s) (direct.rs:64-70)
         V3 d_out_local = its.frame.to_local(lr.d);
         if (!lr.is_valid()) continue;
         cnt.shadow_rays++;
@@ -1752,7 +2014,7 @@ static Color direct_compute_pixel(const Scene& scene, const DirectParams& dp, ui
             if (nm.is_light && dot(nx.n_g, -r2.d) > 0.0f) {
                 float weight_bsdf;
                 if (sd.pdf.kind == PDF::SolidAngle) {
-                    float light_pdf = scene.direct_pdf(nx.mesh, {r2.o, nx.p, nx.n_g, r2.d}).value();
+                    float light_pdf = scene.direct_pdf(nx.mesh, {r2.o, nx.p, nx.n_g, r2.d}, &its.n_s, nx.primitive_id).value();   // direct.rs:156-164
                     weight_bsdf = mis_weight(sd.pdf.v * w_nb_bsdf, light_pdf * w_nb_light);
                 } else weight_bsdf = 1.0f;
                 add_assign(l_i, weight_bsdf * sd.weight * nm.emit() * w_nb_bsdf);
@@ -1868,6 +2130,46 @@ int orc_scene_set_environment_map(orc_scene* sc, uint32_t w, uint32_t h, const f
     return 0;
 }
 
+int orc_scene_set_ats(orc_scene* sc, int build_ats) { sc->s.want_ats = build_ats != 0; return 0; }   // Scene::build_emitters(build_ats)
+// light tree dump, 16 words per node in node order: aabb min / max, cone axis, phi, cos_theta_o, cos_theta_e, then
+// left / right / parent / light as int32 bit patterns (-1 = none); `leaf_of` = node of every (emitter, triangle) in proxy order
+int orc_ats_dump(const orc_scene* sc, uint64_t* n_nodes, float* nodes16, uint64_t* n_lights, int32_t* light_emitter, int32_t* light_prim) {
+    const LightSamplerATS* a = sc->s.ats.get();
+    if (!a) { *n_nodes = 0; *n_lights = 0; return 0; }
+    if (nodes16) for (size_t i = 0; i < a->nodes.size(); i++) {
+        const LightBVHNode& nd = a->nodes[i];
+        float* o = nodes16 + 16 * i;
+        o[0] = nd.bounds.aabb.p_min.x; o[1] = nd.bounds.aabb.p_min.y; o[2] = nd.bounds.aabb.p_min.z;
+        o[3] = nd.bounds.aabb.p_max.x; o[4] = nd.bounds.aabb.p_max.y; o[5] = nd.bounds.aabb.p_max.z;
+        o[6] = nd.bounds.w.x; o[7] = nd.bounds.w.y; o[8] = nd.bounds.w.z;
+        o[9] = nd.bounds.phi; o[10] = nd.bounds.cos_theta_o; o[11] = nd.bounds.cos_theta_e;
+        int32_t link[4] = {(int32_t)nd.left, (int32_t)nd.right, (int32_t)nd.parent, (int32_t)nd.light};
+        std::memcpy(o + 12, link, sizeof(link));
+    }
+    if (light_emitter) for (size_t i = 0; i < a->lights.size(); i++) { light_emitter[i] = (int32_t)a->lights[i].emitter_id; light_prim[i] = (int32_t)a->lights[i].primitive_idx; }
+    *n_nodes = a->nodes.size(); *n_lights = a->lights.size();
+    return 0;
+}
+
+// light-tree probes: kind 0 sample(r = in[0], p = in[1..3], n = in[4..6] if in[7] != 0) -> out = {emitter, prim, pdf_sel};
+// kind 1 pdf(emitter = in[0], prim = in[1], p = in[2..4], n = in[5..7] if in[8] != 0) -> out[0]
+int orc_ats_probe(const orc_scene* sc, int kind, const float* in, float* out) {
+    const LightSamplerATS* a = sc->s.ats.get();
+    if (!a) return -1;
+    if (kind == 0) {
+        V3 p{in[1], in[2], in[3]}, n{in[4], in[5], in[6]};
+        const V3* np_ = in[7] != 0.0f ? &n : nullptr;
+        float pdf_sel;
+        const LightProxy& lp = a->sample(in[0], [&](const LightBounds& b) { return b.importance_point(p, np_); }, &pdf_sel);
+        out[0] = (float)lp.emitter_id; out[1] = (float)lp.primitive_idx; out[2] = pdf_sel;
+    } else {
+        V3 p{in[2], in[3], in[4]}, n{in[5], in[6], in[7]};
+        const V3* np_ = in[8] != 0.0f ? &n : nullptr;
+        out[0] = a->pdf((size_t)in[0], (size_t)in[1], [&](const LightBounds& b) { return b.importance_point(p, np_); });
+    }
+    return 0;
+}
+
 int orc_scene_build(orc_scene* sc) {
     sc->s.build_emitters();
     sc->s.build_bvh();
@@ -1906,6 +2208,7 @@ void orc_math_batch(int fn, size_t n, const float* a, const float* b, float* out
             case 4: out[i] = detmath::powf_det(a[i], b[i]); break;
             case 5: out[i] = detmath::acosf_det(a[i]); break;
             case 6: out[i] = detmath::atan2f_det(a[i], b[i]); break;
+            case 7: out[i] = detmath::asinf_det(a[i]); break;
             default: out[i] = 0.0f;
         }
     }
@@ -1997,7 +2300,7 @@ int orc_bsdf_probe(const orc_scene* sc, int mesh, int op, const float* wi, const
 }
 // EmitterSampler::sample_light probe: out = [pdf, p3, n3, d3, weight3, mesh id (or -kind), pdf kind]
 int orc_sample_light(const orc_scene* sc, const float* p, float r_sel, float r, float ux, float uy, float* out) {
-    LightSampling l = sc->s.sample_light({p[0], p[1], p[2]}, r_sel, r, {ux, uy});
+    LightSampling l = sc->s.sample_light({p[0], p[1], p[2]}, nullptr, r_sel, r, {ux, uy});
     const EmitterRec& em = sc->s.emitters[l.emitter];
     float v[] = {l.pdf.v, l.p.x, l.p.y, l.p.z, l.n.x, l.n.y, l.n.z, l.d.x, l.d.y, l.d.z, l.weight.r, l.weight.g, l.weight.b,
                  (float)(em.kind == EM_MESH ? em.mesh : -em.kind), (float)l.pdf.kind};

@@ -47,6 +47,9 @@ int orc_scene_add_point_light(orc_scene* sc, const float* position, const float*
 int orc_scene_add_directional_light(orc_scene* sc, const float* direction, const float* intensity);
 int orc_scene_set_environment(orc_scene* sc, const float* rgb);
 int orc_scene_set_environment_map(orc_scene* sc, uint32_t w, uint32_t h, const float* rgb);   /* lat-long texture, emitter.rs:300-425 */
+int orc_scene_set_ats(orc_scene* sc, int build_ats);   /* Scene::build_emitters(build_ats), `-x ats` */
+int orc_ats_probe(const orc_scene* sc, int kind, const float* in, float* out);
+int orc_ats_dump(const orc_scene* sc, uint64_t* n_nodes, float* nodes16, uint64_t* n_lights, int32_t* light_emitter, int32_t* light_prim);
 int orc_env_probe(const orc_scene* sc, int kind, const float* in, float* out);
 int orc_scene_build(orc_scene* sc);
 

@@ -29,7 +29,7 @@ PIPELINE_AUTO, PIPELINE_WAVEFRONT, PIPELINE_FUSED = 0, 1, 2
 PUBLIC_SYMBOLS = [
     "rl_scene_create", "rl_scene_destroy", "rl_scene_set_camera", "rl_scene_scale_image", "rl_scene_add_mesh",
     "rl_scene_add_bitmap", "rl_scene_set_medium", "rl_scene_add_point_light", "rl_scene_add_directional_light",
-    "rl_scene_set_environment", "rl_scene_set_environment_map", "rl_scene_build_emitters", "rl_scene_load_pbrt", "rl_scene_load_mitsuba", "rl_scene_load",
+    "rl_scene_set_environment", "rl_scene_set_environment_map", "rl_scene_build_emitters", "rl_scene_enable_ats", "rl_scene_load_pbrt", "rl_scene_load_mitsuba", "rl_scene_load",
     "rl_scene_image_size", "rl_scene_counts", "rl_sampler_seed", "rl_sampler_next_u64", "rl_sampler_next_f32",
     "rl_path_params_default", "rl_context_create", "rl_context_destroy", "rl_last_error", "rl_block_count",
     "rl_generate_block_seeds", "rl_render_path", "rl_render_ao", "rl_render_direct", "rl_trace_batch", "rl_visible_batch", "rl_load_pfm", "rl_load_image", "rl_save_pfm", "rl_save_png", "rl_save_exr", "rl_save_image", "rl_build_info",
@@ -174,6 +174,8 @@ class Scene:
             if sd.environment_map is not None:
                 em = np.ascontiguousarray(sd.environment_map, np.float32)
                 _check(L.rl_scene_set_environment_map(self.h, em.shape[1], em.shape[0], abi.fptr(em)))
+        if sd is not None and getattr(sd, "use_ats", False):
+            _check(L.rl_scene_enable_ats(self.h, 1))
         _check(L.rl_scene_build_emitters(self.h))
 
     @classmethod
@@ -237,6 +239,17 @@ class Scene:
         out = np.zeros(n.value, np.float32)
         _check(L.rl_debug_emitters_cdf(self.h, C.byref(n), abi.fptr(out)))
         return out
+
+    def debug_ats(self):
+        """(nodes [n, 16] f32 — struct LightNode, link words are int32 bit patterns —, light_emitter, light_prim)."""
+        L = lib()
+        i32p = C.POINTER(C.c_int32)
+        L.rl_debug_ats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_uint64), i32p, i32p]
+        nn, nl = C.c_uint64(), C.c_uint64()
+        _check(L.rl_debug_ats(self.h, C.byref(nn), None, C.byref(nl), None, None))
+        nodes = np.zeros((nn.value, 16), np.float32); le = np.zeros(nl.value, np.int32); lp = np.zeros(nl.value, np.int32)
+        _check(L.rl_debug_ats(self.h, C.byref(nn), abi.fptr(nodes), C.byref(nl), le.ctypes.data_as(i32p), lp.ctypes.data_as(i32p)))
+        return nodes, le, lp
 
     def camera_ray(self, px, py):
         o = (C.c_float * 3)()

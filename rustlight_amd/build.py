@@ -13,7 +13,7 @@ LIB = os.path.join(LIB_DIR, "librustlight_amd.so")
 BIN = os.path.join(LIB_DIR, "rustlight-amd")
 
 HIP_SOURCES = ["kernels/wavefront.hip"]
-CXX_SOURCES = ["host/scene.cpp", "host/bvh.cpp", "host/io.cpp", "host/pbrt.cpp", "host/meshio.cpp", "host/mitsuba.cpp"]
+CXX_SOURCES = ["host/scene.cpp", "host/bvh.cpp", "host/io.cpp", "host/pbrt.cpp", "host/meshio.cpp", "host/mitsuba.cpp", "host/lighttree.cpp"]
 # -ffp-contract=off: rustlight's f32 arithmetic is never contracted into FMAs
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-value", "-Wno-unused-function"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -73,7 +73,7 @@ struct MeshRecord {
     uint32_t tri_base;       // first triangle in the global index array
     uint32_t n_tris;
     uint32_t cdf_base;       // first entry of this mesh's area cdf (n_tris + 1 entries)
-    uint32_t pad;
+    uint32_t ats_base;       // light tree: first entry of this mesh's triangles in ats_leaf_of (emissive meshes, when the tree is built)
 };
 enum { MESH_HAS_NORMALS = 1, MESH_HAS_UV = 2, MESH_IS_LIGHT = 4 };
 
@@ -89,6 +89,16 @@ struct EmitterRecord {
     float pad[4];
 };
 static_assert(sizeof(EmitterRecord) == 64, "EmitterRecord must be 64 bytes");
+
+// one node of the `-x ats` light tree: LightBVHNode + the LightBounds fields importance_point reads (emitter.rs:901-935, 1094-1105)
+struct LightNode {
+    float bmin[3], bmax[3];      // bounds.aabb
+    float axis[3];               // bounds.w
+    float phi, cos_theta_o, cos_theta_e;
+    int32_t left, right, parent; // -1 = none
+    int32_t light;               // leaf: index into the light-proxy list; inner: -1
+};
+static_assert(sizeof(LightNode) == 64, "LightNode must be 64 bytes");
 
 struct CameraRecord {   // struct Camera (src/camera.rs:5-15)
     float sample_to_camera[16];  // column-major
@@ -136,6 +146,12 @@ struct DeviceScene {
     const float* env_marg_cdf;     // env_h + 1
     float env_marg_func_int;
     float env_sel_pdf;             // p_sel of the environment emitter (EmitterSampler::pdf)
+    // LightSamplerATS (`-x ats`): ats_root < 0 = plain emitter cdf
+    int32_t ats_root;
+    const LightNode* ats_nodes;
+    const int32_t* ats_light_mesh;     // per light proxy: mesh index
+    const int32_t* ats_light_prim;     // per light proxy: triangle inside the mesh
+    const uint32_t* ats_leaf_of;       // leaf node of (mesh.ats_base + triangle)
     const float* mesh_cdf;         // concatenated per-mesh area cdfs
     uint32_t n_meshes;
     CameraRecord camera;

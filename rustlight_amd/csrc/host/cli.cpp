@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
     size_t nbsamples = 1;
     float scale_image = 1.0f;
     int device = 0;
-    bool single_scattering = false, have_cmd = false;
+    bool single_scattering = false, have_cmd = false, use_ats = false, shading_normals = true;
     std::string cmd, ao_distance = "1.0", average, equal_time;
     bool ao_normal_correction = false;
     size_t nb_bsdf = 1, nb_light = 1;
@@ -53,7 +53,13 @@ int main(int argc, char** argv) {
             else if (a == "--stream-mode") mode = val() == "reference" ? RL_STREAM_REFERENCE_ORDER : RL_STREAM_PER_SAMPLE;
             else if (a == "-a" || a == "--average") average = val();
             else if (a == "-e" || a == "--equal-time") equal_time = val();
-            else if (a == "-l" || a == "-x") { std::fprintf(stderr, "option %s is not supported by this drop-in\n", a.c_str()); return 2; }
+            else if (a == "-x" || a == "--xtra-options") {   // ExtraOptions (cli.rs:41-50): ats | no-shading are honoured
+                const std::string o = val();
+                if (o == "ats") use_ats = true;
+                else if (o == "no-shading") shading_normals = false;
+                else { std::fprintf(stderr, "extra option %s is not supported by this drop-in (ats, no-shading)\n", o.c_str()); return 2; }
+            }
+            else if (a == "-l" || a == "--log") (void)val();   // log file: nothing is logged on this path
             else if (a[0] == '-') { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
             else if (scene_path.empty()) scene_path = a;
             else { std::fprintf(stderr, "only the `path`, `ao` and `direct` subcommands are provided (got %s)\n", a.c_str()); return 2; }
@@ -79,7 +85,7 @@ int main(int argc, char** argv) {
         return 2;
     }
     try {
-        std::unique_ptr<Scene> scene(Scene::load(scene_path));
+        std::unique_ptr<Scene> scene(Scene::load(scene_path, shading_normals));
         scene->nb_samples = nbsamples;
         scene->output_img_path = output;
         {   // medium: sigma_s[:sigma_a[:g]] (cli.rs:355-399)
@@ -96,7 +102,7 @@ int main(int argc, char** argv) {
             }
         }
         if (scale_image != 1.0f) rl_scene_scale_image(scene->handle, scale_image);
-        scene->build_emitters();
+        scene->build_emitters(use_ats);      // scene.build_emitters(use_ats) (cli.rs:432)
         IntegratorPathTracing integrator;
         integrator.min_depth = match_infinity(min_depth);
         integrator.max_depth = match_infinity(max_depth);

@@ -41,7 +41,10 @@ struct Scene {
         if (rc != RL_OK) throw std::runtime_error(std::string("error on loading the scene: ") + rl_last_error());
         return new Scene(h);
     }
-    void build_emitters() { if (rl_scene_build_emitters(handle) != RL_OK) throw std::runtime_error("build_emitters failed"); }
+    void build_emitters(bool build_ats = false) {   // Scene::build_emitters(build_ats) (scene.rs:53-123)
+        if (rl_scene_enable_ats(handle, build_ats ? 1 : 0) != RL_OK || rl_scene_build_emitters(handle) != RL_OK)
+            throw std::runtime_error(std::string("build_emitters failed: ") + rl_last_error());
+    }
 };
 
 struct BufferCollection {   // only the "primal" buffer exists on this path

@@ -212,6 +212,15 @@ int rl_debug_emitters_cdf(const rl_scene* scene, uint64_t* n_entries, float* cdf
     return RL_OK;
 }
 
+// the `-x ats` light tree as built by rl_scene_build_emitters: 16 words per node (struct LightNode) + the light proxies
+int rl_debug_ats(const rl_scene* scene, uint64_t* n_nodes, float* nodes16, uint64_t* n_lights, int32_t* light_emitter, int32_t* light_prim) {
+    if (!scene || !n_nodes || !n_lights || !scene->emitters_built) return RL_ERR_INVALID_ARGUMENT;
+    if (nodes16) std::memcpy(nodes16, scene->ats_nodes.data(), scene->ats_nodes.size() * sizeof(rl::LightNode));
+    if (light_emitter && light_prim) for (size_t i = 0; i < scene->ats_light_emitter.size(); i++) { light_emitter[i] = scene->ats_light_emitter[i]; light_prim[i] = scene->ats_light_prim[i]; }
+    *n_nodes = scene->ats_nodes.size(); *n_lights = scene->ats_light_emitter.size();
+    return RL_OK;
+}
+
 // Camera::generate on the host (src/camera.rs:81-91) — same arithmetic as k_raygen
 int rl_debug_camera_ray(const rl_scene* scene, float px, float py, float* origin, float* direction) {
     if (!scene || !scene->has_camera) return RL_ERR_INVALID_ARGUMENT;

@@ -1,5 +1,6 @@
 // scene.cpp — host-side scene construction (untimed prologue of the render).
 #include "scene.h"
+#include "../kernels/wavefront.h"
 #include "../detmath_shared.h"
 
 #include <algorithm>
@@ -299,7 +300,20 @@ int rl_scene_build_emitters(rl_scene* scene) {
         float fi;
         build_cdf(flux, &scene->emitters_cdf, &fi);
     }
+    scene->ats_root = -1; scene->ats_nodes.clear();
+    if (scene->want_ats) {   // emitter_sampler.build_ats() (scene.rs:118-120)
+        std::string err;
+        int rc = build_light_tree(scene, &err);
+        if (rc != RL_OK) { rl_set_error(err); return rc; }
+    }
     scene->emitters_built = true;
+    return RL_OK;
+}
+
+int rl_scene_enable_ats(rl_scene* scene, int build_ats) {
+    if (!scene) return RL_ERR_INVALID_ARGUMENT;
+    scene->want_ats = build_ats != 0;
+    scene->emitters_built = false;
     return RL_OK;
 }
 

@@ -58,6 +58,13 @@ struct rl_scene {
     std::vector<float> emitters_cdf;        // n + 1
     float bsphere_center[3] = {0, 0, 0};
     float bsphere_radius = 0;
+    // LightSamplerATS, built by rl_scene_build_emitters when want_ats (Scene::build_emitters(build_ats), `-x ats`)
+    bool want_ats = false;
+    int32_t ats_root = -1;
+    std::vector<rl::LightNode> ats_nodes;
+    std::vector<int32_t> ats_light_emitter, ats_light_prim;   // light proxies in tree order
+    std::vector<uint32_t> ats_leaf_of;                        // leaf of (ats_emitter_base[emitter] + triangle)
+    std::vector<uint32_t> ats_emitter_base;
 
     bool rebuild_camera();   // Camera::new
 };
@@ -95,6 +102,7 @@ struct FlatScene {
 };
 void flatten_scene(const rl_scene& scene, FlatScene* out);
 
+int build_light_tree(rl_scene* scene, std::string* err);   // lighttree.cpp
 int read_pfm(const char* path, uint32_t* w, uint32_t* h, std::vector<float>* rgb);   // Bitmap::read_pfm
 int load_pbrt(const char* path, bool use_shading_normals, rl_scene** out, std::string* err);
 

@@ -475,46 +475,130 @@ RL_DEV bool bsphere_intersect(V3 center, float radius, V3 o, V3 d, float tnear, 
     return false;
 }
 
-// EmitterSampler::sample_light (non-ATS, src/emitter.rs:1604-1620) -> Emitter::direct_sample of the picked emitter
-RL_DEV LightSample sample_light(const DeviceScene& sc, V3 p, float r_sel, float r, V2 uv) {
+// Mesh::sample_tri + the direct_sample tail shared by Mesh::direct_sample / direct_sample_tri (geometry.rs:261-337,
+// emitter.rs:609-688): point on triangle `prim` of the mesh, geometry term, solid-angle pdf from `pdf_area`.
+RL_DEV void mesh_sample_triangle(const DeviceScene& sc, const MeshRecord& mr, unsigned int prim, float pdf_area, V3 p, V2 uv, LightSample* ls) {
+    unsigned int gtri = mr.tri_base + prim;
+    unsigned int i0 = sc.tri_indices[3 * gtri], i1 = sc.tri_indices[3 * gtri + 1], i2 = sc.tri_indices[3 * gtri + 2];
+    V3 v0 = mk3(sc.positions[3 * i0], sc.positions[3 * i0 + 1], sc.positions[3 * i0 + 2]);
+    V3 v1 = mk3(sc.positions[3 * i1], sc.positions[3 * i1 + 1], sc.positions[3 * i1 + 2]);
+    V3 v2 = mk3(sc.positions[3 * i2], sc.positions[3 * i2 + 1], sc.positions[3 * i2 + 2]);
+    V2 b = uniform_sample_triangle(uv);
+    float w2 = 1.0f - b.x - b.y;
+    V3 pos = v0 * b.x + v1 * b.y + v2 * w2;
+    V3 n_g = normalize(cross(v2 - v0, v1 - v0));     // (v2-v0) x (v1-v0): geometry.rs:272-276
+    if (mr.flags & MESH_HAS_NORMALS) {
+        V3 n0 = mk3(sc.normals[3 * i0], sc.normals[3 * i0 + 1], sc.normals[3 * i0 + 2]);
+        V3 n1 = mk3(sc.normals[3 * i1], sc.normals[3 * i1 + 1], sc.normals[3 * i1 + 2]);
+        V3 n2 = mk3(sc.normals[3 * i2], sc.normals[3 * i2 + 1], sc.normals[3 * i2 + 2]);
+        V3 n = n0 * b.x + n1 * b.y + n2 * w2;
+        float nl = length2(n);
+        if (nl == 0.0f) n = n_g;
+        else if (nl != 1.0f) n = n / sqrt_rn(nl);
+        if (dot(n_g, n) < 0.0f) n_g = -n_g;
+    }
+    if (pdf_area < 0.0f) pdf_area = div_rn(1.0f, length(cross(v1 - v0, v2 - v0)) * 0.5f);   // sample_tri: PDF::Area(1 / area_tri)
+    V3 d = pos - p;
+    float dist = length(d);
+    if (dist != 0.0f) d = d / dist;
+    float geom = dist != 0.0f ? div_rn(rmax(dot(n_g, -d), 0.0f), dist * dist) : 0.0f;
+    float pdf = geom == 0.0f ? 0.0f : div_rn(pdf_area, geom);   // PDF::as_solid_angle_geom
+    Col emit = mkc(mr.emission[0], mr.emission[1], mr.emission[2]);
+    ls->weight = pdf == 0.0f ? czero() : emit * geom / pdf_area;
+    ls->pdf = pdf; ls->pdf_kind = PDF_SOLID_ANGLE;
+    ls->p = pos; ls->n = n_g; ls->d = d;
+}
+
+// ------------------------------------------------------------------------------------------
+// LightSamplerATS (`-x ats`, src/emitter.rs:901-1086, 1294-1367): the light tree is walked with probabilities
+// proportional to LightBounds::importance_point of the two children.
+// DirectionCone::subtended_directions(aabb, p).cos_theta (emitter.rs:831-846)
+RL_DEV float ats_cos_subtended(V3 bmin, V3 bmax, V3 p) {
+    V3 c = (bmax - bmin) * 0.5f + bmin;                 // AABB::center
+    float radius = length(c - bmax);                    // AABB::to_sphere
+    if (length2(p - c) < radius * radius) return -1.0f;
+    float sin2 = div_rn(radius * radius, length2(c - p));
+    return sqrt_rn(rmax(1.0f - sin2, 0.0f));
+}
+RL_DEV float ats_cos_sub(float sa, float ca, float sb, float cb) { return ca > cb ? 1.0f : ca * cb + sa * sb; }
+RL_DEV float ats_sin_sub(float sa, float ca, float sb, float cb) { return ca > cb ? 1.0f : sa * cb - ca * sb; }
+// LightBounds::importance_point (emitter.rs:1024-1086); two_sided is never set for mesh proxies
+RL_DEV float ats_importance(const LightNode& nd, V3 p, bool has_n, V3 n) {
+    V3 bmin = mk3(nd.bmin[0], nd.bmin[1], nd.bmin[2]), bmax = mk3(nd.bmax[0], nd.bmax[1], nd.bmax[2]);
+    V3 pc = (bmax - bmin) * 0.5f + bmin;
+    float d2 = rmax(length2(p - pc), 0.0001f);
+    V3 wi = normalize(p - pc);
+    float cos_theta = dot(mk3(nd.axis[0], nd.axis[1], nd.axis[2]), wi);
+    float sin_theta = sqrt_rn(rmax(1.0f - cos_theta * cos_theta, 0.0f));
+    float cos_u = ats_cos_subtended(bmin, bmax, p);
+    float sin_u = sqrt_rn(rmax(1.0f - cos_u * cos_u, 0.0f));
+    float sin_o = sqrt_rn(rmax(1.0f - nd.cos_theta_o * nd.cos_theta_o, 0.0f));
+    float cos_x = ats_cos_sub(sin_theta, cos_theta, sin_o, nd.cos_theta_o);
+    float sin_x = ats_sin_sub(sin_theta, cos_theta, sin_o, nd.cos_theta_o);
+    float cos_p = ats_cos_sub(sin_x, cos_x, sin_u, cos_u);
+    if (cos_p <= nd.cos_theta_e) return 0.0f;
+    float imp = div_rn(nd.phi * cos_p, d2);
+    if (has_n) {
+        float cos_i = fabsf(dot(wi, n));
+        float sin_i = sqrt_rn(rmax(1.0f - cos_i * cos_i, 0.0f));
+        imp = imp * ats_cos_sub(sin_i, cos_i, sin_u, cos_u);
+    }
+    return rmax(imp, 0.0f);
+}
+RL_DEV float ats_prob_left(const DeviceScene& sc, const LightNode& nd, V3 p, bool has_n, V3 n) {
+    float il = ats_importance(sc.ats_nodes[nd.left], p, has_n, n), ir = ats_importance(sc.ats_nodes[nd.right], p, has_n, n);
+    return (il == 0.0f && ir == 0.0f) ? 0.5f : div_rn(il, il + ir);
+}
+// LightSamplerATS::sample (emitter.rs:1330-1367): returns the light proxy index, *pdf_sel its probability
+RL_DEV int ats_sample(const DeviceScene& sc, float r, V3 p, bool has_n, V3 n, float* pdf_sel) {
+    float pdf = 1.0f;
+    int ni = sc.ats_root;
+    for (;;) {
+        const LightNode nd = sc.ats_nodes[ni];
+        if (nd.left < 0 && nd.right < 0) { *pdf_sel = pdf; return nd.light; }
+        float pl = ats_prob_left(sc, nd, p, has_n, n);
+        if (r < pl) { r = div_rn(r, pl); ni = nd.left; pdf = pdf * pl; }
+        else { r = div_rn(r - pl, 1.0f - pl); ni = nd.right; pdf = pdf * (1.0f - pl); }
+    }
+}
+// LightSamplerATS::pdf (emitter.rs:1294-1328): product of the branch probabilities from the leaf up to the root
+RL_DEV float ats_pdf(const DeviceScene& sc, unsigned int leaf, V3 p, bool has_n, V3 n) {
+    int id = (int)leaf;
+    float pdf = 1.0f;
+    for (;;) {
+        int ip = sc.ats_nodes[id].parent;
+        if (ip < 0) break;
+        const LightNode nd = sc.ats_nodes[ip];
+        float pl = ats_prob_left(sc, nd, p, has_n, n);
+        pdf = nd.left == id ? pdf * pl : pdf * (1.0f - pl);
+        id = ip;
+    }
+    return pdf;
+}
+
+// EmitterSampler::sample_light (src/emitter.rs:1604-1639) -> Emitter::direct_sample of the emitter picked from the flux cdf,
+// or direct_sample_tri of the (emitter, triangle) picked by the light tree.  `n`: Some(&its.n_s) at surfaces, None in the medium.
+RL_DEV LightSample sample_light(const DeviceScene& sc, V3 p, bool has_n, V3 n, float r_sel, float r, V2 uv) {
+    if (sc.ats_root >= 0) {
+        float pdf_sel;
+        int li = ats_sample(sc, r_sel, p, has_n, n, &pdf_sel);
+        LightSample ls;
+        ls.kind = EMITTER_MESH;
+        mesh_sample_triangle(sc, sc.meshes[sc.ats_light_mesh[li]], (unsigned int)sc.ats_light_prim[li], -1.0f, p, uv, &ls);
+        ls.weight = div_unguarded(ls.weight, pdf_sel);
+        ls.pdf = ls.pdf * pdf_sel;
+        return ls;
+    }
     unsigned int id = cdf_sample(sc.emitters_cdf, sc.n_emitters + 1, r_sel);
     float pdf_sel = sc.emitters_cdf[id + 1] - sc.emitters_cdf[id];
     const EmitterRecord em = sc.emitters[id];
     LightSample ls;
     ls.kind = em.kind;
     if (em.kind == EMITTER_MESH) {
-        // Mesh::direct_sample -> Mesh::sample -> sample_tri (emitter.rs:652-688, geometry.rs:261-348)
+        // Mesh::direct_sample -> Mesh::sample: triangle by area cdf, pdf = Area(1 / cdf.total()) (emitter.rs:652-688, geometry.rs:340-348)
         MeshRecord mr = sc.meshes[em.mesh];
         unsigned int prim = cdf_sample(sc.mesh_cdf + mr.cdf_base, mr.n_tris + 1, r);
-        unsigned int gtri = mr.tri_base + prim;
-        unsigned int i0 = sc.tri_indices[3 * gtri], i1 = sc.tri_indices[3 * gtri + 1], i2 = sc.tri_indices[3 * gtri + 2];
-        V3 v0 = mk3(sc.positions[3 * i0], sc.positions[3 * i0 + 1], sc.positions[3 * i0 + 2]);
-        V3 v1 = mk3(sc.positions[3 * i1], sc.positions[3 * i1 + 1], sc.positions[3 * i1 + 2]);
-        V3 v2 = mk3(sc.positions[3 * i2], sc.positions[3 * i2 + 1], sc.positions[3 * i2 + 2]);
-        V2 b = uniform_sample_triangle(uv);
-        float w2 = 1.0f - b.x - b.y;
-        V3 pos = v0 * b.x + v1 * b.y + v2 * w2;
-        V3 n_g = normalize(cross(v2 - v0, v1 - v0));     // (v2-v0) x (v1-v0): geometry.rs:272-276
-        if (mr.flags & MESH_HAS_NORMALS) {
-            V3 n0 = mk3(sc.normals[3 * i0], sc.normals[3 * i0 + 1], sc.normals[3 * i0 + 2]);
-            V3 n1 = mk3(sc.normals[3 * i1], sc.normals[3 * i1 + 1], sc.normals[3 * i1 + 2]);
-            V3 n2 = mk3(sc.normals[3 * i2], sc.normals[3 * i2 + 1], sc.normals[3 * i2 + 2]);
-            V3 n = n0 * b.x + n1 * b.y + n2 * w2;
-            float nl = length2(n);
-            if (nl == 0.0f) n = n_g;
-            else if (nl != 1.0f) n = n / sqrt_rn(nl);
-            if (dot(n_g, n) < 0.0f) n_g = -n_g;
-        }
-        float pdf_area = mr.inv_area;                      // res.pdf = Area(1 / cdf.total())
-        V3 d = pos - p;
-        float dist = length(d);
-        if (dist != 0.0f) d = d / dist;
-        float geom = dist != 0.0f ? div_rn(rmax(dot(n_g, -d), 0.0f), dist * dist) : 0.0f;
-        float pdf = geom == 0.0f ? 0.0f : div_rn(pdf_area, geom);   // PDF::as_solid_angle_geom
-        Col emit = mkc(mr.emission[0], mr.emission[1], mr.emission[2]);
-        ls.weight = pdf == 0.0f ? czero() : emit * geom / pdf_area;
-        ls.pdf = pdf; ls.pdf_kind = PDF_SOLID_ANGLE;
-        ls.p = pos; ls.n = n_g; ls.d = d;
+        mesh_sample_triangle(sc, mr, prim, mr.inv_area, p, uv, &ls);
     } else if (em.kind == EMITTER_POINT) {                 // PointEmitter::direct_sample (emitter.rs:194-213)
         V3 lp = mk3(em.v[0], em.v[1], em.v[2]);
         V3 d = lp - p;
@@ -547,9 +631,25 @@ RL_DEV LightSample sample_light(const DeviceScene& sc, V3 p, float r_sel, float 
     return ls;
 }
 
-// EmitterSampler::direct_pdf for a mesh light hit by a BSDF-sampled ray (emitter.rs:571-579, 1566-1575)
-RL_DEV float light_direct_pdf(const MeshRecord& mr, V3 o, V3 p, V3 n, V3 dir) {
+// EmitterSampler::direct_pdf for a mesh light hit by a BSDF-sampled ray (emitter.rs:571-589, 1566-1603).  With the light
+// tree: pdf of the hit triangle (1 / its area) x the probability of reaching its leaf; `n` as the caller passes it
+// (None from the path tracer's MIS, Some(&its.n_s) from `direct`).
+RL_DEV float light_direct_pdf(const DeviceScene& sc, const MeshRecord& mr, int prim_in_mesh, V3 o, V3 p, V3 n, V3 dir, bool has_ns, V3 ns) {
     float cos_light = rmax(dot(n, -dir), 0.0f);
+    if (sc.ats_root >= 0) {
+        float tri = 0.0f;
+        if (cos_light != 0.0f) {
+            float geom = div_rn(cos_light, length2(p - o));
+            unsigned int gtri = mr.tri_base + (unsigned int)prim_in_mesh;
+            unsigned int i0 = sc.tri_indices[3 * gtri], i1 = sc.tri_indices[3 * gtri + 1], i2 = sc.tri_indices[3 * gtri + 2];
+            V3 v0 = mk3(sc.positions[3 * i0], sc.positions[3 * i0 + 1], sc.positions[3 * i0 + 2]);
+            V3 v1 = mk3(sc.positions[3 * i1], sc.positions[3 * i1 + 1], sc.positions[3 * i1 + 2]);
+            V3 v2 = mk3(sc.positions[3 * i2], sc.positions[3 * i2 + 1], sc.positions[3 * i2 + 2]);
+            float area_tri = length(cross(v1 - v0, v2 - v0)) * 0.5f;                 // Mesh::pdf_tri (geometry.rs:226-234)
+            tri = div_rn(div_rn(1.0f, area_tri), geom);
+        }
+        return tri * ats_pdf(sc, sc.ats_leaf_of[mr.ats_base + (unsigned int)prim_in_mesh], o, has_ns, ns);
+    }
     if (cos_light == 0.0f) return 0.0f * mr.emitter_pdf;
     float geom = div_rn(cos_light, length2(p - o));
     return div_rn(mr.inv_area, geom) * mr.emitter_pdf;

@@ -17,5 +17,6 @@ int rl_debug_bvh(const rl_scene* scene, uint64_t* n_nodes, uint64_t* n_prims, fl
                  int32_t* prim_mesh, int32_t* prim_tri);
 // host-only: Camera::generate for one pixel position
 int rl_debug_emitters_cdf(const rl_scene* scene, uint64_t* n_entries, float* cdf);
+int rl_debug_ats(const rl_scene* scene, uint64_t* n_nodes, float* nodes16, uint64_t* n_lights, int32_t* light_emitter, int32_t* light_prim);
 int rl_debug_camera_ray(const rl_scene* scene, float px, float py, float* origin, float* direction);
 }

@@ -551,7 +551,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
                     // LightSamplingStrategy::pdf -> pdf_emitter (strategies/emitters.rs:10-92,250-282)
                     float p2 = 0.0f;
                     if (!is_volume && (mr.flags & MESH_IS_LIGHT) && (prev == PREV_SURFACE || prev == PREV_VOLUME))
-                        p2 = light_direct_pdf(mr, ro, sp.p, sp.n_g, rd);
+                        p2 = light_direct_pdf(sc, mr, sc.tris[prim].tri, ro, sp.p, sp.n_g, rd, false, mk3(0.0f, 0.0f, 0.0f));   // n = None (emitters.rs:52-57)
                     float total = (0.0f + pdf_edge) + p2;
                     wmis = div_rn(pdf_edge, total);                             // balance heuristic (path.rs:80-98)
                 }
@@ -616,7 +616,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
                 V2 c; c.x = rng_next_f32(rng); c.y = rng_next_f32(rng);
                 n_draws += 4;
                 n_shadow += 1;     // the reference always traces the shadow ray (emitters.rs:125-126)
-                LightSample ls = sample_light(sc, vp, a, b, c);
+                LightSample ls = sample_light(sc, vp, !is_volume, is_volume ? mk3(0.0f, 0.0f, 0.0f) : sp.n_s, a, b, c);   // Some(&its.n_s) | None
                 if (ls.pdf != 0.0f) {
                     Col wl;
                     float p_dir;
@@ -901,7 +901,7 @@ RL_DEV Col mc_compute_pixel(const DeviceScene& sc, const SceneRecs& recs, const 
         float b = rng_next_f32(rng);
         V2 c; c.x = rng_next_f32(rng); c.y = rng_next_f32(rng);
         n_draws += 4;
-        LightSample ls = sample_light(sc, sp.p, a, b, c);
+        LightSample ls = sample_light(sc, sp.p, true, sp.n_s, a, b, c);   // Some(&its.n_s) (direct.rs:64-70)
         V3 d_out_local = to_local(sp.frame, ls.d);
         if (ls.pdf == 0.0f) continue;
         n_shadow++;
@@ -925,7 +925,7 @@ RL_DEV Col mc_compute_pixel(const DeviceScene& sc, const SceneRecs& recs, const 
             if ((nm.flags & MESH_IS_LIGHT) && dot(nx.n_g, -d_out_world) > 0.0f) {
                 float weight_bsdf = 1.0f;
                 if (bs.pdf_kind == PDF_SOLID_ANGLE) {
-                    float light_pdf = light_direct_pdf(nm, sp.p, nx.p, nx.n_g, d_out_world);
+                    float light_pdf = light_direct_pdf(sc, nm, sc.tris[h2.prim].tri, sp.p, nx.p, nx.n_g, d_out_world, true, sp.n_s);   // direct.rs:156-164
                     weight_bsdf = mis_weight_power(bs.pdf * w_nb_bsdf, light_pdf * w_nb_light);
                 }
                 l_i = l_i + weight_bsdf * bs.weight * mkc(nm.emission[0], nm.emission[1], nm.emission[2]) * w_nb_bsdf;
@@ -1146,7 +1146,19 @@ extern "C" int rl_context_create(const rl_scene* scene, int device, rl_context**
         if ((rc = upload(ctx, flat.positions, &ds.positions)) != RL_OK) break;
         if ((rc = upload(ctx, flat.normals, &ds.normals)) != RL_OK) break;
         if ((rc = upload(ctx, flat.uvs, &ds.uvs)) != RL_OK) break;
+        // `-x ats`: every emissive mesh learns where its triangles' leaves are listed; the tree itself is uploaded below
+        for (MeshRecord& mr : flat.meshes) mr.ats_base = 0xffffffffu;
+        std::vector<int32_t> ats_light_mesh;
+        if (scene->ats_root >= 0) {
+            for (size_t e = 0; e < scene->emitters.size(); e++) flat.meshes[scene->emitters[e].mesh].ats_base = scene->ats_emitter_base[e];
+            for (int32_t e : scene->ats_light_emitter) ats_light_mesh.push_back(scene->emitters[e].mesh);
+        }
         if ((rc = upload(ctx, flat.meshes, &ds.meshes)) != RL_OK) break;
+        ds.ats_root = scene->ats_root;
+        if ((rc = upload(ctx, scene->ats_nodes, &ds.ats_nodes)) != RL_OK) break;
+        if ((rc = upload(ctx, ats_light_mesh, &ds.ats_light_mesh)) != RL_OK) break;
+        if ((rc = upload(ctx, scene->ats_light_prim, &ds.ats_light_prim)) != RL_OK) break;
+        if ((rc = upload(ctx, scene->ats_leaf_of, &ds.ats_leaf_of)) != RL_OK) break;
         if ((rc = upload(ctx, flat.materials, &ds.materials)) != RL_OK) break;
         if ((rc = upload(ctx, flat.bitmaps, &ds.bitmaps)) != RL_OK) break;
         if ((rc = upload(ctx, flat.bitmap_texels, &ds.bitmap_texels)) != RL_OK) break;

@@ -87,6 +87,7 @@ class SceneData:
     lights: list = field(default_factory=list)           # [{"type": "point"|"directional", "a": position|direction, "intensity": rgb}]
     environment: Optional[tuple] = None                  # EnvironmentLightColor::Constant(rgb)
     environment_map: Optional[np.ndarray] = None         # EnvironmentLightColor::Texture: H x W x 3 lat-long image (z up)
+    use_ats: bool = False                                # Scene::build_emitters(build_ats): the `-x ats` light tree
 
     @property
     def n_triangles(self) -> int:
@@ -221,6 +222,30 @@ def sky_scene(width: int = 64, height: int = 64, keep_area_light: bool = False) 
     keep = {"Floor", "ShortBox", "TallBox"} | ({"Light"} if keep_area_light else set())
     sd.meshes = [m for m in sd.meshes if m.name in keep]
     sd.environment_map = sky_map()
+    return sd
+
+
+def many_lights(width: int = 64, height: int = 64, n: int = 5, use_ats: bool = True, glowing_spheres: int = 0) -> SceneData:
+    """Cornell box whose single light is replaced by an n x n grid of small emissive quads under the ceiling, with emission
+    varying over two decades and alternating tilt — the many-light case the `-x ats` light tree is for."""
+    sd = cbox(width, height)
+    sd.meshes = [m for m in sd.meshes if m.name != "Light"]
+    k = 0
+    for i in range(n):
+        for j in range(n):
+            cx = -0.8 + 1.6 * (i + 0.5) / n
+            cz = -0.8 + 1.6 * (j + 0.5) / n
+            h = 0.06
+            tilt = 0.05 * ((i + 2 * j) % 3 - 1)
+            e = 0.5 * (1.0 + ((7 * i + 3 * j) % 11)) ** 2 / 4.0
+            P = [cx - h, 1.95 + tilt, cz - h, cx + h, 1.95 - tilt, cz - h, cx + h, 1.95 - tilt, cz + h, cx - h, 1.95 + tilt, cz + h]
+            sd.meshes.append(_quad_mesh(f"L{k}", P, [0, -1, 0], matte((0.0, 0.0, 0.0)), emission=(e, 0.8 * e, 0.5 * e)))
+            k += 1
+    for q in range(glowing_spheres):        # emissive tessellated spheres: light-triangle normals in every direction (cone unions, rotations)
+        v, idx, nrm, uv = uv_sphere((-0.55 + 0.55 * q, 0.35 + 0.3 * q, 0.45 - 0.25 * q), 0.12 + 0.03 * q, 6, 8)
+        e = 3.0 + 2.0 * q
+        sd.meshes.append(MeshData(f"Glow{q}", v, idx, nrm, uv, matte((0.0, 0.0, 0.0)), emission=(e, e, 0.7 * e)))
+    sd.use_ats = use_ats
     return sd
 
 

@@ -69,6 +69,23 @@ def test_host_bvh_and_camera_equal_oracle(built, maker):
     assert ps.counts()["emitters"] == os_.info()["emitters"]
 
 
+@pytest.mark.parametrize("maker", [lambda: scenes.many_lights(32, 32, 4, glowing_spheres=3), lambda: scenes.many_lights(16, 16, 1), lambda: scenes.cbox(16, 16)])
+def test_light_tree_build_matches_the_oracle(built, maker):
+    """`rl_scene_enable_ats`: the host builds LightSamplerATS (cone unions, bucketed split, itertools::partition order)
+    bit for bit like the oracle — nodes, links and the reordered light list."""
+    sd = maker()
+    sd.use_ats = True
+    got, want = api.Scene(sd).debug_ats(), orc.Scene(sd).ats_dump()
+    np.testing.assert_array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
+    np.testing.assert_array_equal(got[1], want[1])
+    np.testing.assert_array_equal(got[2], want[2])
+    assert got[0].shape[0] == 2 * len(got[1]) - 1
+    with pytest.raises(api.RustlightError):                # assert!(e.is_surface()): point lights cannot enter the tree
+        bad = scenes.cbox_other_lights(16, 16, environment=False, directional=False)
+        bad.use_ats = True
+        api.Scene(bad)
+
+
 def test_pbrt_loader_round_trip(built, tmp_path):
     sd = scenes.cbox(128, 96)
     p = str(tmp_path / "cbox.pbrt")

@@ -200,6 +200,29 @@ def test_textured_environment_parity(built, keep_area_light, pipeline):
         assert out[0].mean() > 0.02
 
 
+@pytest.mark.parametrize("pipeline", [api.PIPELINE_WAVEFRONT, api.PIPELINE_FUSED])
+def test_light_tree_sampling_parity(built, pipeline):
+    """`-x ats` — NEE draws (emitter, triangle) by descending the light tree with
+    importance_point(p, Some(n_s) | None), MIS evaluates the tree pdf of the triangle a BSDF ray hit (n = None): bit-exact
+    against the oracle for path (all strategies, with a medium) and direct."""
+    sd = scenes.many_lights(48, 40, 3, glowing_spheres=2)
+    ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+    for kw in (dict(spp=4), dict(spp=2, strategy=api.STRATEGY_EMITTER), dict(spp=2, strategy=api.STRATEGY_BSDF, max_depth=5), dict(spp=2, stream_mode=api.STREAM_REFERENCE_ORDER, max_depth=4)):
+        out = _render_pair(sd, ctx, osc, pipeline=pipeline, **kw)
+        _assert_parity(*out)
+        assert out[0].mean() > 0.05
+    fog = scenes.many_lights(32, 32, 2, glowing_spheres=1)
+    fog.medium = scenes.Medium((0.05, 0.05, 0.05), (0.4, 0.4, 0.4))
+    _assert_parity(*_render_pair(fog, spp=3, pipeline=pipeline, max_depth=6))
+    if pipeline == api.PIPELINE_WAVEFRONT:
+        seeds = api.IndependentSampler(4).block_seeds(sd.width, sd.height)
+        for kw in (dict(), dict(nb_bsdf_samples=2, nb_light_samples=2)):
+            img, st = ctx.render_direct(seeds, spp=3, **kw)
+            ref, ost = osc.render_direct(seeds=seeds, spp=3, **kw)
+            np.testing.assert_array_equal(img, ref)
+            assert all(st[k] == ost[k] for k in ("camera_samples", "extension_rays", "shadow_rays", "rng_draws"))
+
+
 @pytest.mark.parametrize("mode", [api.STREAM_PER_SAMPLE, api.STREAM_REFERENCE_ORDER])
 def test_ao_and_direct_integrators_parity(built, mode):
     """`ao` and `direct` through the same tiling driver, bit-exact vs the oracle."""

@@ -162,6 +162,44 @@ def test_textured_environment(built):
     assert max(means) - min(means) < 0.06 * np.mean(means), means
 
 
+def test_light_tree(built):
+    """the `-x ats` light tree (LightSamplerATS): structure, a proper probability over the
+    leaves, sample() consistent with pdf(), and an estimator that agrees with the flux-cdf sampler."""
+    sd = scenes.many_lights(32, 32, 3, glowing_spheres=2)
+    sc = orc.Scene(sd)
+    nodes, le, lp = sc.ats_dump()
+    links = nodes[:, 12:].view(np.int32)
+    n_lights = sum(m.indices.shape[0] for m in sd.meshes if m.emission is not None)
+    assert len(le) == n_lights and nodes.shape[0] == 2 * n_lights - 1
+    leaves = links[:, 0] < 0
+    assert leaves.sum() == n_lights and sorted(links[leaves, 3]) == list(range(n_lights))      # every light is exactly one leaf
+    root = nodes.shape[0] - 1                                                                    # post-order: the root comes last
+    assert links[root, 2] == -1 and (links[:root, 2] >= 0).all()
+    for i in np.nonzero(~leaves)[0]:
+        assert links[links[i, 0], 2] == i and links[links[i, 1], 2] == i
+        assert abs(nodes[i, 9] - (nodes[links[i, 0], 9] + nodes[links[i, 1], 9])) <= 1e-5 * nodes[i, 9]   # phi adds up
+        assert (nodes[i, :3] <= nodes[links[i, 0], :3]).all() and (nodes[i, 3:6] >= nodes[links[i, 1], 3:6]).all()
+    rng = np.random.default_rng(5)
+    for _ in range(6):
+        p = rng.uniform(-0.9, 0.9, 3).astype(np.float32); p[1] = abs(p[1])
+        n = rng.normal(size=3); n = (n / np.linalg.norm(n)).astype(np.float32)
+        for has_n in (0.0, 1.0):
+            total = sum(sc.ats_probe(1, [le[k], lp[k], *p, *n, has_n])[0] for k in range(n_lights))
+            assert abs(total - 1.0) < 1e-4, total                                                # the branch probabilities telescope to 1
+            for r in rng.uniform(0, 1, 8).astype(np.float32):
+                e, prim, pdf_sel = sc.ats_probe(0, [r, *p, *n, has_n])[:3]
+                assert pdf_sel > 0 and abs(sc.ats_probe(1, [e, prim, *p, *n, has_n])[0] - pdf_sel) <= 1e-5 * pdf_sel
+    # same expectation as the flux-cdf sampler (pure NEE, one bounce), with less noise on this many-light scene
+    flat = scenes.many_lights(32, 32, 3, glowing_spheres=2, use_ats=False)
+    a = orc.Scene(sd).render(master_seed=3, spp=128, strategy=2, max_depth=2)[0]
+    b = orc.Scene(flat).render(master_seed=4, spp=128, strategy=2, max_depth=2)[0]
+    assert abs(a.mean() - b.mean()) < 0.03 * b.mean(), (a.mean(), b.mean())
+    # the direct integrator takes the tree through both of its techniques (MIS pdf with n = Some(n_s))
+    d1 = orc.Scene(sd).render_direct(master_seed=5, spp=64)[0]
+    d2 = orc.Scene(flat).render_direct(master_seed=6, spp=64)[0]
+    assert abs(d1.mean() - d2.mean()) < 0.05 * d2.mean(), (d1.mean(), d2.mean())
+
+
 def test_ao_and_direct(built, orc_cbox64):
     ao, st = orc_cbox64.render_ao(master_seed=1, spp=8)
     assert set(np.unique(ao)).issubset({i / 8 for i in range(9)}) and 0.2 < ao.mean() < 0.9        # occlusion is 0/1 per sample
