@@ -1317,13 +1317,19 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     const bool fused = params->pipeline == 2 || (params->pipeline == 0 && ctx->single_bsdf && per_sample && params->pool_slots == 0);
     // sample-parallel pixels: `split` lanes per pixel, per-sample radiances parked in HBM ([spp][pixel][3] floats) and folded
     // in order.  Auto: scenes that traverse out of L2 / HBM want ~8 M paths in flight per wavefront launch (measured on the
-    // 508 k-triangle living-room scene at 1080p: 1 lane/pixel 935 ms, 4 lanes 787 ms, 8 lanes 836 ms); LDS-staged scenes and
-    // the persistent kernel are VALU-bound and only pay for the extra state, so they stay at one lane per pixel.
+    // 508 k-triangle living-room scene at 1080p: 1 lane/pixel 935 ms, 4 lanes 787 ms, 8 lanes 836 ms); LDS-staged scenes in the
+    // wavefront pipeline are VALU-bound and only pay for the extra state, so they stay at one lane per pixel.
     // The parking buffer is capped (kSampleBufBudget), beyond it one lane per pixel.
     unsigned split = 1;
     if (per_sample && n_pixels > 0) {
+        // The persistent kernel keeps 4 x 256-lane workgroups per CU resident; a shard with few pixel tiles but many samples
+        // per pixel (rank r of N at spp = 128 N: 1020 tiles at N = 8) leaves most of those slots empty once the tiles that
+        // look past the scene have drained, so it is cut into >= ~16 k workgroups (measured, rank 0 of 8 at 1024 spp:
+        // 1 lane / pixel 122 ms, 8 lanes 69 ms, 16 lanes 69 ms; a full 8160-tile frame is best left at 1 lane: 64 vs 67 ms).
+        const unsigned fused_groups = (n_pixels + 255u) / 256u;
+        const unsigned fused_auto = fused_groups >= 6000u ? 1u : (16384u + fused_groups - 1u) / std::max(1u, fused_groups);
         const unsigned want = params->sample_split ? params->sample_split
-                            : ((fused || ctx->lds_scene) ? 1u : std::max(1u, (8u << 20) / std::max(1u, n_pixels)));
+                            : (fused ? fused_auto : (ctx->lds_scene ? 1u : std::max(1u, (8u << 20) / std::max(1u, n_pixels))));
         split = std::max(1u, std::min(want, params->spp));
         if ((size_t)n_pixels * params->spp * 3 * sizeof(float) > kSampleBufBudget) split = 1;
         while (split > 1 && (size_t)n_pixels * split > (size_t)0x7fffff00u) split--;
