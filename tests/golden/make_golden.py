@@ -7,6 +7,8 @@ self-check without it:  python tests/golden/make_golden.py
   draws_block0_seed0.npy                                   first 64 f32 draws of block 0's sampler
   trace_cbox_kat.npz                                       512 rays + (t, u, v, mesh, tri) hits
   pixel_kat.npz                                            per-sample radiance / draw counts of 32 camera samples
+  features.npz                                             40x32 forward-order renders (eval_order = 1, what the kernels
+                                                           reproduce bit for bit) of one scene per widened feature
 """
 import os
 import sys
@@ -21,7 +23,34 @@ from rustlight_amd import scenes  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def feature_cases():
+    """name -> (SceneData, integrator, kwargs): shared with tests/test_gpu_parity.py::test_golden_feature_renders."""
+    fog = scenes.cbox_medium(40, 32, 0.5, 0.05, g=0.4)
+    return {
+        "medium_hg": (fog, "path", dict(spp=2, max_depth=8)),
+        "mixed_materials": (scenes.living_room(40, 32, n_spheres=12, tess=8), "path", dict(spp=2)),
+        "other_emitters": (scenes.cbox_other_lights(40, 32), "path", dict(spp=2)),
+        "environment_map": (scenes.sky_scene(40, 32, keep_area_light=True), "path", dict(spp=2)),
+        "light_tree": (scenes.many_lights(40, 32, 3, glowing_spheres=2), "path", dict(spp=2)),
+        "light_tree_direct": (scenes.many_lights(40, 32, 3, glowing_spheres=2), "direct", dict(spp=2)),
+        "ao": (scenes.cbox(40, 32), "ao", dict(spp=2, max_distance=0.5)),
+        "reference_order": (scenes.cbox(40, 32), "path", dict(spp=2, stream_mode=0)),
+    }
+
+
 def main():
+    feats = {}
+    for name, (fsd, integ, kw) in feature_cases().items():
+        fsc = orc.Scene(fsd)
+        if integ == "path":
+            img, _ = fsc.render(master_seed=7, eval_order=1, **kw)
+        elif integ == "direct":
+            img, _ = fsc.render_direct(master_seed=7, **kw)
+        else:
+            img, _ = fsc.render_ao(master_seed=7, **kw)
+        feats[name] = img
+        print(name, float(img.mean()))
+    np.savez_compressed(os.path.join(HERE, "features.npz"), **feats)
     sd = scenes.cbox(64, 64)
     sc = orc.Scene(sd)
     for mode, name in ((0, "reference_order"), (1, "per_sample")):

@@ -17,6 +17,17 @@ def test_golden_images(built, orc_cbox64):
         assert st["camera_samples"] == 64 * 64 * 4
 
 
+def test_golden_feature_renders(built):
+    """One committed forward-order render per widened feature (medium, mixed BSDFs, emitters, environment map, light tree, ao,
+    direct, reference-order streams): the oracle must not drift from them."""
+    from tests.golden.make_golden import feature_cases
+    gold = np.load(os.path.join(GOLD, "features.npz"))
+    for name, (sd, integ, kw) in feature_cases().items():
+        sc = orc.Scene(sd)
+        img = (sc.render(master_seed=7, eval_order=1, **kw) if integ == "path" else sc.render_direct(master_seed=7, **kw) if integ == "direct" else sc.render_ao(master_seed=7, **kw))[0]
+        np.testing.assert_array_equal(img, gold[name], err_msg=name)
+
+
 def test_golden_draws_and_pixels(built, orc_cbox64):
     seeds = orc.block_seeds(0, 64, 64)
     r = orc.Rng(int(seeds[0]))
