@@ -308,6 +308,29 @@ def test_progressive_wrappers(built, cbox64, tmp_path):
     np.testing.assert_array_equal(one, passes[0])
 
 
+def test_degenerate_inputs(built):
+    """Empty scene (no mesh at all, with and without an environment), a 1 x 1 image, a 17 x 1 strip, spp = 1, a mesh-less scene lit
+    by a point light only: no crash, same bits as the oracle."""
+    to_world = np.asarray(scenes.CBOX_TO_WORLD, np.float32)
+    empty = scenes.SceneData(20, 12, 40.0, 0, to_world, False, [])
+    out = _render_pair(empty, spp=2, strategy=api.STRATEGY_BSDF)
+    _assert_parity(*out)
+    assert out[0].max() == 0.0
+    sky = scenes.SceneData(20, 12, 40.0, 0, to_world, False, [], environment=(0.25, 0.5, 1.0))
+    out = _render_pair(sky, spp=2)
+    _assert_parity(*out)
+    np.testing.assert_array_equal(out[0][3, 4], np.asarray([0.25, 0.5, 1.0], np.float32))
+    for (w, h) in ((1, 1), (17, 1), (1, 33)):
+        for pl in (api.PIPELINE_WAVEFRONT, api.PIPELINE_FUSED):
+            _assert_parity(*_render_pair(scenes.cbox(w, h), spp=1, pipeline=pl))
+    floor_only = scenes.SceneData(24, 16, 30.0, 0, np.asarray([1, 0, 0, 0, 0, 0, 1, 0, 0, -1, 0, 0, 0, 3, 0, 1], np.float32), False,
+                                  [scenes._quad_mesh("Floor", [-5, 0, -5, -5, 0, 5, 5, 0, 5, 5, 0, -5], [0, 1, 0], scenes.matte((0.5, 0.5, 0.5)))],
+                                  lights=[{"type": "point", "a": (0.0, 2.0, 0.0), "intensity": (3.0, 3.0, 3.0)}])
+    out = _render_pair(floor_only, spp=2)
+    _assert_parity(*out)
+    assert out[0].mean() > 0.01
+
+
 def test_furnace_invariant_on_gpu(built):
     sd = scenes.furnace(albedo=0.5, le=1.0, width=16, height=16)
     ctx = api.Context(api.Scene(sd), 0)
