@@ -1,0 +1,184 @@
+// pathstate.hip.h — path-state pool (SoA fields, flags), the three state accessors the stage functions are written against,
+// render constants, block-local statistics / stream compaction helpers.
+// Part of the single translation unit wavefront.hip (included once, after devmath / shading / trace).
+#pragma once
+
+namespace rl {
+
+// ------------------------------------------------------------------------------------------
+// path-state pool (SoA): field f of slot i is at base[f * P + i]
+enum FField {
+    F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ,         // extension ray (origin doubles as the NEE origin)
+    F_T, F_U, F_V,                               // hit record (with U_PRIM)
+    F_BR, F_BG, F_BB,                            // beta: throughput of evaluate()'s edge products
+    F_TR, F_TG, F_TB,                            // thr: generate()'s Russian-roulette throughput
+    F_LR, F_LG, F_LB,                            // radiance of the current sample
+    F_AR, F_AG, F_AB,                            // pixel accumulator (sum over samples, in sample order)
+    F_WR, F_WG, F_WB,                            // weight of the edge being traced (BSDF / phase weight)
+    F_RR, F_PDF,                                 // its rr_weight and directional pdf
+    F_SX, F_SY, F_SZ,                            // NEE target point on the light
+    F_CR, F_CG, F_CB,                            // NEE contribution, already times beta and MIS weight
+    F_XI,                                        // medium distance-sampling random number of the edge
+    F_COUNT
+};
+enum UField { U_FLAGS, U_DEPTH, U_PRIM, U_ITEM, U_CURSOR, U_SAMPLE, U_COUNT };
+enum QField { Q_R0, Q_R1, Q_R2, Q_R3, Q_I0, Q_I1, Q_I2, Q_I3, Q_COUNT };
+
+enum : unsigned {
+    ST_FINISHED = 1u,      // slot has no work left
+    ST_REGEN = 2u,         // sample ended: raygen must fold it and start the next one
+    ST_FRESH = 4u,         // no sample has run in this slot yet
+    ST_RAY = 8u,           // extension ray valid
+    ST_SHADOW = 16u,       // NEE shadow ray valid
+    ST_PREV_SHIFT = 5u,    // 2 bits: kind of the vertex the traced edge leaves
+    ST_PDF_SA = 128u,      // edge pdf is PDF::SolidAngle (else Discrete)
+    ST_ZEROED = 256u,      // single_scattering: a surface vertex has been passed (path.rs:122-124)
+};
+enum : unsigned { PREV_SENSOR = 0u, PREV_SURFACE = 1u, PREV_SURFACE_SMOOTH = 2u, PREV_VOLUME = 3u };
+
+#ifndef RL_FUSED_WAVES
+#define RL_FUSED_WAVES 4   // min waves per SIMD requested for the persistent fused kernel (<= 168 VGPRs)
+#endif
+static constexpr unsigned kDepthCap = 2048u;   // same cut as the oracle (NaN-throughput paths never die)
+
+struct Pool {
+    float* f;
+    unsigned* u;
+    unsigned long long* q;
+    unsigned P;
+};
+
+struct Counters {
+    unsigned int active;        // slots that still own work
+    unsigned int next_item;     // work-item dispenser
+    unsigned int pad[2];
+};
+
+static constexpr int kLdsStackLevels = 12;   // stack levels kept in LDS per lane
+static constexpr size_t kSampleBufBudget = (size_t)16 << 30;   // bytes of HBM the per-sample parking buffer may take
+// traversal stack configuration (see TravStack)
+struct StackConf { int lds_levels; int* overflow; size_t overflow_stride; };
+
+template <bool LDS_ONLY = false>
+RL_DEV TravStackT<LDS_ONLY> make_stack(const StackConf& sc_, unsigned* lds_after_list, size_t global_thread) {
+    TravStackT<LDS_ONLY> st;
+    st.lds = reinterpret_cast<int2*>(lds_after_list) + threadIdx.x;
+    st.lds_stride = (int)blockDim.x;
+    st.lds_levels = sc_.lds_levels;
+    st.glob = sc_.overflow ? sc_.overflow + global_thread : nullptr;
+    st.glob_stride = sc_.overflow_stride;
+    return st;
+}
+
+struct RenderConst {
+    // IntegratorPathTracing fields (explicit/path.rs:14-20)
+    unsigned spp;
+    int has_min, has_max, has_rr;
+    unsigned min_depth, max_depth, rr_depth;
+    int strategy, single_scattering;
+    int stream_mode, seed_variant;
+    float inv_spp;
+    // image / work decomposition
+    unsigned W, H, nby;
+    unsigned n_items;
+    unsigned split;                     // per-sample mode: lanes per pixel (sample s of a pixel runs on lane s % split)
+    float* sample_buf;                  // split > 1: [spp][n_items / split][3] per-sample radiance, folded in order by k_fold_samples
+    const unsigned* owned_blocks;       // block ids of this shard, in creation order
+    const unsigned* block_item_base;    // per owned block: first pixel item (per-sample mode)
+    unsigned n_owned;
+    const unsigned long long* block_seeds;   // one per block of the whole image
+    unsigned long long* item_seed;      // per pixel item (per-sample mode)
+    unsigned* item_pixel;               // per pixel item: y * W + x
+    float* out;                         // W*H*3 framebuffer
+    Counters* counters;
+    unsigned long long* partials;       // [max grid blocks][STAT_COUNT] statistics rows
+};
+
+// Path-state accessors.  The stage functions below are written once against `ps.f/u/q(field)`:
+//  * PoolState: the wavefront kernels — state lives in the HBM pool, one coalesced word per lane;
+//  * RegState:  the persistent fused kernel — the same fields are plain locals (every index is a compile-time
+//    constant, so the arrays are scalarised into VGPRs and untouched fields disappear).
+struct PoolState {
+    Pool pool; unsigned slot;
+    RL_DEV float& f(int field) const { return pool.f[(size_t)field * pool.P + slot]; }
+    RL_DEV unsigned& u(int field) const { return pool.u[(size_t)field * pool.P + slot]; }
+    RL_DEV unsigned long long& q(int field) const { return pool.q[(size_t)field * pool.P + slot]; }
+};
+struct RegState {
+    float fv[F_COUNT]; unsigned uv[U_COUNT]; unsigned long long qv[Q_COUNT];
+    RL_DEV float& f(int field) { return fv[field]; }
+    RL_DEV unsigned& u(int field) { return uv[field]; }
+    RL_DEV unsigned long long& q(int field) { return qv[field]; }
+};
+// FusedState: RegState whose "cold" fields (touched once per camera sample, by raygen only) are parked in LDS
+// ([field][thread] layout, conflict-free) instead of occupying VGPRs through the traversal and shading code.
+struct FusedState {
+    float fv[F_COUNT]; unsigned uv[U_COUNT]; unsigned long long qv[Q_COUNT];
+    float* cold_f; unsigned* cold_u; unsigned long long* cold_q;     // already offset by threadIdx.x
+    static constexpr int kColdF = 3, kColdU = 3, kColdQ = 4;
+    RL_DEV float& f(int field) { return (field >= F_AR && field <= F_AB) ? cold_f[(field - F_AR) * 256] : fv[field]; }
+    RL_DEV unsigned& u(int field) { return (field >= U_ITEM && field <= U_SAMPLE) ? cold_u[(field - U_ITEM) * 256] : uv[field]; }
+    RL_DEV unsigned long long& q(int field) { return (field >= Q_I0) ? cold_q[(field - Q_I0) * 256] : qv[field]; }
+};
+static constexpr size_t kFusedColdBytes = 256 * (FusedState::kColdQ * 8 + FusedState::kColdF * 4 + FusedState::kColdU * 4);
+#define PF(field) ps.f(field)
+#define PU(field) ps.u(field)
+#define PQ(field) ps.q(field)
+
+template <class PS> RL_DEV V3 load3(PS& ps, int f0) { return mk3(PF(f0), PF(f0 + 1), PF(f0 + 2)); }
+template <class PS> RL_DEV Col loadc(PS& ps, int f0) { return mkc(PF(f0), PF(f0 + 1), PF(f0 + 2)); }
+template <class PS> RL_DEV void store3(PS& ps, int f0, V3 v) { PF(f0) = v.x; PF(f0 + 1) = v.y; PF(f0 + 2) = v.z; }
+template <class PS> RL_DEV void storec(PS& ps, int f0, Col c) { PF(f0) = c.r; PF(f0 + 1) = c.g; PF(f0 + 2) = c.b; }
+template <class PS> RL_DEV Rng load_rng(PS& ps, int q0) { Rng r; r.s0 = PQ(q0); r.s1 = PQ(q0 + 1); r.s2 = PQ(q0 + 2); r.s3 = PQ(q0 + 3); return r; }
+template <class PS> RL_DEV void store_rng(PS& ps, int q0, const Rng& r) { PQ(q0) = r.s0; PQ(q0 + 1) = r.s1; PQ(q0 + 2) = r.s2; PQ(q0 + 3) = r.s3; }
+
+// Statistics without atomics on shared words (a device-scope atomic on one word costs ~10 ns and
+// serialises: MI355X_MICROARCH "fanin"): wave64 shuffle sum -> LDS per block -> one plain
+// read-modify-write of this block's own row of `partials` (rows are private to a block index;
+// launches on one stream are ordered).  The host sums the rows after the render.
+enum { STAT_SAMPLES, STAT_VERTICES, STAT_EXT_RAYS, STAT_SHADOW_RAYS, STAT_DRAWS, STAT_COUNT = 8 };
+RL_DEV unsigned wave_sum(unsigned v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+template <int N>
+RL_DEV void block_stats(unsigned long long* partials, const int (&which)[N], const unsigned (&vals)[N]) {
+    __shared__ unsigned s_acc[N];
+    if (threadIdx.x < N) s_acc[threadIdx.x] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        unsigned v = wave_sum(vals[k]);
+        if ((threadIdx.x & 63u) == 0u && v) atomicAdd(&s_acc[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < N && s_acc[threadIdx.x]) partials[(size_t)blockIdx.x * STAT_COUNT + which[threadIdx.x]] += s_acc[threadIdx.x];
+}
+
+// Block-local stream compaction with wave64 ballot + prefix popcount (no global atomics): the threads of a
+// workgroup whose slot satisfies `pred` are packed to the front, so the traversal / shading loops run on
+// full waves and the remaining waves exit at once.  `list` = 256 + 4 words of LDS.  Returns the number of
+// packed entries; thread `t < n` then works on slot `list[t]`.
+RL_DEV unsigned block_compact(bool pred, unsigned slot, unsigned* list) {
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long mask = __ballot(pred);
+    const unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
+    unsigned* wave_cnt = list + 256;
+    if (lane == 0u) wave_cnt[wave] = (unsigned)__popcll(mask);
+    __syncthreads();
+    unsigned base = 0, total = 0;
+#pragma unroll
+    for (unsigned w = 0; w < 4u; w++) { unsigned c = wave_cnt[w]; if (w < wave) base += c; total += c; }
+    if (pred) list[base + rank] = slot;
+    __syncthreads();
+    return total;
+}
+
+RL_DEV void block_geometry(const RenderConst& rc, unsigned b, unsigned* bx, unsigned* by, unsigned* bw, unsigned* bh) {
+    *bx = (b / rc.nby) * 16u;            // block index b = (ix/16) * ceil(H/16) + iy/16 (mod.rs:357-358)
+    *by = (b % rc.nby) * 16u;
+    *bw = min(16u, rc.W - *bx);
+    *bh = min(16u, rc.H - *by);
+}
+
+}  // namespace rl

@@ -1,0 +1,358 @@
+// stages.hip.h — the four per-vertex stage functions shared by the wavefront kernels and the persistent fused kernel:
+// raygen_slot, extend_slot, shade_slot<MAT, MEDIUM>, shadow_slot (reference: integrators/mod.rs:403-450, paths/strategies/*.rs,
+// integrators/explicit/path.rs:37-184).
+// Part of the single translation unit wavefront.hip (included once, after devmath / shading / trace).
+#pragma once
+
+namespace rl {
+
+// ------------------------------------------------------------------------------------------
+// Camera::generate (src/camera.rs:81-91): direction of the ray through image position (u, v)
+RL_DEV V3 camera_direction(const DeviceScene& sc, float u, float v) {
+    const float* m = sc.camera.sample_to_camera;
+    float sx = div_rn(u, (float)sc.camera.width), sy = div_rn(v, (float)sc.camera.height), sz = 0.0f;
+    float hx = ((m[0] * sx + m[4] * sy) + m[8] * sz) + m[12] * 1.0f;
+    float hy = ((m[1] * sx + m[5] * sy) + m[9] * sz) + m[13] * 1.0f;
+    float hz = ((m[2] * sx + m[6] * sy) + m[10] * sz) + m[14] * 1.0f;
+    float hw = ((m[3] * sx + m[7] * sy) + m[11] * sz) + m[15] * 1.0f;
+    float inv_w = div_rn(1.0f, hw);
+    V3 near_p = mk3(hx * inv_w, hy * inv_w, hz * inv_w);
+    V3 dl = normalize(near_p);
+    const float* tw = sc.camera.to_world;
+    return mk3(((tw[0] * dl.x + tw[4] * dl.y) + tw[8] * dl.z) + tw[12] * 0.0f,
+               ((tw[1] * dl.x + tw[5] * dl.y) + tw[9] * dl.z) + tw[13] * 0.0f,
+               ((tw[2] * dl.x + tw[6] * dl.y) + tw[10] * dl.z) + tw[14] * 0.0f);
+}
+
+// raygen_slot — sample completion, work-item hand-out, sampler forking, Path::from_sensor (2 draws) and
+// Camera::generate for one slot that asked for regeneration.  DYNAMIC: work items come from the global
+// dispenser (wavefront pool); otherwise the slot owns exactly one item (persistent fused kernel).
+template <bool DYNAMIC, class PS>
+RL_DEV void raygen_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, unsigned& n_samples, unsigned& n_draws) {
+    unsigned flags = PU(U_FLAGS);
+    if (!(flags & ST_REGEN)) return;
+    const bool fresh = (flags & ST_FRESH) != 0u;
+    unsigned item = PU(U_ITEM), s = PU(U_SAMPLE), cursor = PU(U_CURSOR);
+    Col acc = loadc(ps, F_AR);
+    bool need_item = fresh;
+    unsigned bx = 0, by = 0, bw = 1, bh = 1;
+    if (rc.stream_mode == RL_STREAM_REFERENCE_ORDER && item < rc.n_items) block_geometry(rc, rc.owned_blocks[item], &bx, &by, &bw, &bh);
+    const unsigned split = rc.stream_mode == RL_STREAM_PER_SAMPLE ? rc.split : 1u;
+    const unsigned pitem = split > 1u ? item / split : item;         // pixel item of this lane
+    if (!fresh && split > 1u) {
+        // sample-parallel pixels: this lane owns samples s, s + split, ...; each sample's radiance is parked in
+        // sample_buf[s][pixel item] and k_fold_samples adds them up in sample order, as mod.rs:431 does
+        const Col L = loadc(ps, F_LR);
+        float* dst = rc.sample_buf + 3 * ((size_t)s * (rc.n_items / split) + pitem);
+        dst[0] = L.r; dst[1] = L.g; dst[2] = L.b;
+        s += split;
+        if (s >= rc.spp) need_item = true;
+    } else if (!fresh) {
+        // im_block.accumulate(.., c, "primal") in sample order (mod.rs:431)
+        acc = acc + loadc(ps, F_LR);
+        s++;
+        if (s == rc.spp) {
+            unsigned pix = rc.stream_mode == RL_STREAM_PER_SAMPLE ? rc.item_pixel[item] : (by + cursor / bw) * rc.W + (bx + cursor % bw);
+            Col px = scale_unguarded(acc, rc.inv_spp);            // im_block.scale(1 / spp) (mod.rs:436)
+            rc.out[3 * (size_t)pix] = px.r; rc.out[3 * (size_t)pix + 1] = px.g; rc.out[3 * (size_t)pix + 2] = px.b;
+            acc = czero();
+            s = 0;
+            if (rc.stream_mode == RL_STREAM_PER_SAMPLE) need_item = true;
+            else { cursor++; if (cursor == bw * bh) need_item = true; }
+        }
+    }
+    Rng rng;
+    if (need_item) {
+        if (!fresh) item = DYNAMIC ? atomicAdd(&rc.counters->next_item, 1u) : rc.n_items;   // fused kernel: one item per thread
+        if (item >= rc.n_items) {
+            PU(U_FLAGS) = ST_FINISHED;
+            if (DYNAMIC) atomicSub(&rc.counters->active, 1u);
+            return;
+        }
+        cursor = 0;
+        if (rc.stream_mode == RL_STREAM_PER_SAMPLE) {
+            const unsigned pi = split > 1u ? item / split : item;
+            Rng item_rng = rng_seed(rc.item_seed[pi], rc.seed_variant);     // pixel sampler = block_sampler.clone_box()
+            if (split > 1u) { s = item % split; for (unsigned k = 0; k < s; k++) rng_next_u64(item_rng); }   // forks of the samples before ours
+            rng = rng_seed(rng_next_u64(item_rng), rc.seed_variant);        // sample sampler = pixel_sampler.clone_box()
+            store_rng(ps, Q_I0, item_rng);
+        } else {
+            unsigned b = rc.owned_blocks[item];
+            block_geometry(rc, b, &bx, &by, &bw, &bh);
+            rng = rng_seed(rc.block_seeds[b], rc.seed_variant);            // the block's own sampler (mod.rs:371)
+        }
+        PU(U_ITEM) = item;
+    } else if (rc.stream_mode == RL_STREAM_PER_SAMPLE) {
+        Rng item_rng = load_rng(ps, Q_I0);
+        for (unsigned k = 1; k < split; k++) rng_next_u64(item_rng);        // the forks taken by the other lanes of this pixel
+        rng = rng_seed(rng_next_u64(item_rng), rc.seed_variant);
+        store_rng(ps, Q_I0, item_rng);
+    } else {
+        rng = load_rng(ps, Q_R0);
+    }
+    unsigned px, py;
+    if (rc.stream_mode == RL_STREAM_PER_SAMPLE) { unsigned pix = rc.item_pixel[split > 1u ? item / split : item]; px = pix % rc.W; py = pix / rc.W; }
+    else { px = bx + cursor % bw; py = by + cursor / bw; }
+    // Path::from_sensor: uv = (ix + next(), iy + next())
+    float u = (float)px + rng_next_f32(rng);
+    float v = (float)py + rng_next_f32(rng);
+    n_draws += 2;
+    n_samples++;
+    storec(ps, F_AR, acc);
+    PU(U_SAMPLE) = s;
+    PU(U_CURSOR) = cursor;
+    const bool expand = (!rc.has_max || 1u < rc.max_depth);   // TechniquePathTracing::expand at depth 1
+    if (!expand) {   // sensor not expanded: the sample is 0 (next raygen pass folds it)
+        storec(ps, F_LR, czero());
+        store_rng(ps, Q_R0, rng);
+        PU(U_FLAGS) = ST_REGEN;
+        return;
+    }
+    const V3 d = camera_direction(sc, u, v);   // Camera::generate (camera.rs:81-91)
+    // the sensor edge's state is implied by PREV_SENSOR and never stored: origin = Camera::position(),
+    // weight 1, rr_weight 1, PDF::SolidAngle(1), beta = thr = 1 (strategies/directional.rs:27-41)
+    store3(ps, F_DX, d);
+    if (sc.medium.enabled) { PF(F_XI) = rng_next_f32(rng); n_draws++; }   // Edge::from_ray's medium.sample(ray, next())
+    store_rng(ps, Q_R0, rng);
+    PU(U_DEPTH) = 1u;
+    PU(U_FLAGS) = ST_RAY | (PREV_SENSOR << ST_PREV_SHIFT) | ST_PDF_SA;
+}
+
+// ------------------------------------------------------------------------------------------
+// extend_slot / shadow_slot — Acceleration::trace and Acceleration::visible for one slot.
+template <class PS, class Stack>
+RL_DEV void extend_slot(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, PS& ps, int* dbg = nullptr) {
+    const unsigned flags = PU(U_FLAGS);
+    const bool primary = ((flags >> ST_PREV_SHIFT) & 3u) == PREV_SENSOR;    // camera rays start at Camera::position()
+    V3 o = primary ? mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]) : load3(ps, F_OX);
+    V3 d = load3(ps, F_DX);
+    Hit hit; hit.t = kF32Max; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
+    traverse<false>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
+                    o, d, kEps, kF32Max, hit, stack);
+    PF(F_T) = hit.t; PF(F_U) = hit.u; PF(F_V) = hit.v;
+    PU(U_PRIM) = (unsigned)hit.prim;
+    if (dbg) { dbg[0] = hit.steps; dbg[1] = hit.tris; }
+}
+template <class PS, class Stack>
+RL_DEV void shadow_slot(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, PS& ps) {
+    // Acceleration::visible(p0, p1) (accel.rs:316-343)
+    V3 p0 = load3(ps, F_OX), p1 = load3(ps, F_SX);
+    V3 d = p1 - p0;
+    float len = length(d);
+    d = d / len;
+    float tfar = len * (1.0f - 0.00001f);
+    Hit hit; hit.t = tfar; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
+    V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
+    float te;
+    bool vis;
+    if (!slab(mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]), p0, inv_d, kEps, tfar, &te))
+        vis = false;   // root box missed => "occluded" (accel.rs:338-340)
+    else
+        vis = !traverse<true>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
+                              p0, d, kEps, tfar, hit, stack);
+    if (vis) storec(ps, F_LR, loadc(ps, F_LR) + loadc(ps, F_CR));
+}
+
+// shade_slot<MAT, MEDIUM> — one path vertex of one slot.  MAT >= 0: the hit material is known to have that
+// BSDF type (per-BSDF code path, uniform over the calling lanes); MAT = -1: generic (run-time switch).
+template <int MAT, bool MEDIUM, class PS>
+RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, unsigned flags,
+                       unsigned& n_vertices, unsigned& n_draws, unsigned& n_shadow, unsigned& n_ext) {
+    n_ext += 1;      // every shaded slot carried exactly one extension ray through k_extend
+    const unsigned prev = (flags >> ST_PREV_SHIFT) & 3u;
+    const unsigned depth = PU(U_DEPTH);          // generate()'s depth at which the edge's origin vertex was expanded
+    const int prim = (int)PU(U_PRIM);
+    const bool primary = prev == PREV_SENSOR;     // sensor edge: implied state, see k_raygen
+    const V3 ro = primary ? mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]) : load3(ps, F_OX);
+    const V3 rd = load3(ps, F_DX);
+    const float t_hit = PF(F_T);
+    Col w_edge = primary ? cone() : loadc(ps, F_WR);
+    const float rr = primary ? 1.0f : PF(F_RR);
+    const float pdf_edge = primary ? 1.0f : PF(F_PDF);
+    Col beta = primary ? cone() : loadc(ps, F_BR);
+    Col L = primary ? czero() : loadc(ps, F_LR);
+    bool zeroed = (flags & ST_ZEROED) != 0u;
+    const bool hit = prim >= 0;
+    bool is_volume = false;
+    V3 vpos = mk3(0.0f, 0.0f, 0.0f);
+    if (MEDIUM) {
+        // Edge::from_ray (paths/edge.rs:93-162): distance sampling up to the surface (or infinity on a miss)
+        MediumSample ms = medium_sample(sc.medium, hit ? t_hit : kF32Max, PF(F_XI));
+        w_edge = w_edge * ms.w;
+        is_volume = !hit || !ms.exited;
+        if (is_volume) vpos = ro + rd * ms.t;
+    }
+    bool ended = false;
+    unsigned new_flags = ST_REGEN;
+    if (!MEDIUM && !hit) {
+        // edge without a next vertex: Edge::contribution = weight * rr * scene.enviroment_luminance(d) (edge.rs:201-210)
+        ended = true;
+        if (sc.env_emitter >= 0) {
+            Col contrib = (w_edge * rr) * env_eval(sc, rd);
+            const bool add_contrib = rc.has_min ? (depth - 1u) >= rc.min_depth : true;
+            if (prev == PREV_SENSOR) {
+                if (!is_zero(contrib) && add_contrib) L = L + contrib;
+            } else if (!zeroed) {
+                if (rc.strategy == RL_STRATEGY_EMITTER) contrib = czero();
+                if (!is_zero(contrib) && add_contrib) {
+                    float wmis = 1.0f;
+                    if (rc.strategy == RL_STRATEGY_ALL && (flags & ST_PDF_SA)) {
+                        // pdf_emitter, `None` next vertex: direct_pdf of the environment (emitters.rs:18-46)
+                        float p2 = (prev == PREV_SURFACE || prev == PREV_VOLUME) ? env_direct_pdf(sc, rd) : 0.0f;
+                        float total = (0.0f + pdf_edge) + p2;
+                        wmis = div_rn(pdf_edge, total);
+                    }
+                    L = L + beta * (contrib * wmis);
+                }
+            }
+            storec(ps, F_LR, L);
+        }
+    }
+    if (!ended) {
+        const Col W = w_edge * rr;                // edge.weight * edge.rr_weight (Color * f32, guarded)
+        SurfacePoint sp;
+        const Material* mat = nullptr;
+        MeshRecord mr;
+        if (!is_volume) {
+            sp = fill_intersection(sc, prim, PF(F_U), PF(F_V), ro, rd, t_hit);
+            mr = sc.meshes[sp.mesh];
+            mat = &sc.materials[mr.material];
+        }
+        // ---- contribution carried by the arriving edge (Edge::contribution -> Vertex::contribution)
+        Col emit = czero();
+        if (!is_volume && (mr.flags & MESH_IS_LIGHT) && dot(sp.n_s, -rd) >= 0.0f) emit = mkc(mr.emission[0], mr.emission[1], mr.emission[2]);
+        Col contrib = W * emit;
+        const unsigned cur = depth - 1u;          // evaluate()'s curr_depth of the origin vertex
+        const bool add_contrib = rc.has_min ? cur >= rc.min_depth : true;
+        if (prev == PREV_SENSOR) {
+            if (!is_zero(contrib) && add_contrib) L = L + contrib;              // path.rs:152-166 (no MIS)
+        } else if (!zeroed) {
+            if (rc.strategy == RL_STRATEGY_EMITTER) contrib = czero();          // id_sampling 0 != 1
+            if (!is_zero(contrib) && add_contrib) {
+                float wmis = 1.0f;
+                if (rc.strategy == RL_STRATEGY_ALL && (flags & ST_PDF_SA)) {
+                    // LightSamplingStrategy::pdf -> pdf_emitter (strategies/emitters.rs:10-92,250-282)
+                    float p2 = 0.0f;
+                    if (!is_volume && (mr.flags & MESH_IS_LIGHT) && (prev == PREV_SURFACE || prev == PREV_VOLUME))
+                        p2 = light_direct_pdf(sc, mr, sc.tris[prim].tri, ro, sp.p, sp.n_g, rd, false, mk3(0.0f, 0.0f, 0.0f));   // n = None (emitters.rs:52-57)
+                    float total = (0.0f + pdf_edge) + p2;
+                    wmis = div_rn(pdf_edge, total);                             // balance heuristic (path.rs:80-98)
+                }
+                L = L + beta * (contrib * wmis);
+            }
+        }
+        beta = beta * W;
+        if (rc.single_scattering && !is_volume) zeroed = true;                  // evaluate(): surface vertex => subtree is 0
+
+        // ---- expand the new vertex (generate(), strategies/mod.rs:35-80)
+        const unsigned gen = depth + 1u;
+        const bool expand = (rc.has_max ? gen < rc.max_depth : true) && gen < kDepthCap;
+        if (expand) {
+            n_vertices += 1;
+            Rng rng = load_rng(ps, Q_R0);
+            Col thr = primary ? cone() : loadc(ps, F_TR);
+            const V3 vp = is_volume ? vpos : sp.p;
+            const V3 d_in = -rd;
+            // strategy 0: DirectionalSamplingStrategy::bounce (strategies/directional.rs:44-153)
+            V2 s2; s2.x = rng_next_f32(rng); s2.y = rng_next_f32(rng);
+            n_draws += 2;
+            bool has_edge = false;
+            bool sampled = false;
+            Col sw = czero(); V3 sd_world = mk3(0.0f, 0.0f, 0.0f); float spdf = 0.0f; int spdf_kind = PDF_SOLID_ANGLE;
+            if (is_volume) {
+                phase_sample(sc.medium, d_in, s2, &sd_world, &sw, &spdf);
+                sampled = true;
+            } else {
+                BsdfSample bs;
+                if (bsdf_sample<MAT>(sc, *mat, sp.has_uv, sp.uv, sp.wi, s2, &bs)) {
+                    sampled = true;
+                    sw = bs.weight; spdf = bs.pdf; spdf_kind = bs.pdf_kind;
+                    sd_world = to_world(sp.frame, bs.d);
+                }
+            }
+            float rr_new = 1.0f;
+            if (sampled) {
+                thr = thr * sw;
+                if (!is_zero(thr)) {
+                    const bool do_rr = rc.has_rr ? rc.rr_depth <= gen : true;
+                    bool alive = true;
+                    if (do_rr) {
+                        float q = rmin(channel_max(thr), 0.95f);
+                        float x = rng_next_f32(rng);
+                        n_draws++;
+                        if (q < x) alive = false; else rr_new = div_rn(1.0f, q);
+                    }
+                    if (alive) {
+                        thr = scale_unguarded(thr, rr_new);
+                        has_edge = true;
+                        if (MEDIUM) { PF(F_XI) = rng_next_f32(rng); n_draws++; }   // the new edge's medium.sample draw
+                    }
+                }
+            }
+            // strategy 1: LightSamplingStrategy::sample (strategies/emitters.rs:95-248)
+            const bool use_light = rc.strategy != RL_STRATEGY_BSDF;
+            const bool smooth = !is_volume && mat->smooth;
+            bool shadow = false;
+            if (use_light && !smooth) {
+                float a = rng_next_f32(rng);
+                float b = rng_next_f32(rng);
+                V2 c; c.x = rng_next_f32(rng); c.y = rng_next_f32(rng);
+                n_draws += 4;
+                n_shadow += 1;     // the reference always traces the shadow ray (emitters.rs:125-126)
+                LightSample ls = sample_light(sc, vp, !is_volume, is_volume ? mk3(0.0f, 0.0f, 0.0f) : sp.n_s, a, b, c);   // Some(&its.n_s) | None
+                if (ls.pdf != 0.0f) {
+                    Col wl;
+                    float p_dir;
+                    if (is_volume) { wl = phase_eval(sc.medium, d_in, ls.d); p_dir = phase_pdf(sc.medium, d_in, ls.d); }   // (no environment with a medium)
+                    else {
+                        V3 wo = to_local(sp.frame, ls.d);
+                        wl = bsdf_eval<MAT>(sc, *mat, sp.has_uv, sp.uv, sp.wi, wo, false);
+                        // the MIS pdf is asked along Edge::from_vertex's own direction (p_light - p) / |..| (edge.rs:37-39):
+                        // bitwise equal to ls.d for mesh lights, recomputed for the environment
+                        V3 wo_edge = wo;
+                        if (ls.kind == EMITTER_ENV) { V3 ed = ls.p - vp; ed = ed / length(ed); wo_edge = to_local(sp.frame, ed); }
+                        p_dir = bsdf_pdf<MAT>(sc, *mat, sp.has_uv, sp.uv, sp.wi, wo_edge, false);
+                    }
+                    if (MEDIUM) {
+                        V3 dd = ls.p - vp;
+                        wl = wl * medium_transmittance(sc.medium, dot(dd, ls.d));
+                    }
+                    Col c_l = ls.weight * wl * 1.0f;                       // contrib * weight * rr_weight (edge.rs:204)
+                    const bool add_l = rc.has_min ? (gen - 1u) >= rc.min_depth : true;
+                    if (!zeroed && !is_zero(c_l) && add_l) {
+                        float wmis = 1.0f;
+                        if (rc.strategy == RL_STRATEGY_ALL && ls.pdf_kind == PDF_SOLID_ANGLE) {   // Discrete (point / directional): no MIS
+                            float total = (0.0f + p_dir) + ls.pdf;
+                            wmis = div_rn(ls.pdf, total);
+                        }
+                        Col pending = beta * (c_l * wmis);
+                        // a zero contribution needs no visibility test: the image cannot change
+                        if (!is_zero(pending)) {
+                            shadow = true;
+                            store3(ps, F_SX, ls.p);
+                            storec(ps, F_CR, pending);
+                        }
+                    }
+                }
+            }
+            store_rng(ps, Q_R0, rng);
+            store3(ps, F_OX, vp);
+            new_flags = shadow ? ST_SHADOW : 0u;
+            if (has_edge) {
+                store3(ps, F_DX, sd_world);
+                storec(ps, F_TR, thr);
+                storec(ps, F_WR, sw);
+                PF(F_RR) = rr_new;
+                PF(F_PDF) = spdf;
+                PU(U_DEPTH) = gen;
+                const unsigned kind = is_volume ? PREV_VOLUME : (smooth ? PREV_SURFACE_SMOOTH : PREV_SURFACE);
+                new_flags |= ST_RAY | (kind << ST_PREV_SHIFT) | (spdf_kind == PDF_SOLID_ANGLE ? ST_PDF_SA : 0u) | (zeroed ? ST_ZEROED : 0u);
+            } else new_flags |= ST_REGEN;
+        }
+        storec(ps, F_BR, beta);
+        storec(ps, F_LR, L);
+    } else if (primary && sc.env_emitter < 0) storec(ps, F_LR, L);   // camera ray left the scene: the sample is 0
+    PU(U_FLAGS) = new_flags;
+}
+
+}  // namespace rl

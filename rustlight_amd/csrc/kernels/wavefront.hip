@@ -19,6 +19,13 @@
 //              adds the pre-weighted contribution to the path's radiance
 // (k_shade_sorted when the scene mixes BSDF types: block-local stream compaction + material sort with
 // wave64 ballot + prefix popcounts, then one packed pass per BSDF).  Radiance is accumulated front-to-back (DESIGN.md §Radiance order).
+// k_path_fused runs the same four stages back to back in one persistent launch with the state in registers / LDS;
+// k_pixel_mc is the `ao` / `direct` form.  This file holds the kernels and the host driver behind the C-ABI
+// (rl_context_*, rl_render_path / _ao / _direct, rl_trace_batch, rl_visible_batch); the device code it instantiates is in
+//   pathstate.hip.h  pool layout, state accessors, block-local statistics / compaction
+//   stages.hip.h     raygen_slot, extend_slot, shade_slot, shadow_slot
+//   mc.hip.h         ao / direct pixel estimators
+//   trace.hip.h      BVH2 traversal;   shading.hip.h  BSDFs, emitters, light tree, medium;   devmath.hip.h  f32 contract, RNG
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -34,184 +41,11 @@
 #include "shading.hip.h"
 #include "trace.hip.h"
 #include "wavefront.h"
+#include "pathstate.hip.h"
+#include "stages.hip.h"
+#include "mc.hip.h"
 
 namespace rl {
-
-// ------------------------------------------------------------------------------------------
-// path-state pool (SoA): field f of slot i is at base[f * P + i]
-enum FField {
-    F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ,         // extension ray (origin doubles as the NEE origin)
-    F_T, F_U, F_V,                               // hit record (with U_PRIM)
-    F_BR, F_BG, F_BB,                            // beta: throughput of evaluate()'s edge products
-    F_TR, F_TG, F_TB,                            // thr: generate()'s Russian-roulette throughput
-    F_LR, F_LG, F_LB,                            // radiance of the current sample
-    F_AR, F_AG, F_AB,                            // pixel accumulator (sum over samples, in sample order)
-    F_WR, F_WG, F_WB,                            // weight of the edge being traced (BSDF / phase weight)
-    F_RR, F_PDF,                                 // its rr_weight and directional pdf
-    F_SX, F_SY, F_SZ,                            // NEE target point on the light
-    F_CR, F_CG, F_CB,                            // NEE contribution, already times beta and MIS weight
-    F_XI,                                        // medium distance-sampling random number of the edge
-    F_COUNT
-};
-enum UField { U_FLAGS, U_DEPTH, U_PRIM, U_ITEM, U_CURSOR, U_SAMPLE, U_COUNT };
-enum QField { Q_R0, Q_R1, Q_R2, Q_R3, Q_I0, Q_I1, Q_I2, Q_I3, Q_COUNT };
-
-enum : unsigned {
-    ST_FINISHED = 1u,      // slot has no work left
-    ST_REGEN = 2u,         // sample ended: raygen must fold it and start the next one
-    ST_FRESH = 4u,         // no sample has run in this slot yet
-    ST_RAY = 8u,           // extension ray valid
-    ST_SHADOW = 16u,       // NEE shadow ray valid
-    ST_PREV_SHIFT = 5u,    // 2 bits: kind of the vertex the traced edge leaves
-    ST_PDF_SA = 128u,      // edge pdf is PDF::SolidAngle (else Discrete)
-    ST_ZEROED = 256u,      // single_scattering: a surface vertex has been passed (path.rs:122-124)
-};
-enum : unsigned { PREV_SENSOR = 0u, PREV_SURFACE = 1u, PREV_SURFACE_SMOOTH = 2u, PREV_VOLUME = 3u };
-
-#ifndef RL_FUSED_WAVES
-#define RL_FUSED_WAVES 4   // min waves per SIMD requested for the persistent fused kernel (<= 168 VGPRs)
-#endif
-static constexpr unsigned kDepthCap = 2048u;   // same cut as the oracle (NaN-throughput paths never die)
-
-struct Pool {
-    float* f;
-    unsigned* u;
-    unsigned long long* q;
-    unsigned P;
-};
-
-struct Counters {
-    unsigned int active;        // slots that still own work
-    unsigned int next_item;     // work-item dispenser
-    unsigned int pad[2];
-};
-
-static constexpr int kLdsStackLevels = 12;   // stack levels kept in LDS per lane
-static constexpr size_t kSampleBufBudget = (size_t)16 << 30;   // bytes of HBM the per-sample parking buffer may take
-// traversal stack configuration (see TravStack)
-struct StackConf { int lds_levels; int* overflow; size_t overflow_stride; };
-
-template <bool LDS_ONLY = false>
-RL_DEV TravStackT<LDS_ONLY> make_stack(const StackConf& sc_, unsigned* lds_after_list, size_t global_thread) {
-    TravStackT<LDS_ONLY> st;
-    st.lds = reinterpret_cast<int2*>(lds_after_list) + threadIdx.x;
-    st.lds_stride = (int)blockDim.x;
-    st.lds_levels = sc_.lds_levels;
-    st.glob = sc_.overflow ? sc_.overflow + global_thread : nullptr;
-    st.glob_stride = sc_.overflow_stride;
-    return st;
-}
-
-struct RenderConst {
-    // IntegratorPathTracing fields (explicit/path.rs:14-20)
-    unsigned spp;
-    int has_min, has_max, has_rr;
-    unsigned min_depth, max_depth, rr_depth;
-    int strategy, single_scattering;
-    int stream_mode, seed_variant;
-    float inv_spp;
-    // image / work decomposition
-    unsigned W, H, nby;
-    unsigned n_items;
-    unsigned split;                     // per-sample mode: lanes per pixel (sample s of a pixel runs on lane s % split)
-    float* sample_buf;                  // split > 1: [spp][n_items / split][3] per-sample radiance, folded in order by k_fold_samples
-    const unsigned* owned_blocks;       // block ids of this shard, in creation order
-    const unsigned* block_item_base;    // per owned block: first pixel item (per-sample mode)
-    unsigned n_owned;
-    const unsigned long long* block_seeds;   // one per block of the whole image
-    unsigned long long* item_seed;      // per pixel item (per-sample mode)
-    unsigned* item_pixel;               // per pixel item: y * W + x
-    float* out;                         // W*H*3 framebuffer
-    Counters* counters;
-    unsigned long long* partials;       // [max grid blocks][STAT_COUNT] statistics rows
-};
-
-// Path-state accessors.  The stage functions below are written once against `ps.f/u/q(field)`:
-//  * PoolState: the wavefront kernels — state lives in the HBM pool, one coalesced word per lane;
-//  * RegState:  the persistent fused kernel — the same fields are plain locals (every index is a compile-time
-//    constant, so the arrays are scalarised into VGPRs and untouched fields disappear).
-struct PoolState {
-    Pool pool; unsigned slot;
-    RL_DEV float& f(int field) const { return pool.f[(size_t)field * pool.P + slot]; }
-    RL_DEV unsigned& u(int field) const { return pool.u[(size_t)field * pool.P + slot]; }
-    RL_DEV unsigned long long& q(int field) const { return pool.q[(size_t)field * pool.P + slot]; }
-};
-struct RegState {
-    float fv[F_COUNT]; unsigned uv[U_COUNT]; unsigned long long qv[Q_COUNT];
-    RL_DEV float& f(int field) { return fv[field]; }
-    RL_DEV unsigned& u(int field) { return uv[field]; }
-    RL_DEV unsigned long long& q(int field) { return qv[field]; }
-};
-// FusedState: RegState whose "cold" fields (touched once per camera sample, by raygen only) are parked in LDS
-// ([field][thread] layout, conflict-free) instead of occupying VGPRs through the traversal and shading code.
-struct FusedState {
-    float fv[F_COUNT]; unsigned uv[U_COUNT]; unsigned long long qv[Q_COUNT];
-    float* cold_f; unsigned* cold_u; unsigned long long* cold_q;     // already offset by threadIdx.x
-    static constexpr int kColdF = 3, kColdU = 3, kColdQ = 4;
-    RL_DEV float& f(int field) { return (field >= F_AR && field <= F_AB) ? cold_f[(field - F_AR) * 256] : fv[field]; }
-    RL_DEV unsigned& u(int field) { return (field >= U_ITEM && field <= U_SAMPLE) ? cold_u[(field - U_ITEM) * 256] : uv[field]; }
-    RL_DEV unsigned long long& q(int field) { return (field >= Q_I0) ? cold_q[(field - Q_I0) * 256] : qv[field]; }
-};
-static constexpr size_t kFusedColdBytes = 256 * (FusedState::kColdQ * 8 + FusedState::kColdF * 4 + FusedState::kColdU * 4);
-#define PF(field) ps.f(field)
-#define PU(field) ps.u(field)
-#define PQ(field) ps.q(field)
-
-template <class PS> RL_DEV V3 load3(PS& ps, int f0) { return mk3(PF(f0), PF(f0 + 1), PF(f0 + 2)); }
-template <class PS> RL_DEV Col loadc(PS& ps, int f0) { return mkc(PF(f0), PF(f0 + 1), PF(f0 + 2)); }
-template <class PS> RL_DEV void store3(PS& ps, int f0, V3 v) { PF(f0) = v.x; PF(f0 + 1) = v.y; PF(f0 + 2) = v.z; }
-template <class PS> RL_DEV void storec(PS& ps, int f0, Col c) { PF(f0) = c.r; PF(f0 + 1) = c.g; PF(f0 + 2) = c.b; }
-template <class PS> RL_DEV Rng load_rng(PS& ps, int q0) { Rng r; r.s0 = PQ(q0); r.s1 = PQ(q0 + 1); r.s2 = PQ(q0 + 2); r.s3 = PQ(q0 + 3); return r; }
-template <class PS> RL_DEV void store_rng(PS& ps, int q0, const Rng& r) { PQ(q0) = r.s0; PQ(q0 + 1) = r.s1; PQ(q0 + 2) = r.s2; PQ(q0 + 3) = r.s3; }
-
-// Statistics without atomics on shared words (a device-scope atomic on one word costs ~10 ns and
-// serialises: MI355X_MICROARCH "fanin"): wave64 shuffle sum -> LDS per block -> one plain
-// read-modify-write of this block's own row of `partials` (rows are private to a block index;
-// launches on one stream are ordered).  The host sums the rows after the render.
-enum { STAT_SAMPLES, STAT_VERTICES, STAT_EXT_RAYS, STAT_SHADOW_RAYS, STAT_DRAWS, STAT_COUNT = 8 };
-RL_DEV unsigned wave_sum(unsigned v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-template <int N>
-RL_DEV void block_stats(unsigned long long* partials, const int (&which)[N], const unsigned (&vals)[N]) {
-    __shared__ unsigned s_acc[N];
-    if (threadIdx.x < N) s_acc[threadIdx.x] = 0u;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-        unsigned v = wave_sum(vals[k]);
-        if ((threadIdx.x & 63u) == 0u && v) atomicAdd(&s_acc[k], v);
-    }
-    __syncthreads();
-    if (threadIdx.x < N && s_acc[threadIdx.x]) partials[(size_t)blockIdx.x * STAT_COUNT + which[threadIdx.x]] += s_acc[threadIdx.x];
-}
-
-// Block-local stream compaction with wave64 ballot + prefix popcount (no global atomics): the threads of a
-// workgroup whose slot satisfies `pred` are packed to the front, so the traversal / shading loops run on
-// full waves and the remaining waves exit at once.  `list` = 256 + 4 words of LDS.  Returns the number of
-// packed entries; thread `t < n` then works on slot `list[t]`.
-RL_DEV unsigned block_compact(bool pred, unsigned slot, unsigned* list) {
-    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned long long mask = __ballot(pred);
-    const unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
-    unsigned* wave_cnt = list + 256;
-    if (lane == 0u) wave_cnt[wave] = (unsigned)__popcll(mask);
-    __syncthreads();
-    unsigned base = 0, total = 0;
-#pragma unroll
-    for (unsigned w = 0; w < 4u; w++) { unsigned c = wave_cnt[w]; if (w < wave) base += c; total += c; }
-    if (pred) list[base + rank] = slot;
-    __syncthreads();
-    return total;
-}
-
-RL_DEV void block_geometry(const RenderConst& rc, unsigned b, unsigned* bx, unsigned* by, unsigned* bw, unsigned* bh) {
-    *bx = (b / rc.nby) * 16u;            // block index b = (ix/16) * ceil(H/16) + iy/16 (mod.rs:357-358)
-    *by = (b % rc.nby) * 16u;
-    *bw = min(16u, rc.W - *bx);
-    *bh = min(16u, rc.H - *by);
-}
 
 // ------------------------------------------------------------------------------------------
 // per-sample stream mode: fork the block sampler once per pixel in the block's (iy, ix) loop order
@@ -246,118 +80,6 @@ __global__ void k_init(RenderConst rc, Pool pool) {
     storec(ps, F_LR, czero());
 }
 
-// ------------------------------------------------------------------------------------------
-// Camera::generate (src/camera.rs:81-91): direction of the ray through image position (u, v)
-RL_DEV V3 camera_direction(const DeviceScene& sc, float u, float v) {
-    const float* m = sc.camera.sample_to_camera;
-    float sx = div_rn(u, (float)sc.camera.width), sy = div_rn(v, (float)sc.camera.height), sz = 0.0f;
-    float hx = ((m[0] * sx + m[4] * sy) + m[8] * sz) + m[12] * 1.0f;
-    float hy = ((m[1] * sx + m[5] * sy) + m[9] * sz) + m[13] * 1.0f;
-    float hz = ((m[2] * sx + m[6] * sy) + m[10] * sz) + m[14] * 1.0f;
-    float hw = ((m[3] * sx + m[7] * sy) + m[11] * sz) + m[15] * 1.0f;
-    float inv_w = div_rn(1.0f, hw);
-    V3 near_p = mk3(hx * inv_w, hy * inv_w, hz * inv_w);
-    V3 dl = normalize(near_p);
-    const float* tw = sc.camera.to_world;
-    return mk3(((tw[0] * dl.x + tw[4] * dl.y) + tw[8] * dl.z) + tw[12] * 0.0f,
-               ((tw[1] * dl.x + tw[5] * dl.y) + tw[9] * dl.z) + tw[13] * 0.0f,
-               ((tw[2] * dl.x + tw[6] * dl.y) + tw[10] * dl.z) + tw[14] * 0.0f);
-}
-
-// raygen_slot — sample completion, work-item hand-out, sampler forking, Path::from_sensor (2 draws) and
-// Camera::generate for one slot that asked for regeneration.  DYNAMIC: work items come from the global
-// dispenser (wavefront pool); otherwise the slot owns exactly one item (persistent fused kernel).
-template <bool DYNAMIC, class PS>
-RL_DEV void raygen_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, unsigned& n_samples, unsigned& n_draws) {
-    unsigned flags = PU(U_FLAGS);
-    if (!(flags & ST_REGEN)) return;
-    const bool fresh = (flags & ST_FRESH) != 0u;
-    unsigned item = PU(U_ITEM), s = PU(U_SAMPLE), cursor = PU(U_CURSOR);
-    Col acc = loadc(ps, F_AR);
-    bool need_item = fresh;
-    unsigned bx = 0, by = 0, bw = 1, bh = 1;
-    if (rc.stream_mode == RL_STREAM_REFERENCE_ORDER && item < rc.n_items) block_geometry(rc, rc.owned_blocks[item], &bx, &by, &bw, &bh);
-    const unsigned split = rc.stream_mode == RL_STREAM_PER_SAMPLE ? rc.split : 1u;
-    const unsigned pitem = split > 1u ? item / split : item;         // pixel item of this lane
-    if (!fresh && split > 1u) {
-        // sample-parallel pixels: this lane owns samples s, s + split, ...; each sample's radiance is parked in
-        // sample_buf[s][pixel item] and k_fold_samples adds them up in sample order, as mod.rs:431 does
-        const Col L = loadc(ps, F_LR);
-        float* dst = rc.sample_buf + 3 * ((size_t)s * (rc.n_items / split) + pitem);
-        dst[0] = L.r; dst[1] = L.g; dst[2] = L.b;
-        s += split;
-        if (s >= rc.spp) need_item = true;
-    } else if (!fresh) {
-        // im_block.accumulate(.., c, "primal") in sample order (mod.rs:431)
-        acc = acc + loadc(ps, F_LR);
-        s++;
-        if (s == rc.spp) {
-            unsigned pix = rc.stream_mode == RL_STREAM_PER_SAMPLE ? rc.item_pixel[item] : (by + cursor / bw) * rc.W + (bx + cursor % bw);
-            Col px = scale_unguarded(acc, rc.inv_spp);            // im_block.scale(1 / spp) (mod.rs:436)
-            rc.out[3 * (size_t)pix] = px.r; rc.out[3 * (size_t)pix + 1] = px.g; rc.out[3 * (size_t)pix + 2] = px.b;
-            acc = czero();
-            s = 0;
-            if (rc.stream_mode == RL_STREAM_PER_SAMPLE) need_item = true;
-            else { cursor++; if (cursor == bw * bh) need_item = true; }
-        }
-    }
-    Rng rng;
-    if (need_item) {
-        if (!fresh) item = DYNAMIC ? atomicAdd(&rc.counters->next_item, 1u) : rc.n_items;   // fused kernel: one item per thread
-        if (item >= rc.n_items) {
-            PU(U_FLAGS) = ST_FINISHED;
-            if (DYNAMIC) atomicSub(&rc.counters->active, 1u);
-            return;
-        }
-        cursor = 0;
-        if (rc.stream_mode == RL_STREAM_PER_SAMPLE) {
-            const unsigned pi = split > 1u ? item / split : item;
-            Rng item_rng = rng_seed(rc.item_seed[pi], rc.seed_variant);     // pixel sampler = block_sampler.clone_box()
-            if (split > 1u) { s = item % split; for (unsigned k = 0; k < s; k++) rng_next_u64(item_rng); }   // forks of the samples before ours
-            rng = rng_seed(rng_next_u64(item_rng), rc.seed_variant);        // sample sampler = pixel_sampler.clone_box()
-            store_rng(ps, Q_I0, item_rng);
-        } else {
-            unsigned b = rc.owned_blocks[item];
-            block_geometry(rc, b, &bx, &by, &bw, &bh);
-            rng = rng_seed(rc.block_seeds[b], rc.seed_variant);            // the block's own sampler (mod.rs:371)
-        }
-        PU(U_ITEM) = item;
-    } else if (rc.stream_mode == RL_STREAM_PER_SAMPLE) {
-        Rng item_rng = load_rng(ps, Q_I0);
-        for (unsigned k = 1; k < split; k++) rng_next_u64(item_rng);        // the forks taken by the other lanes of this pixel
-        rng = rng_seed(rng_next_u64(item_rng), rc.seed_variant);
-        store_rng(ps, Q_I0, item_rng);
-    } else {
-        rng = load_rng(ps, Q_R0);
-    }
-    unsigned px, py;
-    if (rc.stream_mode == RL_STREAM_PER_SAMPLE) { unsigned pix = rc.item_pixel[split > 1u ? item / split : item]; px = pix % rc.W; py = pix / rc.W; }
-    else { px = bx + cursor % bw; py = by + cursor / bw; }
-    // Path::from_sensor: uv = (ix + next(), iy + next())
-    float u = (float)px + rng_next_f32(rng);
-    float v = (float)py + rng_next_f32(rng);
-    n_draws += 2;
-    n_samples++;
-    storec(ps, F_AR, acc);
-    PU(U_SAMPLE) = s;
-    PU(U_CURSOR) = cursor;
-    const bool expand = (!rc.has_max || 1u < rc.max_depth);   // TechniquePathTracing::expand at depth 1
-    if (!expand) {   // sensor not expanded: the sample is 0 (next raygen pass folds it)
-        storec(ps, F_LR, czero());
-        store_rng(ps, Q_R0, rng);
-        PU(U_FLAGS) = ST_REGEN;
-        return;
-    }
-    const V3 d = camera_direction(sc, u, v);   // Camera::generate (camera.rs:81-91)
-    // the sensor edge's state is implied by PREV_SENSOR and never stored: origin = Camera::position(),
-    // weight 1, rr_weight 1, PDF::SolidAngle(1), beta = thr = 1 (strategies/directional.rs:27-41)
-    store3(ps, F_DX, d);
-    if (sc.medium.enabled) { PF(F_XI) = rng_next_f32(rng); n_draws++; }   // Edge::from_ray's medium.sample(ray, next())
-    store_rng(ps, Q_R0, rng);
-    PU(U_DEPTH) = 1u;
-    PU(U_FLAGS) = ST_RAY | (PREV_SENSOR << ST_PREV_SHIFT) | ST_PDF_SA;
-}
-
 // k_raygen — persistent threads (grid-stride loop over the pool).
 __global__ void __launch_bounds__(256) k_raygen(RenderConst rc, DeviceScene sc, Pool pool) {
     unsigned n_samples = 0, n_draws = 0;
@@ -389,41 +111,6 @@ __global__ void __launch_bounds__(256) k_fold_samples(RenderConst rc) {
 // [3] sum over waves of 64 * (max node steps in the wave) = what the wave pays, [4] waves, [5] rays with zero steps
 __device__ unsigned long long g_trav_stats[8];
 #endif
-// ------------------------------------------------------------------------------------------
-// extend_slot / shadow_slot — Acceleration::trace and Acceleration::visible for one slot.
-template <class PS, class Stack>
-RL_DEV void extend_slot(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, PS& ps, int* dbg = nullptr) {
-    const unsigned flags = PU(U_FLAGS);
-    const bool primary = ((flags >> ST_PREV_SHIFT) & 3u) == PREV_SENSOR;    // camera rays start at Camera::position()
-    V3 o = primary ? mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]) : load3(ps, F_OX);
-    V3 d = load3(ps, F_DX);
-    Hit hit; hit.t = kF32Max; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
-    traverse<false>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
-                    o, d, kEps, kF32Max, hit, stack);
-    PF(F_T) = hit.t; PF(F_U) = hit.u; PF(F_V) = hit.v;
-    PU(U_PRIM) = (unsigned)hit.prim;
-    if (dbg) { dbg[0] = hit.steps; dbg[1] = hit.tris; }
-}
-template <class PS, class Stack>
-RL_DEV void shadow_slot(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, PS& ps) {
-    // Acceleration::visible(p0, p1) (accel.rs:316-343)
-    V3 p0 = load3(ps, F_OX), p1 = load3(ps, F_SX);
-    V3 d = p1 - p0;
-    float len = length(d);
-    d = d / len;
-    float tfar = len * (1.0f - 0.00001f);
-    Hit hit; hit.t = tfar; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
-    V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
-    float te;
-    bool vis;
-    if (!slab(mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]), p0, inv_d, kEps, tfar, &te))
-        vis = false;   // root box missed => "occluded" (accel.rs:338-340)
-    else
-        vis = !traverse<true>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
-                              p0, d, kEps, tfar, hit, stack);
-    if (vis) storec(ps, F_LR, loadc(ps, F_LR) + loadc(ps, F_CR));
-}
-
 // k_extend / k_shadow — traversal kernels.  Dynamic LDS = [staged scene][compaction list][per-lane stacks].
 template <bool LDS_SCENE, bool SHADOW>
 RL_DEV void trace_kernel_body(const DeviceScene& sc, const Pool& pool, const StackConf& stc) {
@@ -469,208 +156,6 @@ template <bool LDS_SCENE>
 __global__ void __launch_bounds__(256) k_extend(RenderConst rc, DeviceScene sc, Pool pool, StackConf stc) { trace_kernel_body<LDS_SCENE, false>(sc, pool, stc); }
 template <bool LDS_SCENE>
 __global__ void __launch_bounds__(256) k_shadow(RenderConst rc, DeviceScene sc, Pool pool, StackConf stc) { trace_kernel_body<LDS_SCENE, true>(sc, pool, stc); }
-
-// shade_slot<MAT, MEDIUM> — one path vertex of one slot.  MAT >= 0: the hit material is known to have that
-// BSDF type (per-BSDF code path, uniform over the calling lanes); MAT = -1: generic (run-time switch).
-template <int MAT, bool MEDIUM, class PS>
-RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, unsigned flags,
-                       unsigned& n_vertices, unsigned& n_draws, unsigned& n_shadow, unsigned& n_ext) {
-    n_ext += 1;      // every shaded slot carried exactly one extension ray through k_extend
-    const unsigned prev = (flags >> ST_PREV_SHIFT) & 3u;
-    const unsigned depth = PU(U_DEPTH);          // generate()'s depth at which the edge's origin vertex was expanded
-    const int prim = (int)PU(U_PRIM);
-    const bool primary = prev == PREV_SENSOR;     // sensor edge: implied state, see k_raygen
-    const V3 ro = primary ? mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]) : load3(ps, F_OX);
-    const V3 rd = load3(ps, F_DX);
-    const float t_hit = PF(F_T);
-    Col w_edge = primary ? cone() : loadc(ps, F_WR);
-    const float rr = primary ? 1.0f : PF(F_RR);
-    const float pdf_edge = primary ? 1.0f : PF(F_PDF);
-    Col beta = primary ? cone() : loadc(ps, F_BR);
-    Col L = primary ? czero() : loadc(ps, F_LR);
-    bool zeroed = (flags & ST_ZEROED) != 0u;
-    const bool hit = prim >= 0;
-    bool is_volume = false;
-    V3 vpos = mk3(0.0f, 0.0f, 0.0f);
-    if (MEDIUM) {
-        // Edge::from_ray (paths/edge.rs:93-162): distance sampling up to the surface (or infinity on a miss)
-        MediumSample ms = medium_sample(sc.medium, hit ? t_hit : kF32Max, PF(F_XI));
-        w_edge = w_edge * ms.w;
-        is_volume = !hit || !ms.exited;
-        if (is_volume) vpos = ro + rd * ms.t;
-    }
-    bool ended = false;
-    unsigned new_flags = ST_REGEN;
-    if (!MEDIUM && !hit) {
-        // edge without a next vertex: Edge::contribution = weight * rr * scene.enviroment_luminance(d) (edge.rs:201-210)
-        ended = true;
-        if (sc.env_emitter >= 0) {
-            Col contrib = (w_edge * rr) * env_eval(sc, rd);
-            const bool add_contrib = rc.has_min ? (depth - 1u) >= rc.min_depth : true;
-            if (prev == PREV_SENSOR) {
-                if (!is_zero(contrib) && add_contrib) L = L + contrib;
-            } else if (!zeroed) {
-                if (rc.strategy == RL_STRATEGY_EMITTER) contrib = czero();
-                if (!is_zero(contrib) && add_contrib) {
-                    float wmis = 1.0f;
-                    if (rc.strategy == RL_STRATEGY_ALL && (flags & ST_PDF_SA)) {
-                        // pdf_emitter, `None` next vertex: direct_pdf of the environment (emitters.rs:18-46)
-                        float p2 = (prev == PREV_SURFACE || prev == PREV_VOLUME) ? env_direct_pdf(sc, rd) : 0.0f;
-                        float total = (0.0f + pdf_edge) + p2;
-                        wmis = div_rn(pdf_edge, total);
-                    }
-                    L = L + beta * (contrib * wmis);
-                }
-            }
-            storec(ps, F_LR, L);
-        }
-    }
-    if (!ended) {
-        const Col W = w_edge * rr;                // edge.weight * edge.rr_weight (Color * f32, guarded)
-        SurfacePoint sp;
-        const Material* mat = nullptr;
-        MeshRecord mr;
-        if (!is_volume) {
-            sp = fill_intersection(sc, prim, PF(F_U), PF(F_V), ro, rd, t_hit);
-            mr = sc.meshes[sp.mesh];
-            mat = &sc.materials[mr.material];
-        }
-        // ---- contribution carried by the arriving edge (Edge::contribution -> Vertex::contribution)
-        Col emit = czero();
-        if (!is_volume && (mr.flags & MESH_IS_LIGHT) && dot(sp.n_s, -rd) >= 0.0f) emit = mkc(mr.emission[0], mr.emission[1], mr.emission[2]);
-        Col contrib = W * emit;
-        const unsigned cur = depth - 1u;          // evaluate()'s curr_depth of the origin vertex
-        const bool add_contrib = rc.has_min ? cur >= rc.min_depth : true;
-        if (prev == PREV_SENSOR) {
-            if (!is_zero(contrib) && add_contrib) L = L + contrib;              // path.rs:152-166 (no MIS)
-        } else if (!zeroed) {
-            if (rc.strategy == RL_STRATEGY_EMITTER) contrib = czero();          // id_sampling 0 != 1
-            if (!is_zero(contrib) && add_contrib) {
-                float wmis = 1.0f;
-                if (rc.strategy == RL_STRATEGY_ALL && (flags & ST_PDF_SA)) {
-                    // LightSamplingStrategy::pdf -> pdf_emitter (strategies/emitters.rs:10-92,250-282)
-                    float p2 = 0.0f;
-                    if (!is_volume && (mr.flags & MESH_IS_LIGHT) && (prev == PREV_SURFACE || prev == PREV_VOLUME))
-                        p2 = light_direct_pdf(sc, mr, sc.tris[prim].tri, ro, sp.p, sp.n_g, rd, false, mk3(0.0f, 0.0f, 0.0f));   // n = None (emitters.rs:52-57)
-                    float total = (0.0f + pdf_edge) + p2;
-                    wmis = div_rn(pdf_edge, total);                             // balance heuristic (path.rs:80-98)
-                }
-                L = L + beta * (contrib * wmis);
-            }
-        }
-        beta = beta * W;
-        if (rc.single_scattering && !is_volume) zeroed = true;                  // evaluate(): surface vertex => subtree is 0
-
-        // ---- expand the new vertex (generate(), strategies/mod.rs:35-80)
-        const unsigned gen = depth + 1u;
-        const bool expand = (rc.has_max ? gen < rc.max_depth : true) && gen < kDepthCap;
-        if (expand) {
-            n_vertices += 1;
-            Rng rng = load_rng(ps, Q_R0);
-            Col thr = primary ? cone() : loadc(ps, F_TR);
-            const V3 vp = is_volume ? vpos : sp.p;
-            const V3 d_in = -rd;
-            // strategy 0: DirectionalSamplingStrategy::bounce (strategies/directional.rs:44-153)
-            V2 s2; s2.x = rng_next_f32(rng); s2.y = rng_next_f32(rng);
-            n_draws += 2;
-            bool has_edge = false;
-            bool sampled = false;
-            Col sw = czero(); V3 sd_world = mk3(0.0f, 0.0f, 0.0f); float spdf = 0.0f; int spdf_kind = PDF_SOLID_ANGLE;
-            if (is_volume) {
-                phase_sample(sc.medium, d_in, s2, &sd_world, &sw, &spdf);
-                sampled = true;
-            } else {
-                BsdfSample bs;
-                if (bsdf_sample<MAT>(sc, *mat, sp.has_uv, sp.uv, sp.wi, s2, &bs)) {
-                    sampled = true;
-                    sw = bs.weight; spdf = bs.pdf; spdf_kind = bs.pdf_kind;
-                    sd_world = to_world(sp.frame, bs.d);
-                }
-            }
-            float rr_new = 1.0f;
-            if (sampled) {
-                thr = thr * sw;
-                if (!is_zero(thr)) {
-                    const bool do_rr = rc.has_rr ? rc.rr_depth <= gen : true;
-                    bool alive = true;
-                    if (do_rr) {
-                        float q = rmin(channel_max(thr), 0.95f);
-                        float x = rng_next_f32(rng);
-                        n_draws++;
-                        if (q < x) alive = false; else rr_new = div_rn(1.0f, q);
-                    }
-                    if (alive) {
-                        thr = scale_unguarded(thr, rr_new);
-                        has_edge = true;
-                        if (MEDIUM) { PF(F_XI) = rng_next_f32(rng); n_draws++; }   // the new edge's medium.sample draw
-                    }
-                }
-            }
-            // strategy 1: LightSamplingStrategy::sample (strategies/emitters.rs:95-248)
-            const bool use_light = rc.strategy != RL_STRATEGY_BSDF;
-            const bool smooth = !is_volume && mat->smooth;
-            bool shadow = false;
-            if (use_light && !smooth) {
-                float a = rng_next_f32(rng);
-                float b = rng_next_f32(rng);
-                V2 c; c.x = rng_next_f32(rng); c.y = rng_next_f32(rng);
-                n_draws += 4;
-                n_shadow += 1;     // the reference always traces the shadow ray (emitters.rs:125-126)
-                LightSample ls = sample_light(sc, vp, !is_volume, is_volume ? mk3(0.0f, 0.0f, 0.0f) : sp.n_s, a, b, c);   // Some(&its.n_s) | None
-                if (ls.pdf != 0.0f) {
-                    Col wl;
-                    float p_dir;
-                    if (is_volume) { wl = phase_eval(sc.medium, d_in, ls.d); p_dir = phase_pdf(sc.medium, d_in, ls.d); }   // (no environment with a medium)
-                    else {
-                        V3 wo = to_local(sp.frame, ls.d);
-                        wl = bsdf_eval<MAT>(sc, *mat, sp.has_uv, sp.uv, sp.wi, wo, false);
-                        // the MIS pdf is asked along Edge::from_vertex's own direction (p_light - p) / |..| (edge.rs:37-39):
-                        // bitwise equal to ls.d for mesh lights, recomputed for the environment
-                        V3 wo_edge = wo;
-                        if (ls.kind == EMITTER_ENV) { V3 ed = ls.p - vp; ed = ed / length(ed); wo_edge = to_local(sp.frame, ed); }
-                        p_dir = bsdf_pdf<MAT>(sc, *mat, sp.has_uv, sp.uv, sp.wi, wo_edge, false);
-                    }
-                    if (MEDIUM) {
-                        V3 dd = ls.p - vp;
-                        wl = wl * medium_transmittance(sc.medium, dot(dd, ls.d));
-                    }
-                    Col c_l = ls.weight * wl * 1.0f;                       // contrib * weight * rr_weight (edge.rs:204)
-                    const bool add_l = rc.has_min ? (gen - 1u) >= rc.min_depth : true;
-                    if (!zeroed && !is_zero(c_l) && add_l) {
-                        float wmis = 1.0f;
-                        if (rc.strategy == RL_STRATEGY_ALL && ls.pdf_kind == PDF_SOLID_ANGLE) {   // Discrete (point / directional): no MIS
-                            float total = (0.0f + p_dir) + ls.pdf;
-                            wmis = div_rn(ls.pdf, total);
-                        }
-                        Col pending = beta * (c_l * wmis);
-                        // a zero contribution needs no visibility test: the image cannot change
-                        if (!is_zero(pending)) {
-                            shadow = true;
-                            store3(ps, F_SX, ls.p);
-                            storec(ps, F_CR, pending);
-                        }
-                    }
-                }
-            }
-            store_rng(ps, Q_R0, rng);
-            store3(ps, F_OX, vp);
-            new_flags = shadow ? ST_SHADOW : 0u;
-            if (has_edge) {
-                store3(ps, F_DX, sd_world);
-                storec(ps, F_TR, thr);
-                storec(ps, F_WR, sw);
-                PF(F_RR) = rr_new;
-                PF(F_PDF) = spdf;
-                PU(U_DEPTH) = gen;
-                const unsigned kind = is_volume ? PREV_VOLUME : (smooth ? PREV_SURFACE_SMOOTH : PREV_SURFACE);
-                new_flags |= ST_RAY | (kind << ST_PREV_SHIFT) | (spdf_kind == PDF_SOLID_ANGLE ? ST_PDF_SA : 0u) | (zeroed ? ST_ZEROED : 0u);
-            } else new_flags |= ST_REGEN;
-        }
-        storec(ps, F_BR, beta);
-        storec(ps, F_LR, L);
-    } else if (primary && sc.env_emitter < 0) storec(ps, F_LR, L);   // camera ray left the scene: the sample is 0
-    PU(U_FLAGS) = new_flags;
-}
 
 // k_shade<MAT, MEDIUM>: scenes with a single BSDF type — every live slot goes straight to that BSDF's code.
 template <int MAT, bool MEDIUM>
@@ -821,121 +306,6 @@ __global__ void __launch_bounds__(256, RL_FUSED_WAVES) k_path_fused(RenderConst 
         const unsigned vals[5] = {n_samples, n_vertices, n_draws, n_shadow, n_ext};
         block_stats<5>(rc.partials, which, vals);
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_pixel_mc<KIND> — the other two `compute_mc` integrators, one lane per work item
-// (pixel, or block in reference-order mode), samples folded in order:
-//   KIND 0  IntegratorAO::compute_pixel      src/integrators/ao.rs:20-70
-//   KIND 1  IntegratorDirect::compute_pixel  src/integrators/direct.rs:21-233 (power heuristic, mod.rs:462-478)
-struct McConst {
-    int has_max_distance; float max_distance; int normal_correction;
-    unsigned nb_bsdf_samples, nb_light_samples;
-};
-RL_DEV float mis_weight_power(float pdf_a, float pdf_b) {
-    if (pdf_a == 0.0f) return 0.0f;
-    if (!finite_f(pdf_a) || !finite_f(pdf_b)) return 0.0f;
-    float w = div_rn(pdf_a * pdf_a, pdf_a * pdf_a + pdf_b * pdf_b);
-    return finite_f(w) ? w : 0.0f;
-}
-template <class Stack>
-RL_DEV bool trace_closest(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, V3 o, V3 d, Hit& hit) {
-    hit.t = kF32Max; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
-    traverse<false>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
-                    o, d, kEps, kF32Max, hit, stack);
-    return hit.prim >= 0;
-}
-template <class Stack>
-RL_DEV bool trace_visible(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, V3 p0, V3 p1) {
-    V3 d = p1 - p0;
-    float len = length(d);
-    d = d / len;
-    float tfar = len * (1.0f - 0.00001f);
-    Hit hit; hit.t = tfar; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
-    V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
-    float te;
-    if (!slab(mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]), p0, inv_d, kEps, tfar, &te)) return false;
-    return !traverse<true>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
-                           p0, d, kEps, tfar, hit, stack);
-}
-
-template <int KIND, class Stack>
-RL_DEV Col mc_compute_pixel(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, const McConst& mp, unsigned px, unsigned py, Rng& rng,
-                            unsigned& n_draws, unsigned& n_ext, unsigned& n_shadow, unsigned& n_vertices) {
-    float u = (float)px + rng_next_f32(rng);
-    float v = (float)py + rng_next_f32(rng);
-    n_draws += 2;
-    const V3 o = mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]);
-    const V3 d = camera_direction(sc, u, v);
-    Hit hit;
-    n_ext++;
-    if (!trace_closest(sc, recs, stack, o, d, hit)) {
-        if (KIND == 1 && sc.env_emitter >= 0) return env_eval(sc, d);   // scene.enviroment_luminance(ray.d)
-        return czero();
-    }
-    const SurfacePoint sp = fill_intersection(sc, hit.prim, hit.u, hit.v, o, d, hit.t);
-    if (KIND == 0) {
-        if (!mp.normal_correction && sp.wi.z <= 0.0f) return czero();
-        const bool flipped = mp.normal_correction && sp.wi.z <= 0.0f;
-        V2 s2; s2.x = rng_next_f32(rng); s2.y = rng_next_f32(rng);
-        n_draws += 2;
-        V3 d_local = cosine_sample_hemisphere(s2);
-        V3 d_world = flipped ? to_world(sp.frame, -d_local) : to_world(sp.frame, d_local);
-        Hit h2;
-        n_ext++;
-        if (!trace_closest(sc, recs, stack, sp.p, d_world, h2)) return cone();
-        if (!mp.has_max_distance) return czero();
-        return h2.t > mp.max_distance ? cone() : czero();
-    }
-    // ---- direct
-    Col l_i = czero();
-    if (sp.wi.z <= 0.0f) return l_i;
-    const MeshRecord mr = sc.meshes[sp.mesh];
-    const Material& mat = sc.materials[mr.material];
-    l_i = l_i + ((mr.flags & MESH_IS_LIGHT) ? mkc(mr.emission[0], mr.emission[1], mr.emission[2]) : czero());
-    const float w_nb_bsdf = mp.nb_bsdf_samples == 0u ? 0.0f : div_rn(1.0f, (float)mp.nb_bsdf_samples);
-    const float w_nb_light = mp.nb_light_samples == 0u ? 0.0f : div_rn(1.0f, (float)mp.nb_light_samples);
-    n_vertices++;
-    for (unsigned k = 0; k < mp.nb_light_samples; k++) {
-        float a = rng_next_f32(rng);
-        float b = rng_next_f32(rng);
-        V2 c; c.x = rng_next_f32(rng); c.y = rng_next_f32(rng);
-        n_draws += 4;
-        LightSample ls = sample_light(sc, sp.p, true, sp.n_s, a, b, c);   // Some(&its.n_s) (direct.rs:64-70)
-        V3 d_out_local = to_local(sp.frame, ls.d);
-        if (ls.pdf == 0.0f) continue;
-        n_shadow++;
-        if (!trace_visible(sc, recs, stack, sp.p, ls.p)) continue;
-        if (mat.smooth) continue;
-        float pdf_bsdf = bsdf_pdf<-1>(sc, mat, sp.has_uv, sp.uv, sp.wi, d_out_local, false);
-        float weight_light = ls.pdf_kind == PDF_SOLID_ANGLE ? mis_weight_power(ls.pdf * w_nb_light, pdf_bsdf * w_nb_bsdf) : 1.0f;
-        l_i = l_i + weight_light * bsdf_eval<-1>(sc, mat, sp.has_uv, sp.uv, sp.wi, d_out_local, false) * w_nb_light * ls.weight;
-    }
-    for (unsigned k = 0; k < mp.nb_bsdf_samples; k++) {
-        V2 s2; s2.x = rng_next_f32(rng); s2.y = rng_next_f32(rng);
-        n_draws += 2;
-        BsdfSample bs;
-        if (!bsdf_sample<-1>(sc, mat, sp.has_uv, sp.uv, sp.wi, s2, &bs)) continue;
-        V3 d_out_world = to_world(sp.frame, bs.d);
-        Hit h2;
-        n_ext++;
-        if (trace_closest(sc, recs, stack, sp.p, d_out_world, h2)) {
-            const SurfacePoint nx = fill_intersection(sc, h2.prim, h2.u, h2.v, sp.p, d_out_world, h2.t);
-            const MeshRecord nm = sc.meshes[nx.mesh];
-            if ((nm.flags & MESH_IS_LIGHT) && dot(nx.n_g, -d_out_world) > 0.0f) {
-                float weight_bsdf = 1.0f;
-                if (bs.pdf_kind == PDF_SOLID_ANGLE) {
-                    float light_pdf = light_direct_pdf(sc, nm, sc.tris[h2.prim].tri, sp.p, nx.p, nx.n_g, d_out_world, true, sp.n_s);   // direct.rs:156-164
-                    weight_bsdf = mis_weight_power(bs.pdf * w_nb_bsdf, light_pdf * w_nb_light);
-                }
-                l_i = l_i + weight_bsdf * bs.weight * mkc(nm.emission[0], nm.emission[1], nm.emission[2]) * w_nb_bsdf;
-            }
-        } else if (sc.env_emitter >= 0) {
-            float weight_bsdf = bs.pdf_kind == PDF_SOLID_ANGLE ? mis_weight_power(bs.pdf * w_nb_bsdf, env_direct_pdf(sc, d_out_world) * w_nb_light) : 1.0f;
-            l_i = l_i + weight_bsdf * bs.weight * env_eval(sc, d_out_world) * w_nb_bsdf;
-        }
-    }
-    return l_i;
 }
 
 template <int KIND, bool LDS_SCENE>
