@@ -36,6 +36,14 @@ def test_no_gpu_means_loud_failure_not_fallback(built, cbox64):
         pytest.skip("GPU present")
     with pytest.raises(api.NoDeviceError):
         api.Context(api.Scene(cbox64))
+    # the CLI (C++ mirror of examples/cli.rs) parses, loads and builds the scene, then refuses to render without a device
+    import subprocess
+    cli = os.path.join(os.path.dirname(api.LIB_PATH), "rustlight-amd")
+    for args in (["-n", "1", "-o", "/tmp/never.pfm", "path"], ["-x", "ats", "-n", "1", "-o", "/tmp/never.pfm", "direct", "-b", "1"]):
+        r = subprocess.run([cli, os.path.join(ROOT, "data", "cbox.pbrt"), *args], capture_output=True, text=True)
+        assert r.returncode != 0 and "no CPU fallback" in r.stderr and not os.path.exists("/tmp/never.pfm")
+    r = subprocess.run([cli, os.path.join(ROOT, "data", "cbox.pbrt"), "-x", "hvs-light", "path"], capture_output=True, text=True)
+    assert r.returncode == 2 and "not supported" in r.stderr
 
 
 def test_error_codes(built):

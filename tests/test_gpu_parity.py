@@ -285,6 +285,35 @@ def test_golden_feature_renders_on_gpu(built):
         np.testing.assert_array_equal(img, gold[name], err_msg=name)
 
 
+def test_cli_renders_what_the_api_renders(built, tmp_path):
+    """`rustlight-amd` (the C++ mirror of examples/cli.rs) end to end: scene file -> loader -> emitters (-x ats) -> integrator ->
+    image file, equal to the Python mirror's render with the same master seed; `-m` adds the medium, `direct` / `ao` run too."""
+    import os
+    import subprocess
+    from rustlight_amd import export
+    cli = os.path.join(os.path.dirname(api.LIB_PATH), "rustlight-amd")
+    sd = scenes.many_lights(40, 32, 2)
+    sd.flip, sd.fov_axis = True, 0
+    xml = str(tmp_path / "lights.xml")
+    export.write_mitsuba(sd, xml, "ply")
+    def run(*args):
+        out = str(tmp_path / "out.pfm")
+        r = subprocess.run([cli, xml, "-n", "3", "-r", "independent:11", "-o", out, *args], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        return api.load_pfm(out)
+    seeds = lambda: api.IndependentSampler(11).block_seeds(40, 32)
+    ctx = api.Context(api.Scene(sd), 0)
+    np.testing.assert_array_equal(run("-x", "ats", "path", "-m", "5"), ctx.render(seeds(), api.path_params(spp=3, max_depth=5))[0])
+    np.testing.assert_array_equal(run("-x", "ats", "direct", "-b", "2", "-l", "1"), ctx.render_direct(seeds(), spp=3, nb_bsdf_samples=2, nb_light_samples=1)[0])
+    sd.use_ats = False
+    flat = api.Context(api.Scene(sd), 0)
+    np.testing.assert_array_equal(run("path", "-s", "emitter"), flat.render(seeds(), api.path_params(spp=3, strategy=api.STRATEGY_EMITTER))[0])
+    np.testing.assert_array_equal(run("ao", "-d", "0.5"), flat.render_ao(seeds(), spp=3, max_distance=0.5)[0])
+    sd.medium = scenes.Medium((0.1, 0.1, 0.1), (0.3, 0.3, 0.3), scenes.PHASE_HG, 0.5)
+    fog = api.Context(api.Scene(sd), 0)
+    np.testing.assert_array_equal(run("-m", "0.3:0.1:0.5", "path", "-m", "6"), fog.render(seeds(), api.path_params(spp=3, max_depth=6))[0])
+
+
 def test_progressive_wrappers(built, cbox64, tmp_path):
     """IntegratorAverage / IntegratorEqualTime (avg.rs, equal_time.rs): every pass draws fresh block seeds from the same,
     advancing master sampler; pass k of the wrapper equals a plain render with the k-th batch of seeds."""
