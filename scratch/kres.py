@@ -2,7 +2,7 @@
 import re, subprocess, sys
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 extra = sys.argv[2:]
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-c",
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-c",
        "/root/repo/rustlight_amd/csrc/kernels/wavefront.hip", "-o", "/tmp/kres.o", "-Rpass-analysis=kernel-resource-usage", *extra]
 out = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp").stderr
 cur = None; rows = []

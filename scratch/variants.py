@@ -14,7 +14,7 @@ def build(specs):
         name, _, flags = spec.partition(":")
         flags = [f for f in flags.split(",") if f]
         obj = os.path.join(VDIR, name + ".o")
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", *flags, "-c",
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", *flags, "-c",
                os.path.join(ROOT, "rustlight_amd/csrc/kernels/wavefront.hip"), "-o", obj]
         procs.append((name, obj, subprocess.Popen(cmd, cwd="/tmp", stderr=subprocess.PIPE, text=True)))
     for name, obj, p in procs:
