@@ -1,6 +1,6 @@
 # Collect the round's rocprofv3 evidence on the GPU box: kernel-trace stats for both pipelines, HBM PMC passes, bench lines.
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r1c; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND_TAG:-r1d}; mkdir -p $O
 B="python $R/bench.py --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fused -o p -- $B --steps 3 --warmup 1 > $O/fused.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/wavefront -o p -- $B --steps 3 --warmup 1 --pipeline wavefront > $O/wavefront.log 2>&1
