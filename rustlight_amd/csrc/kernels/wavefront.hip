@@ -599,7 +599,11 @@ static int ensure(T** p, size_t* cap, size_t n) {
     return RL_OK;
 }
 
-static int lds_levels_of(const rl_context* ctx) { return std::min<int>((int)ctx->ds.stack_depth, kLdsStackLevels); }
+// Scenes that stream their BVH keep only kLdsStackLevelsStreaming levels in LDS: their pools are sparse (most waves of a
+// workgroup exit after the compaction), so what limits the live waves per CU is how many workgroups' stacks fit in LDS —
+// 508 k-triangle scene, 32 spp: 12 / 8 / 6 / 4 / 2 / 0 levels in LDS = 258 / 233 / 228 / 229 / 240 / 251 ms.
+static constexpr int kLdsStackLevelsStreaming = 6;
+static int lds_levels_of(const rl_context* ctx) { return std::min<int>((int)ctx->ds.stack_depth, ctx->lds_scene ? kLdsStackLevels : kLdsStackLevelsStreaming); }
 static size_t traversal_lds_bytes(const rl_context* ctx, bool lds_scene, unsigned block, bool with_list) {
     size_t stack = (size_t)2 * lds_levels_of(ctx) * block * sizeof(int);
     return (lds_scene ? ctx->scene_lds_bytes : 0) + (with_list ? 272 * sizeof(unsigned) : 0) + stack;   // [scene][compaction list][stacks]
