@@ -177,43 +177,55 @@ __global__ void __launch_bounds__(256) k_shade(RenderConst rc, DeviceScene sc, P
 // binned by the BSDF type of the surface they hit, then each BSDF's code runs once over its packed bin, so
 // a wave never mixes two BSDFs.
 static constexpr int kNumBins = 5;
-template <bool MEDIUM>
+// CHUNKS: 256-slot chunks of the pool per workgroup.  With sample-parallel pixels on a scene most camera rays miss, only one
+// slot in eight carries a vertex; one chunk would leave a single part-filled wave per workgroup (and this kernel's register
+// footprint allows 3 workgroups per CU), so sparse pools are gathered four chunks at a time into full waves
+// (508 k-triangle scene, 128 spp: 781 -> 645 ms; the traversal kernels gain nothing from the same trick).
+template <bool MEDIUM, unsigned CHUNKS>
 __global__ void __launch_bounds__(256) k_shade_sorted(RenderConst rc, DeviceScene sc, Pool pool) {
-    __shared__ unsigned s_list[256];
-    __shared__ unsigned s_wave_cnt[kNumBins][4];
-    unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ unsigned s_list[256 * CHUNKS];
+    __shared__ unsigned s_cnt[kNumBins][CHUNKS][4];
     unsigned n_vertices = 0, n_draws = 0, n_shadow = 0, n_ext = 0;
-    PoolState ps{pool, slot};
-    const unsigned flags = slot < pool.P ? PU(U_FLAGS) : 0u;
-    int bin = -1;
-    if (flags & ST_RAY) {
-        const int prim = (int)PU(U_PRIM);
-        bin = 0;
-        if (prim >= 0) bin = sc.materials[sc.meshes[sc.tris[prim].mesh].material].type;
-    }
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    unsigned rank = 0;
+    unsigned slot[CHUNKS], rank[CHUNKS];
+    int bin[CHUNKS];
 #pragma unroll
-    for (int b = 0; b < kNumBins; b++) {
-        const unsigned long long mask = __ballot(bin == b);
-        if (bin == b) rank = __popcll(mask & ((1ull << lane) - 1ull));
-        if (lane == 0u) s_wave_cnt[b][wave] = (unsigned)__popcll(mask);
+    for (unsigned c = 0; c < CHUNKS; c++) {
+        slot[c] = (blockIdx.x * CHUNKS + c) * blockDim.x + threadIdx.x;
+        const unsigned flags = slot[c] < pool.P ? pool.u[(size_t)U_FLAGS * pool.P + slot[c]] : 0u;
+        bin[c] = -1;
+        if (flags & ST_RAY) {
+            const int prim = (int)pool.u[(size_t)U_PRIM * pool.P + slot[c]];
+            bin[c] = 0;
+            if (prim >= 0) bin[c] = sc.materials[sc.meshes[sc.tris[prim].mesh].material].type;
+        }
+        rank[c] = 0;
+#pragma unroll
+        for (int b = 0; b < kNumBins; b++) {
+            const unsigned long long mask = __ballot(bin[c] == b);
+            if (bin[c] == b) rank[c] = __popcll(mask & ((1ull << lane) - 1ull));
+            if (lane == 0u) s_cnt[b][c][wave] = (unsigned)__popcll(mask);
+        }
     }
     __syncthreads();
     unsigned bin_begin[kNumBins + 1];
-    unsigned my_off = 0, run = 0;
+    unsigned my_off[CHUNKS];
+    unsigned run = 0;
 #pragma unroll
     for (int b = 0; b < kNumBins; b++) {
         bin_begin[b] = run;
 #pragma unroll
-        for (unsigned w = 0; w < 4u; w++) { if (b == bin && w == wave) my_off = run; run += s_wave_cnt[b][w]; }
+        for (unsigned c = 0; c < CHUNKS; c++)
+#pragma unroll
+            for (unsigned w = 0; w < 4u; w++) { if (b == bin[c] && w == wave) my_off[c] = run; run += s_cnt[b][c][w]; }
     }
     bin_begin[kNumBins] = run;
-    if (bin >= 0) s_list[my_off + rank] = slot;
+#pragma unroll
+    for (unsigned c = 0; c < CHUNKS; c++) if (bin[c] >= 0) s_list[my_off[c] + rank[c]] = slot[c];
     __syncthreads();
 #define RL_SHADE_BIN(B)                                                                                       \
     { const unsigned n = bin_begin[(B) + 1] - bin_begin[B];                                                   \
-      if (threadIdx.x < n) { PoolState pb{pool, s_list[bin_begin[B] + threadIdx.x]};                           \
+      for (unsigned i = threadIdx.x; i < n; i += blockDim.x) { PoolState pb{pool, s_list[bin_begin[B] + i]};    \
           shade_slot<B, MEDIUM>(rc, sc, pb, pb.u(U_FLAGS), n_vertices, n_draws, n_shadow, n_ext); } }
     RL_SHADE_BIN(0) RL_SHADE_BIN(1) RL_SHADE_BIN(2) RL_SHADE_BIN(3) RL_SHADE_BIN(4)
 #undef RL_SHADE_BIN
@@ -783,6 +795,9 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     const DeviceScene& ds = ctx->ds;
     const dim3 block(256);
     const dim3 grid_all((P + 255) / 256);
+    // material-sort kernel: sparse pools (several lanes per pixel) are gathered four 256-slot chunks per workgroup
+    const unsigned sort_chunks = split > 1 ? 4u : 1u;
+    const dim3 grid_sort((P + 1023) / 1024);
     int n_cu = 256;
     hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
     const dim3 grid_persistent(std::min<unsigned>((P + 255) / 256, (unsigned)n_cu * 8u));
@@ -843,8 +858,13 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         else hipLaunchKernelGGL((k_extend<false>), grid_all, block, lds_trav, st, rc, ds, pool, stc);
         if (timing) { hipEventRecord(ev[3], st); hipEventRecord(ev[4], st); }
         if (use_sort) {
-            if (medium) hipLaunchKernelGGL((k_shade_sorted<true>), grid_all, block, 0, st, rc, ds, pool);
-            else hipLaunchKernelGGL((k_shade_sorted<false>), grid_all, block, 0, st, rc, ds, pool);
+            if (sort_chunks == 4u) {
+                if (medium) hipLaunchKernelGGL((k_shade_sorted<true, 4>), grid_sort, block, 0, st, rc, ds, pool);
+                else hipLaunchKernelGGL((k_shade_sorted<false, 4>), grid_sort, block, 0, st, rc, ds, pool);
+            } else {
+                if (medium) hipLaunchKernelGGL((k_shade_sorted<true, 1>), grid_all, block, 0, st, rc, ds, pool);
+                else hipLaunchKernelGGL((k_shade_sorted<false, 1>), grid_all, block, 0, st, rc, ds, pool);
+            }
         } else launch_shade_type(ctx->bsdf_type, medium, grid_all, block, st, rc, ds, pool);
         launches += 1;
         if (timing) { hipEventRecord(ev[5], st); hipEventRecord(ev[6], st); }
