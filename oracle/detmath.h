@@ -16,6 +16,8 @@
 //
 // Compile with -ffp-contract=off (no FMA contraction) — the Makefile does.
 #pragma once
+// ORC_TIMING_BUILD (Makefile target librl_oracle_timing.so): the entry points below forward to libm — that build is only
+// ever timed as the CPU baseline of bench.py (-O3, native float transcendentals), never used as the checker.
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -69,14 +71,26 @@ static inline void sincos_d(double x, double* s, double* c) {
     }
 }
 static inline float sinf_det(float x) {
+#ifdef ORC_TIMING_BUILD
+    return std::sin(x);
+#endif
+
     if (!(x - x == 0.0f)) return x - x;  // NaN / inf -> NaN
     double s, c; sincos_d((double)x, &s, &c); return (float)s;
 }
 static inline float cosf_det(float x) {
+#ifdef ORC_TIMING_BUILD
+    return std::cos(x);
+#endif
+
     if (!(x - x == 0.0f)) return x - x;
     double s, c; sincos_d((double)x, &s, &c); return (float)c;
 }
 static inline void sincosf_det(float x, float* s, float* c) {
+#ifdef ORC_TIMING_BUILD
+    *s = std::sin(x); *c = std::cos(x); return;
+#endif
+
     if (!(x - x == 0.0f)) { *s = *c = x - x; return; }
     double sd, cd; sincos_d((double)x, &sd, &cd); *s = (float)sd; *c = (float)cd;
 }
@@ -146,12 +160,20 @@ static inline double log_d(double x) {
     return (ed * LN2_HI + lm) + ed * LN2_LO;
 }
 static inline float expf_det(float x) {
+#ifdef ORC_TIMING_BUILD
+    return std::exp(x);
+#endif
+
     if (x != x) return x;
     if (x > 89.0f) return (float)bits_to_f64(0x7ff0000000000000ull);
     if (x < -104.0f) return 0.0f;
     return (float)exp_d((double)x);
 }
 static inline float logf_det(float x) {
+#ifdef ORC_TIMING_BUILD
+    return std::log(x);
+#endif
+
     if (x != x) return x;
     if (x < 0.0f) return (float)bits_to_f64(0x7ff8000000000000ull);
     if (x == 0.0f) return -(float)bits_to_f64(0x7ff0000000000000ull);
@@ -160,6 +182,10 @@ static inline float logf_det(float x) {
 }
 // powf for the cases rustlight produces (x >= 0; see phong.rs:27-30,81-83,107-110).
 static inline float powf_det(float x, float y) {
+#ifdef ORC_TIMING_BUILD
+    return std::pow(x, y);
+#endif
+
     if (y == 0.0f) return 1.0f;
     if (x == 1.0f) return 1.0f;
     if (x != x || y != y) return x + y;
@@ -203,6 +229,10 @@ static inline double atan_d(double x) {
     return neg ? -r : r;
 }
 static inline float atan2f_det(float y, float x) {
+#ifdef ORC_TIMING_BUILD
+    return std::atan2(y, x);
+#endif
+
     if (x != x || y != y) return x + y;
     const double PI = 3.14159265358979311600;
     double yd = y, xd = x;
@@ -228,6 +258,10 @@ static inline double sqrt_d(double a) {
 }
 static inline float asinf_det(float x);
 static inline float acosf_det(float x) {
+#ifdef ORC_TIMING_BUILD
+    return std::acos(x);
+#endif
+
     if (x != x) return x;
     if (x > 1.0f || x < -1.0f) return (float)bits_to_f64(0x7ff8000000000000ull);
     double xd = x;
@@ -241,6 +275,9 @@ static inline float acosf_det(float x) {
 }
 
 static inline float asinf_det(float x) {
+#ifdef ORC_TIMING_BUILD
+    return std::asin(x);
+#endif
     if (x != x) return x;
     if (x > 1.0f || x < -1.0f) return (float)bits_to_f64(0x7ff8000000000000ull);
     double xd = x;

@@ -42,7 +42,7 @@ class OrcStats(C.Structure):
 def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, f) for f in ("rl_oracle.cpp", "rl_oracle.h", "detmath.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "rustlight_amd.h"))
-    stale = force or not os.path.exists(_LIB_PATH) or any(
+    stale = force or not os.path.exists(_LIB_PATH) or not os.path.exists(os.path.join(_HERE, "librl_oracle_timing.so")) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
@@ -50,13 +50,22 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+_timing = False
+
+
+def use_timing_build(on: bool = True):
+    """bench.py's cpu_baseline: load librl_oracle_timing.so (-O3, libm transcendentals, FMA allowed) instead of the parity build.
+    Must be called before the first use of the module; the timing build is never used as a checker."""
+    global _timing
+    assert _lib is None, "oracle already loaded"
+    _timing = on
 
 
 def lib():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(_LIB_PATH)
+        L = C.CDLL(os.path.join(_HERE, "librl_oracle_timing.so") if _timing else _LIB_PATH)
         L.orc_scene_create.restype = C.c_void_p
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_scene_set_camera.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_int,
