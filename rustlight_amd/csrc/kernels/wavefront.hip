@@ -181,8 +181,12 @@ static constexpr int kNumBins = 5;
 // slot in eight carries a vertex; one chunk would leave a single part-filled wave per workgroup (and this kernel's register
 // footprint allows 3 workgroups per CU), so sparse pools are gathered four chunks at a time into full waves
 // (508 k-triangle scene, 128 spp: 781 -> 645 ms; the traversal kernels gain nothing from the same trick).
+// 3 waves/SIMD (168 VGPRs, 11 spilled) beat the unconstrained 182-VGPR build at 2 waves and a 128-VGPR build at 4 (647 / 621 / 653 ms)
+#ifndef RL_SORT_WAVES
+#define RL_SORT_WAVES 3
+#endif
 template <bool MEDIUM, unsigned CHUNKS>
-__global__ void __launch_bounds__(256) k_shade_sorted(RenderConst rc, DeviceScene sc, Pool pool) {
+__global__ void __launch_bounds__(256, RL_SORT_WAVES) k_shade_sorted(RenderConst rc, DeviceScene sc, Pool pool) {
     __shared__ unsigned s_list[256 * CHUNKS];
     __shared__ unsigned s_cnt[kNumBins][CHUNKS][4];
     unsigned n_vertices = 0, n_draws = 0, n_shadow = 0, n_ext = 0;
