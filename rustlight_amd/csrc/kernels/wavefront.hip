@@ -717,7 +717,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         // look past the scene have drained, so it is cut into >= ~16 k workgroups (measured, rank 0 of 8 at 1024 spp:
         // 1 lane / pixel 122 ms, 8 lanes 69 ms, 16 lanes 69 ms; a full 8160-tile frame is best left at 1 lane: 64 vs 67 ms).
         const unsigned fused_groups = (n_pixels + 255u) / 256u;
-        const unsigned fused_auto = fused_groups >= 6000u ? 1u : (16384u + fused_groups - 1u) / std::max(1u, fused_groups);
+        const unsigned fused_auto = fused_groups >= 6000u ? 1u : std::max(1u, 16384u / std::max(1u, fused_groups));
         const unsigned want = params->sample_split ? params->sample_split
                             : (fused ? fused_auto : (ctx->lds_scene ? 1u : std::max(1u, (8u << 20) / std::max(1u, n_pixels))));
         split = std::max(1u, std::min(want, params->spp));
