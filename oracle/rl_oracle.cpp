@@ -20,7 +20,8 @@
 //     wavefront accumulates it; `eval_order = 0` is the reference's inner-first recursion
 //     (explicit/path.rs:113-184).  They differ only in f32 rounding of the final radiance.
 //
-// Build: see oracle/Makefile (g++ -O2 -ffp-contract=off, no fast-math).
+// Build: see oracle/Makefile (g++ -O2 -ffp-contract=off, no fast-math = the checker; a second, -O3 / libm / FMA build,
+// librl_oracle_timing.so, is only ever timed as bench.py's CPU baseline).
 
 #include <algorithm>
 #include <atomic>
