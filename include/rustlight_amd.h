@@ -239,6 +239,9 @@ typedef struct rl_render_stats {
 /* Opaque device context: BVHAccel::new(scene) (src/accel.rs:202-239) + flattened scene in HBM. */
 typedef struct rl_context rl_context;
 
+/* Number of HIP devices visible to the process (0 and RL_ERR_NO_DEVICE when there is none). */
+int rl_device_count(int* count);
+
 /* IntegratorType::compute's untimed prologue (src/integrators/mod.rs:280): builds the BVH2
  * (full-sweep SAH, leaf <= 2) on the host and uploads scene + BVH to `device` (HIP ordinal).
  * Fails with RL_ERR_NO_DEVICE when no GPU is present — there is no CPU fallback. */

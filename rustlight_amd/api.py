@@ -31,7 +31,7 @@ PUBLIC_SYMBOLS = [
     "rl_scene_add_bitmap", "rl_scene_set_medium", "rl_scene_add_point_light", "rl_scene_add_directional_light",
     "rl_scene_set_environment", "rl_scene_set_environment_map", "rl_scene_build_emitters", "rl_scene_enable_ats", "rl_scene_load_pbrt", "rl_scene_load_mitsuba", "rl_scene_load",
     "rl_scene_image_size", "rl_scene_counts", "rl_sampler_seed", "rl_sampler_next_u64", "rl_sampler_next_f32",
-    "rl_path_params_default", "rl_context_create", "rl_context_destroy", "rl_last_error", "rl_block_count",
+    "rl_path_params_default", "rl_device_count", "rl_context_create", "rl_context_destroy", "rl_last_error", "rl_block_count",
     "rl_generate_block_seeds", "rl_render_path", "rl_render_ao", "rl_render_direct", "rl_trace_batch", "rl_visible_batch", "rl_load_pfm", "rl_load_image", "rl_save_pfm", "rl_save_png", "rl_save_exr", "rl_save_image", "rl_build_info",
 ]
 

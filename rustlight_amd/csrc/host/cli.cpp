@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
     std::string max_depth = "inf", min_depth = "0", rr_depth = "0";
     size_t nbsamples = 1;
     float scale_image = 1.0f;
-    int device = 0;
+    int device = 0, gpus = 1;
     bool single_scattering = false, have_cmd = false, use_ats = false, shading_normals = true;
     std::string cmd, ao_distance = "1.0", average, equal_time;
     bool ao_normal_correction = false;
@@ -50,6 +50,7 @@ int main(int argc, char** argv) {
             else if (a == "-s" || a == "--scale-image") scale_image = std::strtof(val().c_str(), nullptr);
             else if (a == "-t" || a == "--threads") (void)val();   // host threads are irrelevant on the GPU path
             else if (a == "--device") device = std::atoi(val().c_str());
+            else if (a == "--gpus") gpus = std::atoi(val().c_str());
             else if (a == "--stream-mode") mode = val() == "reference" ? RL_STREAM_REFERENCE_ORDER : RL_STREAM_PER_SAMPLE;
             else if (a == "-a" || a == "--average") average = val();
             else if (a == "-e" || a == "--equal-time") equal_time = val();
@@ -113,6 +114,7 @@ int main(int argc, char** argv) {
         else { std::fprintf(stderr, "invalid strategy: %s\n", strategy.c_str()); return 2; }
         integrator.single_scattering = single_scattering;
         integrator.device = device;
+        integrator.n_gpus = gpus;      // --gpus N: blocks dealt round-robin over N devices, framebuffers added on the host
         integrator.stream_mode = mode;
         uint64_t seed;
         if (rng == "independent") seed = std::random_device{}();   // IndependentSampler::default(): OS entropy

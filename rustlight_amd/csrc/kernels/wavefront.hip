@@ -498,6 +498,14 @@ static int upload(rl_context* ctx, const std::vector<T>& v, const T** out) {
     return RL_OK;
 }
 
+extern "C" int rl_device_count(int* count) {
+    if (!count) return RL_ERR_INVALID_ARGUMENT;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { *count = 0; return RL_ERR_NO_DEVICE; }
+    *count = n;
+    return RL_OK;
+}
+
 extern "C" int rl_context_create(const rl_scene* scene, int device, rl_context** out) {
     if (!scene || !out) return RL_ERR_INVALID_ARGUMENT;
     if (!scene->has_camera) return RL_ERR_INVALID_ARGUMENT;

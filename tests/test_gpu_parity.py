@@ -309,6 +309,9 @@ def test_cli_renders_what_the_api_renders(built, tmp_path):
     flat = api.Context(api.Scene(sd), 0)
     np.testing.assert_array_equal(run("path", "-s", "emitter"), flat.render(seeds(), api.path_params(spp=3, strategy=api.STRATEGY_EMITTER))[0])
     np.testing.assert_array_equal(run("ao", "-d", "0.5"), flat.render_ao(seeds(), spp=3, max_distance=0.5)[0])
+    # --gpus N: N device contexts (round-robin over the visible devices — three on the one GPU here), one host thread each,
+    # per-shard framebuffers added on the host: the single-context image again
+    np.testing.assert_array_equal(run("--gpus", "3", "path", "-s", "emitter"), flat.render(seeds(), api.path_params(spp=3, strategy=api.STRATEGY_EMITTER))[0])
     sd.medium = scenes.Medium((0.1, 0.1, 0.1), (0.3, 0.3, 0.3), scenes.PHASE_HG, 0.5)
     fog = api.Context(api.Scene(sd), 0)
     np.testing.assert_array_equal(run("-m", "0.3:0.1:0.5", "path", "-m", "6"), fog.render(seeds(), api.path_params(spp=3, max_depth=6))[0])
