@@ -41,9 +41,12 @@ def main():
     from rustlight_amd import api, scenes
     from rustlight_amd import distributed as rd
 
-    rank, world, local_rank = rd.init_from_env(args.gpus)
+    # RL_BENCH_SHARE_DEVICE=1 RL_BENCH_BACKEND=gloo: dev-only way to run the N > 1 code path on a 1-GPU box (all ranks on device 0)
+    rank, world, local_rank = rd.init_from_env(args.gpus, os.environ.get("RL_BENCH_BACKEND"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback path exists)")
+    if os.environ.get("RL_BENCH_SHARE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
