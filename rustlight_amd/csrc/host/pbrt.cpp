@@ -11,6 +11,7 @@
 //   * lights  = LightSource point / distant / infinite (rgb L or mapname)
 // `Include` is followed; other directives return RL_ERR_UNSUPPORTED.
 #include <cctype>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -251,6 +252,7 @@ int load_pbrt(const char* path, bool use_shading_normals, rl_scene** out, std::s
     std::map<std::string, std::vector<RawShape>> objects;      // ObjectBegin "name" ... ObjectEnd
     std::vector<std::pair<std::string, Mat4>> instances;       // ObjectInstance "name" with the CTM in force
     std::string cur_object; bool in_object = false;
+    std::map<std::string, Mat4> coord_systems;                 // CoordinateSystem "name" / CoordSysTransform "name"
     g_textures = &textures;
     rl_scene* scene = new rl_scene();
     uint32_t width = 512, height = 512;
@@ -277,6 +279,28 @@ int load_pbrt(const char* path, bool use_shading_normals, rl_scene** out, std::s
             double v[3];
             for (int i = 0; i < 3; i++) { Token n = lx.next(); if (n.kind != Token::Num) return fail(RL_ERR_PARSE, d + ": need 3 numbers"); v[i] = n.num; }
             gs.ctm = gs.ctm.times(d == "Translate" ? Mat4::translate((float)v[0], (float)v[1], (float)v[2]) : Mat4::scale((float)v[0], (float)v[1], (float)v[2]));
+        } else if (d == "Rotate") {                  // Rotate angle x y z (degrees about an axis through the origin)
+            double v[4];
+            for (int i = 0; i < 4; i++) { Token n = lx.next(); if (n.kind != Token::Num) return fail(RL_ERR_PARSE, "Rotate: need 4 numbers"); v[i] = n.num; }
+            const Vec3 a = vnormalize({(float)v[1], (float)v[2], (float)v[3]});
+            const float ang = (float)v[0] * 3.14159265358979323846f / 180.0f, sn = std::sin(ang), cs = std::cos(ang);
+            Mat4 r = Mat4::identity();
+            r.m[0][0] = a.x * a.x + (1.0f - a.x * a.x) * cs; r.m[1][0] = a.x * a.y * (1.0f - cs) - a.z * sn;   r.m[2][0] = a.x * a.z * (1.0f - cs) + a.y * sn;
+            r.m[0][1] = a.x * a.y * (1.0f - cs) + a.z * sn;   r.m[1][1] = a.y * a.y + (1.0f - a.y * a.y) * cs; r.m[2][1] = a.y * a.z * (1.0f - cs) - a.x * sn;
+            r.m[0][2] = a.x * a.z * (1.0f - cs) - a.y * sn;   r.m[1][2] = a.y * a.z * (1.0f - cs) + a.x * sn;   r.m[2][2] = a.z * a.z + (1.0f - a.z * a.z) * cs;
+            gs.ctm = gs.ctm.times(r);
+        } else if (d == "CoordinateSystem") {
+            Token name = lx.next();
+            coord_systems[name.text] = gs.ctm;
+        } else if (d == "CoordSysTransform") {
+            Token name = lx.next();
+            auto it = coord_systems.find(name.text);
+            if (it != coord_systems.end()) gs.ctm = it->second;
+        } else if (d == "MediumInterface") {         // participating media come from the CLI's -m, not from the scene file
+            while (lx.peek().kind == Token::Str) lx.next();
+        } else if (d == "MakeNamedMedium") {
+            lx.next();
+            if (!read_params(lx, &ps)) return fail(RL_ERR_PARSE, "MakeNamedMedium: bad parameters");
         } else if (d == "LookAt") {
             double v[9];
             for (int i = 0; i < 9; i++) { Token n = lx.next(); if (n.kind != Token::Num) return fail(RL_ERR_PARSE, "LookAt: need 9 numbers"); v[i] = n.num; }

@@ -113,6 +113,26 @@ def test_pbrt_plymesh_include_instances_and_textures(built, tmp_path):
         api.Scene.load(str(tmp_path / "scene.json"))
 
 
+def test_pbrt_transform_directives(built, tmp_path):
+    """Rotate / Scale / Translate / CoordinateSystem / CoordSysTransform compose like pbrt's CTM (each one is post-multiplied)."""
+    body = ['Film "image" "integer xresolution" [ 16 ] "integer yresolution" [ 16 ]', "LookAt 0 0 5  0 0 0  0 1 0", 'Camera "perspective" "float fov" [ 40 ]',
+            "WorldBegin", 'CoordinateSystem "world0"', "Translate 1 0 0", "Rotate 90 0 0 1", "Scale 2 1 1",
+            'Shape "trianglemesh" "integer indices" [ 0 1 2 ] "point P" [ 0 0 0  1 0 0  0 1 0 ]',
+            'CoordSysTransform "world0"', 'MediumInterface "" ""',
+            'Shape "trianglemesh" "integer indices" [ 0 1 2 ] "point P" [ 0 0 0  1 0 0  0 1 0 ]', "WorldEnd"]
+    p = str(tmp_path / "xf.pbrt")
+    open(p, "w").write("\n".join(body) + "\n")
+    sc = api.Scene.load(p)
+    assert sc.counts()["triangles"] == 2
+    boxes = sc.debug_bvh()[0]
+    # first triangle: scale x by 2, rotate 90 deg about z (x -> y), then shift by +1 in x: spans x in [0, 1], y in [0, 2]
+    np.testing.assert_allclose(boxes[0][:3], [0, 0, -1e-4], atol=2e-4)
+    np.testing.assert_allclose(boxes[0][3:], [1, 2, 1e-4], atol=2e-4)
+    o, d = sc.camera_ray(8.0, 8.0)
+    np.testing.assert_allclose(o, [0, 0, 5], atol=1e-5)
+    np.testing.assert_allclose(d, [0, 0, -1], atol=1e-5)
+
+
 def test_serialized_versions_and_obj_polygons(built, tmp_path):
     sd = _mts_cbox(32, 32)
     for version, dbl in ((3, False), (4, True)):
