@@ -127,11 +127,18 @@ def main():
             traffic = pmc["kernels"].get(dominant, {}).get("hbm_bytes")
         except Exception:
             pass
+        pmc_summary = None          # SQ / TCC counters of the same workload, collected by scratch/pmc_fused.sh in its own rocprofv3 --pmc passes
+        try:
+            ps = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_fused_summary.json")))
+            if ps.get("kernel") == dominant and args.scene == "cbox":
+                pmc_summary = {k: ps[k] for k in ("valu_issue_busy", "lane_utilisation", "l2_hit_rate", "waves")}
+        except Exception:
+            pass
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": kernels[dominant]["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
                     "frac": kernels[dominant]["frac"], "traffic": traffic, "avg_launch_ms": kernels[dominant]["avg_launch_ms"],
                     "launches": kernels[dominant]["launches"], "kernels": kernels,
                     "pipeline_algorithmic_GBps": pipe_bytes / dt / 1e9, "pipeline_frac": pipe_bytes / dt / 1e9 / 8000.0,
-                    "rays_per_s": (agg_all["extension_rays"] + agg_all["shadow_rays"]) / dt}
+                    "rays_per_s": (agg_all["extension_rays"] + agg_all["shadow_rays"]) / dt, "pmc": pmc_summary}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             from oracle import orc
