@@ -110,7 +110,7 @@ def lib():
 
 def _check(rc):
     if rc < 0:
-        msg = (lib().rl_last_error() or b"").decode()
+        msg = (lib().rl_last_error() or b"").decode("utf-8", "replace")
         raise (NoDeviceError if rc == RL_ERR_NO_DEVICE else RustlightError)(rc, msg)
     return rc
 

@@ -3,6 +3,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "../kernels/wavefront.h"
@@ -18,7 +20,7 @@ int read_pfm(const char* path, uint32_t* w, uint32_t* h, std::vector<float>* rgb
     unsigned ww = 0, hh = 0; float enc = 0.0f;
     bool ok = std::fgets(line, sizeof(line), f) && std::strcmp(line, "PF\n") == 0
            && std::fgets(line, sizeof(line), f) && std::sscanf(line, "%u %u", &ww, &hh) == 2
-           && std::fgets(line, sizeof(line), f) && std::sscanf(line, "%f", &enc) == 1 && enc == -1.0f && ww && hh;
+           && std::fgets(line, sizeof(line), f) && std::sscanf(line, "%f", &enc) == 1 && enc == -1.0f && ww && hh && (uint64_t)ww * hh <= (1ull << 28);
     if (!ok) { std::fclose(f); return RL_ERR_PARSE; }
     rgb->assign((size_t)3 * ww * hh, 0.0f);
     std::vector<float> row(3 * (size_t)ww);
@@ -40,7 +42,9 @@ extern "C" {
 int rl_load_pfm(const char* path, uint32_t* width, uint32_t* height, float* rgb, size_t capacity_floats) {
     if (!path || !width || !height) return RL_ERR_INVALID_ARGUMENT;
     std::vector<float> data;
-    int rc = rl::read_pfm(path, width, height, &data);
+    int rc;
+    try { rc = rl::read_pfm(path, width, height, &data); }
+    catch (const std::exception&) { rc = RL_ERR_PARSE; }
     if (rc != RL_OK) return rc;
     if (rgb) {   // rgb == NULL: size query
         if (capacity_floats < data.size()) return RL_ERR_INVALID_ARGUMENT;
@@ -54,7 +58,9 @@ int rl_load_image(const char* path, uint32_t* width, uint32_t* height, float* rg
     if (!path || !width || !height) return RL_ERR_INVALID_ARGUMENT;
     rl::HostBitmap img;
     std::string err;
-    int rc = rl::read_image(path, &img, &err);
+    int rc;
+    try { rc = rl::read_image(path, &img, &err); }
+    catch (const std::exception& e) { rc = RL_ERR_PARSE; err = std::string(path) + ": malformed image (" + e.what() + ")"; }
     if (rc != RL_OK) { rl_set_error(err); return rc; }
     *width = img.w; *height = img.h;
     if (rgb) {

@@ -223,7 +223,9 @@ int read_ply(const std::string& path, LoadedMesh* out, std::string* err) {
             for (size_t k = 0; k < e.props.size() && rd.ok; k++) {
                 const PlyProp& p = e.props[k];
                 if (!p.is_list) { vals[k] = rd.read(p.type, e.sgn[k]); continue; }
-                size_t n = (size_t)rd.read(p.count_type, false);
+                const double cnt = rd.read(p.count_type, false);
+                if (!(cnt >= 0.0 && cnt <= 65536.0)) { *err = path + ": PLY list length out of range"; return RL_ERR_PARSE; }
+                size_t n = (size_t)cnt;
                 std::vector<uint32_t> poly(n);
                 for (size_t j = 0; j < n && rd.ok; j++) poly[j] = (uint32_t)rd.read(p.type, e.sgn[k]);
                 if (is_face && (p.name == "vertex_indices" || p.name == "vertex_index"))
@@ -287,6 +289,7 @@ int read_serialized(const std::string& path, int shape_index, LoadedMesh* out, s
     if (version == 4) { while (p < raw.size() && raw[p]) out->name.push_back((char)raw[p++]); p++; }
     if (!need(16)) { *err = path + ": truncated mesh"; return RL_ERR_PARSE; }
     unsigned long long nv, nt; std::memcpy(&nv, &raw[p], 8); std::memcpy(&nt, &raw[p + 8], 8); p += 16;
+    if (nv > (1ull << 31) || nt > (1ull << 31)) { *err = path + ": implausible mesh size"; return RL_ERR_PARSE; }
     const bool dbl = (flags & 0x2000u) != 0;
     const size_t fs = dbl ? 8 : 4;
     auto read_floats = [&](size_t count, std::vector<float>* dst) {
@@ -330,7 +333,7 @@ int read_png(const std::string& path, HostBitmap* out, std::string* err) {
         p += 12 + len;
     }
     const int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-    if (!w || !h || !channels || interlace || (depth != 8 && depth != 16) || (ctype == 3 && depth != 8)) { *err = path + ": unsupported PNG variant (8/16-bit non-interlaced only)"; return RL_ERR_UNSUPPORTED; }
+    if (!w || !h || (uint64_t)w * h > (1ull << 28) || !channels || interlace || (depth != 8 && depth != 16) || (ctype == 3 && depth != 8)) { *err = path + ": unsupported PNG variant (8/16-bit non-interlaced only)"; return RL_ERR_UNSUPPORTED; }
     std::vector<unsigned char> raw;
     if (!inflate_all(idat.data(), idat.size(), &raw)) { *err = path + ": zlib stream error"; return RL_ERR_PARSE; }
     const size_t bpp = (size_t)channels * depth / 8, stride = bpp * w;

@@ -20,6 +20,7 @@
 #include <map>
 #include <memory>
 #include <sstream>
+#include <stdexcept>
 
 #include "../kernels/wavefront.h"
 #include "meshio.h"
@@ -518,7 +519,9 @@ int load_mitsuba(const char* path, bool use_shading_normals, rl_scene** out, std
 extern "C" int rl_scene_load_mitsuba(const char* path, int use_shading_normals, rl_scene** out) {
     if (!path || !out) return RL_ERR_INVALID_ARGUMENT;
     std::string err;
-    int rc = rl::load_mitsuba(path, use_shading_normals != 0, out, &err);
+    int rc;
+    try { rc = rl::load_mitsuba(path, use_shading_normals != 0, out, &err); }
+    catch (const std::exception& e) { rc = RL_ERR_PARSE; err = std::string(path) + ": malformed scene (" + e.what() + ")"; }   // nothing is thrown across the C ABI
     if (rc != RL_OK) rl_set_error(err);
     return rc;
 }

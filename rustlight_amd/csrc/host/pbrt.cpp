@@ -18,6 +18,7 @@
 #include <fstream>
 #include <map>
 #include <sstream>
+#include <stdexcept>
 
 #include "../kernels/wavefront.h"
 #include "meshio.h"
@@ -482,7 +483,9 @@ int load_pbrt(const char* path, bool use_shading_normals, rl_scene** out, std::s
 extern "C" int rl_scene_load_pbrt(const char* path, int use_shading_normals, rl_scene** out) {
     if (!path || !out) return RL_ERR_INVALID_ARGUMENT;
     std::string err;
-    int rc = rl::load_pbrt(path, use_shading_normals != 0, out, &err);
+    int rc;
+    try { rc = rl::load_pbrt(path, use_shading_normals != 0, out, &err); }
+    catch (const std::exception& e) { rc = RL_ERR_PARSE; err = std::string(path) + ": malformed scene (" + e.what() + ")"; }   // nothing is thrown across the C ABI
     if (rc != RL_OK) rl_set_error(err);
     return rc;
 }
