@@ -3,7 +3,7 @@
 cbox, 1920x1080, 128 spp, diffuse-only, per-sample stream mode, N x MI355X (pixel-tile shards +
 one RCCL framebuffer reduce).  One "step" = one full render (W*H*spp camera samples).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_extend): algorithmic bytes
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_path_fused on this workload): algorithmic bytes
 per launch / mean launch duration from HIP events on the render stream.  `cpu_baseline` times the
 CPU oracle (a C++ restatement of rustlight's path integrator — NOT rustlight itself) on a bounded
 sample of the same workload on the host cores."""

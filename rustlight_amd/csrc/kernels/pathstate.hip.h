@@ -63,7 +63,6 @@ template <bool LDS_ONLY = false>
 RL_DEV TravStackT<LDS_ONLY> make_stack(const StackConf& sc_, unsigned* lds_after_list, size_t global_thread) {
     TravStackT<LDS_ONLY> st;
     st.lds = reinterpret_cast<int2*>(lds_after_list) + threadIdx.x;
-    st.lds_stride = (int)blockDim.x;
     st.lds_levels = sc_.lds_levels;
     st.glob = sc_.overflow ? sc_.overflow + global_thread : nullptr;
     st.glob_stride = sc_.overflow_stride;

@@ -14,6 +14,7 @@
 #pragma once
 #include "../device_types.h"
 #include "devmath.hip.h"
+#include <type_traits>
 
 namespace rl {
 
@@ -105,9 +106,13 @@ struct SceneRecs {
 // with the same coalesced layout.  LDS_ONLY (BVH depth <= the LDS levels, always the case for LDS-staged scenes)
 // compiles the overflow path out, which keeps every stack access a plain ds_* instruction instead of a flat one.  Keeping only ~12 levels
 // in LDS (96 B/lane) lets 8 waves/SIMD stay resident on scenes whose BVH is 20-40 levels deep.
+struct NodeFetchLds;
+struct NodeFetchGlobal;
 template <bool LDS_ONLY>
 struct TravStackT {
-    int2* lds; int lds_stride; int lds_levels;   // lds already offset to this lane; one (code, distance bits) pair per level
+    using NodeFetch = typename std::conditional<LDS_ONLY, NodeFetchLds, NodeFetchGlobal>::type;   // LDS-only stacks go with LDS-staged scenes
+    static constexpr int lds_stride = 256;       // every traversal kernel runs 256-lane workgroups
+    int2* lds; int lds_levels;   // lds already offset to this lane; one (code, distance bits) pair per level
     int* glob; size_t glob_stride;               // glob already offset to this lane
     RL_DEV void push(int sp, int code, float dist) const {
         if (LDS_ONLY || sp < lds_levels) lds[sp * lds_stride] = make_int2(code, __float_as_int(dist));
@@ -131,6 +136,47 @@ RL_DEV int stack_pop(const Stack& st, int& sp, float t_best) {
     return RL_CHILD_NONE;
 }
 
+// One inner node: both child boxes against the ray, verdicts already folded with the current closest hit.
+// `AABB::intersect` clips the far plane with the ray's tfar and the caller then asks `d < its.t` (accel.rs:262-284); its.t never
+// exceeds tfar, so clipping with its.t instead gives `!(min(far planes, its.t) <= t_min)` = "box hit AND t_min < its.t" in one
+// compare (min is exact and its.t is never a NaN).  NodeFetchLds reads the six near and six far planes through per-ray
+// pre-swizzled LDS addresses (the sign of 1/d picks lo or hi once per ray instead of once per plane per node: 12 selects -> 6
+// address adds, and the paired left/right planes come from one ds_read2_b32); NodeFetchGlobal keeps the four 16-byte loads.
+struct NodePlanes { float lnx, lny, lnz, lfx, lfy, lfz, rnx, rny, rnz, rfx, rfy, rfz; int id1, id2; };
+
+struct NodeFetchLds {
+    const float *nx, *ny, *nz, *fx, *fy, *fz; const int* ids;
+    RL_DEV NodeFetchLds(const SceneRecs& recs, V3 inv_d) {
+        const float* b = reinterpret_cast<const float*>(recs.nodes);
+        const bool sx = inv_d.x < 0.0f, sy = inv_d.y < 0.0f, sz = inv_d.z < 0.0f;
+        nx = b + (sx ? 3 : 0); fx = b + (sx ? 0 : 3);
+        ny = b + (sy ? 4 : 1); fy = b + (sy ? 1 : 4);
+        nz = b + (sz ? 5 : 2); fz = b + (sz ? 2 : 5);
+        ids = reinterpret_cast<const int*>(b) + 12;
+    }
+    RL_DEV NodePlanes operator()(int cur) const {
+        const int k = cur * 16;
+        NodePlanes p;
+        p.lnx = nx[k]; p.rnx = nx[k + 6]; p.lny = ny[k]; p.rny = ny[k + 6]; p.lnz = nz[k]; p.rnz = nz[k + 6];
+        p.lfx = fx[k]; p.rfx = fx[k + 6]; p.lfy = fy[k]; p.rfy = fy[k + 6]; p.lfz = fz[k]; p.rfz = fz[k + 6];
+        p.id1 = ids[k]; p.id2 = ids[k + 1];
+        return p;
+    }
+};
+struct NodeFetchGlobal {
+    const float4* nodes; bool sx, sy, sz;
+    RL_DEV NodeFetchGlobal(const SceneRecs& recs, V3 inv_d) : nodes(recs.nodes), sx(inv_d.x < 0.0f), sy(inv_d.y < 0.0f), sz(inv_d.z < 0.0f) {}
+    RL_DEV NodePlanes operator()(int cur) const {
+        const float4* q = nodes + 4 * cur;
+        const float4 a = q[0], b = q[1], c = q[2], e = q[3];
+        NodePlanes p;
+        p.lnx = sx ? a.w : a.x; p.lfx = sx ? a.x : a.w; p.lny = sy ? b.x : a.y; p.lfy = sy ? a.y : b.x; p.lnz = sz ? b.y : a.z; p.lfz = sz ? a.z : b.y;
+        p.rnx = sx ? c.y : b.z; p.rfx = sx ? b.z : c.y; p.rny = sy ? c.z : b.w; p.rfy = sy ? b.w : c.z; p.rnz = sz ? c.w : c.x; p.rfz = sz ? c.x : c.w;
+        p.id1 = __float_as_int(e.x); p.id2 = __float_as_int(e.y);
+        return p;
+    }
+};
+
 template <bool ANY_HIT, class Stack>
 RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3 o, V3 d, float tnear, float tfar,
                      Hit& hit, const Stack& st) {
@@ -140,22 +186,22 @@ RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3
     if (!slab(root_lo, root_hi, o, inv_d, tnear, tfar, &dummy)) cur = RL_CHILD_NONE;   // accel.rs:293-295 / 338-340
     int sp = 0;
     bool found = false;
+    typename Stack::NodeFetch fetch(recs, inv_d);
     while (cur != RL_CHILD_NONE) {
         // ---- phase 1: inner nodes
         while (cur >= 0) {
             hit.steps++;
-            const float4* q = recs.nodes + 4 * cur;
-            float4 a = q[0], b = q[1], c = q[2], e = q[3];
-            V3 llo = mk3(a.x, a.y, a.z), lhi = mk3(a.w, b.x, b.y);
-            V3 rlo = mk3(b.z, b.w, c.x), rhi = mk3(c.y, c.z, c.w);
-            int id1 = __float_as_int(e.x), id2 = __float_as_int(e.y);
-            float d1, d2;
-            if (!slab(llo, lhi, o, inv_d, tnear, tfar, &d1)) d1 = f32_inf();
-            if (!slab(rlo, rhi, o, inv_d, tnear, tfar, &d2)) d2 = f32_inf();
-            if (d1 > d2) { float s = d1; d1 = d2; d2 = s; int si = id1; id1 = id2; id2 = si; }
-            if (d1 < hit.t) {
-                if (d2 < hit.t) { st.push(sp, id2, d2); sp++; }   // may still be pruned by a closer hit: re-checked at pop time
-                cur = id1;
+            const NodePlanes p = fetch(cur);
+            const float d1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((p.lnx - o.x) * inv_d.x, (p.lny - o.y) * inv_d.y), (p.lnz - o.z) * inv_d.z), tnear);
+            const float f1 = __builtin_fminf(__builtin_fminf(__builtin_fminf((p.lfx - o.x) * inv_d.x, (p.lfy - o.y) * inv_d.y), (p.lfz - o.z) * inv_d.z), hit.t);
+            const float d2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((p.rnx - o.x) * inv_d.x, (p.rny - o.y) * inv_d.y), (p.rnz - o.z) * inv_d.z), tnear);
+            const float f2 = __builtin_fminf(__builtin_fminf(__builtin_fminf((p.rfx - o.x) * inv_d.x, (p.rfy - o.y) * inv_d.y), (p.rfz - o.z) * inv_d.z), hit.t);
+            const bool v1 = !(f1 <= d1), v2 = !(f2 <= d2);                 // box hit and entry distance < its.t
+            // the reference orders by distance with a missed box at +inf and keeps the left child first on ties
+            const bool right_first = v2 && (!v1 || d1 > d2);
+            if (v1 || v2) {
+                if (v1 && v2) { st.push(sp, right_first ? p.id1 : p.id2, right_first ? d1 : d2); sp++; }   // re-checked against its.t at pop time
+                cur = right_first ? p.id2 : p.id1;
             } else cur = stack_pop(st, sp, hit.t);
         }
         // ---- phase 2: a leaf (<= 2 triangles, tested in order: accel.rs:245-254) or nothing left
