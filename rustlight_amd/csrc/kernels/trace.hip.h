@@ -62,10 +62,24 @@ RL_DEV bool slab(V3 lo, V3 hi, V3 o, V3 inv_d, float tnear, float tfar, float* t
 }
 #endif
 
-// Mesh::intersection_tri; returns true and updates `hit` if the triangle is the new closest hit.
+// Mesh::intersection_tri; returns true and updates `hit` (t, prim) if the triangle is the new closest hit.
 // The reference evaluates u, v (two sqrt + two divides) before it looks at `t < its.t && t > 1e-5`
 // (geometry.rs:391-398).  All conditions are pure and must hold together, so testing the cheap
 // distance window first accepts exactly the same set of hits with the same (t, u, v) bits.
+//
+// The barycentric verdict `!(u < 0 || v < 0 || u > 1 || v > 1) && u + v <= 1` with v = |u0| / det, u = |w0| / det (both
+// correctly rounded sqrt and divide, ~90 issue slots a wave pays whenever one of its lanes gets this far) is decided from
+// s = sqrt~(|u0|^2) + sqrt~(|w0|^2) (1-ulp v_sqrt_f32) against det: the f32 value of u + v is within 4e-7 relative of
+// s / det, so s <= det (1 - 1e-5) accepts and s >= det (1 + 1e-5) rejects exactly as the reference does; only the band in
+// between (and denormal-range or non-finite inputs) takes the reference's own arithmetic.  u, v themselves are needed for
+// the final closest hit only and are recomputed there from (t, prim) by `tri_uv` with the reference's operations (same
+// inputs, same bits).
+RL_DEV void tri_uv(const float4 q0, const float4 q1, const float4 q2, const float4 q3, V3 o, V3 d, float t, float* u, float* v) {
+    V3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z);
+    V3 pv = (o + t * d) - v0;
+    *v = div_rn(length(cross(e1, pv)), q3.x);
+    *u = div_rn(length(cross(pv, e2)), q3.x);
+}
 RL_DEV bool tri_test(const float4 q0, const float4 q1, const float4 q2, const float4 q3, V3 o, V3 d, Hit& hit, int prim) {
     V3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z);
     V3 n = mk3(q0.w, q1.w, q2.w);
@@ -80,11 +94,23 @@ RL_DEV bool tri_test(const float4 q0, const float4 q1, const float4 q2, const fl
     V3 u0 = cross(e1, pv);
     V3 w0 = cross(pv, e2);
     if (dot(u0, n) < 0.0f || dot(w0, n) < 0.0f) return false;
-    float v = div_rn(length(u0), det);
-    float u = div_rn(length(w0), det);
-    if (u < 0.0f || v < 0.0f || u > 1.0f || v > 1.0f) return false;
-    if (u + v <= 1.0f) { hit.t = t; hit.u = u; hit.v = v; hit.prim = prim; return true; }
-    return false;
+    const float uu = dot(u0, u0), ww = dot(w0, w0);
+#ifdef RL_TRI_REFERENCE_FORM
+    const bool in_range = false; const float s = 0.0f;
+#else
+    const float s = __builtin_amdgcn_sqrtf(uu) + __builtin_amdgcn_sqrtf(ww);
+    const bool in_range = __builtin_fminf(__builtin_fminf(uu, ww), det) >= 0x1p-100f;   // false for NaNs too
+#endif
+    bool accept;
+    if (in_range && s <= det * 0.99999f) accept = true;
+    else if (in_range && s >= det * 1.00001f) accept = false;
+    else {
+        float v = div_rn(sqrt_rn(uu), det);
+        float u = div_rn(sqrt_rn(ww), det);
+        accept = !(u < 0.0f || v < 0.0f || u > 1.0f || v > 1.0f) && (u + v <= 1.0f);
+    }
+    if (accept) { hit.t = t; hit.prim = prim; }
+    return accept;
 }
 
 // Scene records either in LDS (staged) or in global memory.
@@ -218,6 +244,10 @@ RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3
             }
             cur = stack_pop(st, sp, hit.t);
         }
+    }
+    if (!ANY_HIT && found) {   // barycentrics of the closest hit (see tri_test)
+        const float4* q = recs.tris + 4 * hit.prim;
+        tri_uv(q[0], q[1], q[2], q[3], o, d, hit.t, &hit.u, &hit.v);
     }
     return found;
 }
