@@ -27,18 +27,7 @@ RL_DEV bool trace_closest(const DeviceScene& sc, const SceneRecs& recs, const St
     return hit.prim >= 0;
 }
 template <class Stack>
-RL_DEV bool trace_visible(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, V3 p0, V3 p1) {
-    V3 d = p1 - p0;
-    float len = length(d);
-    d = d / len;
-    float tfar = len * (1.0f - 0.00001f);
-    Hit hit; hit.t = tfar; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
-    V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
-    float te;
-    if (!slab(mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]), p0, inv_d, kEps, tfar, &te)) return false;
-    return !traverse<true>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
-                           p0, d, kEps, tfar, hit, stack);
-}
+RL_DEV bool trace_visible(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, V3 p0, V3 p1) { return shadow_visible(sc, recs, stack, p0, p1); }
 
 template <int KIND, class Stack>
 RL_DEV Col mc_compute_pixel(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, const McConst& mp, unsigned px, unsigned py, Rng& rng,

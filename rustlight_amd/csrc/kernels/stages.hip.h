@@ -133,10 +133,9 @@ RL_DEV void extend_slot(const DeviceScene& sc, const SceneRecs& recs, const Stac
     PU(U_PRIM) = (unsigned)hit.prim;
     if (dbg) { dbg[0] = hit.steps; dbg[1] = hit.tris; }
 }
-template <class PS, class Stack>
-RL_DEV void shadow_slot(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, PS& ps) {
-    // Acceleration::visible(p0, p1) (accel.rs:316-343)
-    V3 p0 = load3(ps, F_OX), p1 = load3(ps, F_SX);
+// Acceleration::visible(p0, p1) (accel.rs:316-343)
+template <class Stack>
+RL_DEV bool shadow_visible(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, V3 p0, V3 p1) {
     V3 d = p1 - p0;
     float len = length(d);
     d = d / len;
@@ -144,13 +143,14 @@ RL_DEV void shadow_slot(const DeviceScene& sc, const SceneRecs& recs, const Stac
     Hit hit; hit.t = tfar; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
     V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
     float te;
-    bool vis;
     if (!slab(mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]), p0, inv_d, kEps, tfar, &te))
-        vis = false;   // root box missed => "occluded" (accel.rs:338-340)
-    else
-        vis = !traverse<true>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
-                              p0, d, kEps, tfar, hit, stack);
-    if (vis) storec(ps, F_LR, loadc(ps, F_LR) + loadc(ps, F_CR));
+        return false;   // root box missed => "occluded" (accel.rs:338-340)
+    return !traverse<true>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
+                           p0, d, kEps, tfar, hit, stack);
+}
+template <class PS, class Stack>
+RL_DEV void shadow_slot(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, PS& ps) {
+    if (shadow_visible(sc, recs, stack, load3(ps, F_OX), load3(ps, F_SX))) storec(ps, F_LR, loadc(ps, F_LR) + loadc(ps, F_CR));
 }
 
 // shade_slot<MAT, MEDIUM> — one path vertex of one slot.  MAT >= 0: the hit material is known to have that
