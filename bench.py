@@ -129,7 +129,7 @@ def main():
             pass
         pmc_summary = None          # SQ / TCC counters of the same workload, collected by scratch/pmc_fused.sh in its own rocprofv3 --pmc passes
         try:
-            ps = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_fused_summary.json")))
+            ps = json.load(open(os.path.join(ROOT, "profiles", "r01f_pmc_fused_summary.json")))
             if ps.get("kernel") == dominant and args.scene == "cbox":
                 pmc_summary = {k: ps[k] for k in ("valu_issue_busy", "lane_utilisation", "l2_hit_rate", "waves")}
         except Exception:
