@@ -73,6 +73,58 @@ def test_trace_batch_matches_oracle(built, maker):
     np.testing.assert_array_equal(got[0][:20000], brute[0])
 
 
+def _triangle_soup(seed=5, n=600):
+    """Slivers, tiny and huge triangles at scattered positions: stresses the barycentric verdict of the triangle test (the device
+    decides it from a 1-ulp sqrt estimate outside a 1e-5 band around u + v = 1 and recomputes u, v for the final hit only)."""
+    rng = np.random.default_rng(seed)
+    V, I = [], []
+    for k in range(n):
+        scale = 10.0 ** rng.uniform(-4, 2)
+        c = rng.uniform(-3, 3, 3) * (50.0 if k % 7 == 0 else 1.0)
+        a = rng.normal(size=3); b = rng.normal(size=3)
+        a /= np.linalg.norm(a); b -= a * (a @ b); b /= np.linalg.norm(b)
+        aspect = 10.0 ** rng.uniform(-4, 0) if k % 3 == 0 else 1.0       # every third one is a sliver
+        V += [c, c + a * scale, c + (a * rng.uniform(0, 1) + b * aspect) * scale]
+        I.append([3 * k, 3 * k + 1, 3 * k + 2])
+    m = scenes.MeshData("soup", np.asarray(V, np.float32), np.asarray(I, np.uint32), None, None, scenes.matte((0.5, 0.5, 0.5)))
+    return scenes.SceneData(32, 32, 40.0, 0, np.asarray(scenes.CBOX_TO_WORLD, np.float32), False, [m])
+
+
+def test_triangle_edge_cases_match_oracle(built):
+    sd = _triangle_soup()
+    ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+    V = sd.meshes[0].vertices.astype(np.float64).reshape(-1, 3, 3)
+    rng = np.random.default_rng(11)
+    o, d = [], []
+    for tri in V:
+        v0, e1, e2 = tri[0], tri[1] - tri[0], tri[2] - tri[0]
+        nrm = np.cross(e1, e2); nrm /= max(np.linalg.norm(nrm), 1e-300)
+        size = max(np.linalg.norm(e1), np.linalg.norm(e2))
+        for _ in range(40):
+            kind = rng.integers(0, 5)
+            if kind == 0:   u = rng.uniform(0, 1); v = 1.0 - u                                  # on the hypotenuse: u + v = 1
+            elif kind == 1: u = rng.uniform(0, 1); v = (1.0 - u) * (1.0 + rng.choice([-1, 1]) * 10.0 ** rng.uniform(-8, -3))
+            elif kind == 2: u, v = rng.choice([(0, 0), (1, 0), (0, 1)])                          # a vertex
+            elif kind == 3: u = rng.uniform(0, 1); v = rng.choice([0.0, 1e-7, -1e-7])           # on / next to the edge v = 0
+            else:           u, v = rng.uniform(0, 1, 2) * 0.5                                    # inside
+            target = v0 + u * e1 + v * e2
+            side = rng.normal(size=3) + nrm * rng.choice([-2, 2])
+            side /= np.linalg.norm(side)
+            org = target + side * size * 10.0 ** rng.uniform(-1, 2)
+            o.append(org); d.append((target - org) / np.linalg.norm(target - org))
+    o, d = np.asarray(o, np.float32), np.asarray(d, np.float32)
+    d = (d / np.linalg.norm(d.astype(np.float64), axis=1, keepdims=True)).astype(np.float32)
+    got, ref = ctx.trace(o, d), osc.trace(o, d)
+    for g, r, name in zip(got, ref, ["t", "u", "v", "mesh", "tri"]):
+        np.testing.assert_array_equal(g, r, err_msg=name)
+    assert 0.2 < (got[3] >= 0).mean() < 0.99
+    hit = got[3] >= 0
+    near_edge = hit & (np.abs(got[1] + got[2] - 1.0) < 1e-4)
+    assert near_edge.sum() > 500                      # the band around u + v = 1 really is exercised
+    p1 = o + d * np.float32(1e3)
+    np.testing.assert_array_equal(ctx.visible(o, p1), osc.visible(o, p1))
+
+
 def test_visible_batch_matches_oracle(built, cbox64, ctx_cbox, orc_cbox64):
     o, _ = _random_rays(cbox64, 100000, 2)
     p1, _ = _random_rays(cbox64, 100000, 3)
