@@ -208,8 +208,9 @@ typedef struct rl_path_params {
     /* tuning: number of path slots resident on the device (0 = auto). Does not change results. */
     uint32_t pool_slots;
     /* 0 = auto, 1 = wavefront stage kernels (raygen / extend / shade / shadow per iteration, state in HBM),
-     * 2 = persistent fused kernel (same stages in one launch, state in registers; single-BSDF scenes).
-     * Does not change results. */
+     * 2 = persistent fused kernel (same stages in one launch, state in registers; the BSDF code is specialised when the scene has
+     * one BSDF type and switches per vertex otherwise).  Auto takes the fused kernel for per-sample streams with pool_slots = 0
+     * and the wavefront kernels otherwise.  Does not change results. */
     uint32_t pipeline;
     /* per-sample stream mode: lanes working on one pixel at a time (sample s of a pixel runs on lane s % sample_split; the
      * per-sample radiances are parked in HBM and added up in sample order afterwards, so the sum keeps the reference's

@@ -37,7 +37,10 @@ enum : unsigned {
 enum : unsigned { PREV_SENSOR = 0u, PREV_SURFACE = 1u, PREV_SURFACE_SMOOTH = 2u, PREV_VOLUME = 3u };
 
 #ifndef RL_FUSED_WAVES
-#define RL_FUSED_WAVES 4   // min waves per SIMD requested for the persistent fused kernel (<= 168 VGPRs)
+#define RL_FUSED_WAVES 4   // waves per SIMD requested for the persistent fused kernel on LDS-staged scenes (128 VGPRs; 3 / 4 / 5 / 6: 70.3 / 60.3 / 67.8 / 76.5 ms on cbox)
+#endif
+#ifndef RL_FUSED_WAVES_STREAMING
+#define RL_FUSED_WAVES_STREAMING 6   // scenes that stream their BVH are latency-bound: 85 VGPRs (508 k triangles, 32 spp, 4 / 5 / 6 / 8 waves: 127.3 / 118.4 / 114.8 / 138.5 ms)
 #endif
 static constexpr unsigned kDepthCap = 2048u;   // same cut as the oracle (NaN-throughput paths never die)
 

@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(256, RL_SORT_WAVES) k_shade_sorted(RenderConst
 __device__ unsigned long long g_stage_timers[16];
 #endif
 template <int MAT, bool MEDIUM, bool LDS_SCENE>
-__global__ void __launch_bounds__(256, RL_FUSED_WAVES) k_path_fused(RenderConst rc, DeviceScene sc, StackConf stc) {
+__global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAVES_STREAMING) k_path_fused(RenderConst rc, DeviceScene sc, StackConf stc) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneRecs recs;
     float4* after_scene = smem;
@@ -677,6 +677,7 @@ static void launch_fused_type(int type, bool medium, bool lds, dim3 grid, dim3 b
         case BSDF_PHONG: launch_fused<BSDF_PHONG>(medium, lds, grid, block, lds_bytes, st, rc, ds, stc); break;
         case BSDF_METAL: launch_fused<BSDF_METAL>(medium, lds, grid, block, lds_bytes, st, rc, ds, stc); break;
         case BSDF_GLASS: launch_fused<BSDF_GLASS>(medium, lds, grid, block, lds_bytes, st, rc, ds, stc); break;
+        case -1: launch_fused<-1>(medium, lds, grid, block, lds_bytes, st, rc, ds, stc); break;      // several BSDF types: run-time switch per vertex
         default: launch_fused<BSDF_SUBSTRATE>(medium, lds, grid, block, lds_bytes, st, rc, ds, stc); break;
     }
 }
@@ -709,10 +710,11 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         n_pixels += bw * bh;
     }
     const bool per_sample = params->stream_mode == RL_STREAM_PER_SAMPLE;
-    // pipeline: 1 = wavefront stage kernels, 2 = persistent fused kernel (single-BSDF scenes), 0 = auto
+    // pipeline: 1 = wavefront stage kernels, 2 = persistent fused kernel, 0 = auto (fused for per-sample streams: measured at
+    // 1080p x 32 spp, fused vs wavefront: 508 k-triangle / 6-BSDF scene 127 vs 202 ms, 4.9 k triangles 61 vs 153 ms, Cornell box
+    // with mixed BSDFs 23 vs 70 ms, diffuse Cornell box 15 vs 35 ms)
     if (params->pipeline > 2) return RL_ERR_INVALID_ARGUMENT;
-    if (params->pipeline == 2 && !ctx->single_bsdf) { rl_set_error("the fused pipeline needs a scene with a single BSDF type"); return RL_ERR_UNSUPPORTED; }
-    const bool fused = params->pipeline == 2 || (params->pipeline == 0 && ctx->single_bsdf && per_sample && params->pool_slots == 0);
+    const bool fused = params->pipeline == 2 || (params->pipeline == 0 && per_sample && params->pool_slots == 0);
     // sample-parallel pixels: `split` lanes per pixel, per-sample radiances parked in HBM ([spp][pixel][3] floats) and folded
     // in order.  Auto: scenes that traverse out of L2 / HBM want ~8 M paths in flight per wavefront launch (measured on the
     // 508 k-triangle living-room scene at 1080p: 1 lane/pixel 935 ms, 4 lanes 787 ms, 8 lanes 836 ms); LDS-staged scenes in the
@@ -736,14 +738,15 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     unsigned P = params->pool_slots ? params->pool_slots : std::min<unsigned>(n_items, 16u << 20);
     P = std::max(256u, (P + 255u) / 256u * 256u);
     if (fused) {
-        // One lane per work item by default.  With a participating medium path lengths vary by orders of magnitude, so there
-        // the grid is only what the chip keeps resident (RL_FUSED_WAVES x 256-lane workgroups per CU) and lanes draw further
-        // items from the dispenser as they finish — no workgroup idles behind its slowest pixel (cbox + medium, 32 spp:
-        // 185.5 -> 151.6 ms; plain cbox: 63.5 vs 63.6 ms, where the static tile order keeps rays more coherent).
+        // One lane per work item by default.  With a participating medium path lengths vary by orders of magnitude, and on scenes
+        // that stream their BVH from L2 / HBM the cost per pixel varies as much, so there the grid is only what the chip keeps
+        // resident (RL_FUSED_WAVES x 256-lane workgroups per CU) and lanes draw further items from the dispenser as they finish —
+        // no workgroup idles behind its slowest pixel (cbox + medium, 32 spp: 185.5 -> 151.6 ms; 508 k triangles: 148.6 -> 126.9 ms;
+        // LDS-staged scenes: plain cbox 63.5 vs 63.6 ms, mixed-BSDF cbox 23.3 vs 25.5 ms, so they keep the static tile order).
         int cus = 256;
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        const unsigned resident = (unsigned)cus * (unsigned)RL_FUSED_WAVES * 256u;
-        const bool dynamic_items = getenv("RL_FUSED_DYNAMIC") ? atoi(getenv("RL_FUSED_DYNAMIC")) != 0 : ctx->ds.medium.enabled != 0;
+        const unsigned resident = (unsigned)cus * (unsigned)(ctx->lds_scene ? RL_FUSED_WAVES : RL_FUSED_WAVES_STREAMING) * 256u;
+        const bool dynamic_items = getenv("RL_FUSED_DYNAMIC") ? atoi(getenv("RL_FUSED_DYNAMIC")) != 0 : (ctx->ds.medium.enabled != 0 || !ctx->lds_scene);
         P = std::max(256u, (std::min(n_items, dynamic_items ? resident : n_items) + 255u) / 256u * 256u);
     }
     int rcode;
@@ -845,7 +848,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     if (fused) {
         const size_t lds_fused = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + kFusedColdBytes;
         if (timing) hipEventRecord(ctx->events[0], st);
-        launch_fused_type(ctx->bsdf_type, medium, ctx->lds_scene, grid_all, block, lds_fused, st, rc, ds, stc);
+        launch_fused_type(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, ctx->lds_scene, grid_all, block, lds_fused, st, rc, ds, stc);
         if (timing) hipEventRecord(ctx->events[1], st);
         HIP_OK(hipStreamSynchronize(st));
         if (timing) { float t = 0.0f; HIP_OK(hipEventElapsedTime(&t, ctx->events[0], ctx->events[1])); ms_fused = t; }

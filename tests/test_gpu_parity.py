@@ -215,10 +215,14 @@ def test_medium_parity(built, pipeline):
         _assert_parity(*out)
 
 
-def test_mixed_materials_parity(built):
+@pytest.mark.parametrize("pipeline", [api.PIPELINE_WAVEFRONT, api.PIPELINE_FUSED])
+def test_mixed_materials_parity(built, pipeline):
+    """Six BSDF types in one scene: the wavefront pipeline sorts the live slots by material, the fused kernel switches per vertex."""
     sd = scenes.living_room(64, 48, n_spheres=27, tess=10)
-    out = _render_pair(sd, spp=4, max_depth=10)
+    out = _render_pair(sd, spp=4, max_depth=10, pipeline=pipeline)
     _assert_parity(*out)
+    assert (out[1]["iterations"] == 1) == (pipeline == api.PIPELINE_FUSED)
+    _assert_parity(*_render_pair(sd, spp=5, max_depth=6, pipeline=pipeline, sample_split=2))
 
 
 def test_phong_beckmann_textures_parity(built):
@@ -229,7 +233,8 @@ def test_phong_beckmann_textures_parity(built):
     sd.meshes[5].bsdf = S.Bsdf(type=S.METAL, distribution=S.MF_BECKMANN, alpha_u=0.2, alpha_v=0.2)
     sd.meshes[6].bsdf = S.Bsdf(type=S.SUBSTRATE, diffuse={"type": S.TEX_GRID, "color0": (0.9, 0.1, 0.1), "color1": (0.4, 0.4, 0.4), "line_width": 0.05, "scale": (3.0, 0.0)},
                                specular=S.const_color((0.04, 0.04, 0.04)), distribution=S.MF_NONE)
-    _assert_parity(*_render_pair(sd, spp=4, max_depth=8))
+    for pipeline in (api.PIPELINE_WAVEFRONT, api.PIPELINE_FUSED):
+        _assert_parity(*_render_pair(sd, spp=4, max_depth=8, pipeline=pipeline))
 
 
 @pytest.mark.parametrize("combo", [dict(), dict(keep_area_light=False), dict(point=False, directional=False), dict(environment=False, keep_area_light=False)])
@@ -330,6 +335,7 @@ def test_golden_feature_renders_on_gpu(built):
         spp = kw.pop("spp")
         if integ == "path":
             img = ctx.render(seeds, api.path_params(spp=spp, **kw))[0]
+            np.testing.assert_array_equal(ctx.render(seeds, api.path_params(spp=spp, pipeline=api.PIPELINE_WAVEFRONT, **kw))[0], gold[name], err_msg=name + " (wavefront)")
         elif integ == "direct":
             img = ctx.render_direct(seeds, spp=spp, **kw)[0]
         else:
