@@ -324,8 +324,10 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
     }
 }
 
+// same occupancy targets as the fused path kernel (`direct`, 1080p x 16 spp, unconstrained 191 VGPRs = 2 waves/SIMD vs 4 / 6: cbox 6.7 vs 5.2 / 5.7 ms,
+// 508 k triangles 36.1 vs 22.2 / 21.4 ms)
 template <int KIND, bool LDS_SCENE>
-__global__ void __launch_bounds__(256) k_pixel_mc(RenderConst rc, DeviceScene sc, StackConf stc, McConst mp) {
+__global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAVES_STREAMING) k_pixel_mc(RenderConst rc, DeviceScene sc, StackConf stc, McConst mp) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneRecs recs;
     float4* after_scene = smem;
