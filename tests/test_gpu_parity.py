@@ -421,6 +421,14 @@ def test_degenerate_inputs(built):
     assert out[0].mean() > 0.01
 
 
+def test_randomized_parity(built):
+    """A short run of the differential fuzzer (tests/parity_fuzz.py): random scenes, emitters, materials, media, integrator options,
+    stream modes, pipelines, lanes per pixel and pool sizes — image bits and counters must equal the oracle's in every case."""
+    from tests.parity_fuzz import run
+    n, bad = run(budget=25.0, seed=3)
+    assert bad == 0 and n >= 100, (n, bad)
+
+
 def test_furnace_invariant_on_gpu(built):
     sd = scenes.furnace(albedo=0.5, le=1.0, width=16, height=16)
     ctx = api.Context(api.Scene(sd), 0)
