@@ -66,6 +66,26 @@ def run(budget=20.0, seed=0, verbose=True):
             seed = int(rng.integers(0, 1000))
             pipe = int(rng.choice([0, 1, 2])); split = int(rng.choice([0, 0, 1, 2, 3])); pool = int(rng.choice([0, 0, 512, 4096])) if pipe != 2 else 0
             ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+            which = rng.random()
+            if which < 0.25:          # the `ao` / `direct` integrators (no medium there: src/integrators/{ao,direct}.rs ignore it)
+                seeds = api.IndependentSampler(seed, kw["seed_variant"]).block_seeds(sd.width, sd.height)
+                mk = dict(spp=kw["spp"], stream_mode=kw["stream_mode"], seed_variant=kw["seed_variant"])
+                has_emitter = any(m.emission for m in sd.meshes) or bool(sd.lights) or sd.environment is not None or getattr(sd, "environment_map", None) is not None
+                if which < 0.1 or not has_emitter:
+                    mk.update(max_distance=None if rng.random() < 0.3 else float(rng.uniform(0.1, 2.0)), normal_correction=bool(rng.integers(2)))
+                    img, st = ctx.render_ao(seeds, **mk); ref, ost = osc.render_ao(seeds=seeds, **mk)
+                    keys = ("camera_samples", "extension_rays", "rng_draws")
+                else:
+                    nb, nl = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+                    if nb + nl == 0: nl = 1
+                    mk.update(nb_bsdf_samples=nb, nb_light_samples=nl)
+                    img, st = ctx.render_direct(seeds, **mk); ref, ost = osc.render_direct(seeds=seeds, **mk)
+                    keys = ("camera_samples", "extension_rays", "shadow_rays", "rng_draws")
+                n += 1
+                if not (np.array_equal(img, ref) and all(st[k] == ost[k] for k in keys)):
+                    bad += 1
+                    print("MISMATCH (ao/direct)", n, dict(size=(sd.width, sd.height), tris=sd.n_triangles, seed=seed, **mk), "max abs diff", float(np.nanmax(np.abs(img - ref))), flush=True)
+                continue
             img, st = ctx.render(api.IndependentSampler(seed, kw["seed_variant"]).block_seeds(sd.width, sd.height), api.path_params(pipeline=pipe, sample_split=split, pool_slots=pool, **kw))
             ref, ost = osc.render(master_seed=seed, eval_order=1, **kw)
             ok = np.array_equal(img, ref) and all(st[k] == ost[k] for k in ("camera_samples", "vertices", "extension_rays", "rng_draws", "shadow_rays"))
