@@ -54,6 +54,8 @@ def run(budget=20.0, seed=0, verbose=True):
         kw["stream_mode"] = int(rng.choice([api.STREAM_PER_SAMPLE, api.STREAM_PER_SAMPLE, api.STREAM_REFERENCE_ORDER]))
         kw["seed_variant"] = int(rng.integers(0, 2))
         if kw["max_depth"] is None and kw["rr_depth"] is None: kw["rr_depth"] = 2      # keep paths finite
+        if rng.random() < 0.25:                                                        # one shard of a tile-sharded render
+            kw["shard_count"] = int(rng.integers(2, 5)); kw["shard_index"] = int(rng.integers(0, kw["shard_count"]))
         return kw
 
     t_end = time.time() + budget
@@ -69,7 +71,7 @@ def run(budget=20.0, seed=0, verbose=True):
             which = rng.random()
             if which < 0.25:          # the `ao` / `direct` integrators (no medium there: src/integrators/{ao,direct}.rs ignore it)
                 seeds = api.IndependentSampler(seed, kw["seed_variant"]).block_seeds(sd.width, sd.height)
-                mk = dict(spp=kw["spp"], stream_mode=kw["stream_mode"], seed_variant=kw["seed_variant"])
+                mk = dict(spp=kw["spp"], stream_mode=kw["stream_mode"], seed_variant=kw["seed_variant"], shard_index=kw.get("shard_index", 0), shard_count=kw.get("shard_count", 1))
                 has_emitter = any(m.emission for m in sd.meshes) or bool(sd.lights) or sd.environment is not None or getattr(sd, "environment_map", None) is not None
                 if which < 0.1 or not has_emitter:
                     mk.update(max_distance=None if rng.random() < 0.3 else float(rng.uniform(0.1, 2.0)), normal_correction=bool(rng.integers(2)))
