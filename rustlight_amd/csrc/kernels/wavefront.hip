@@ -19,7 +19,8 @@
 //              adds the pre-weighted contribution to the path's radiance
 // (k_shade_sorted when the scene mixes BSDF types: block-local stream compaction + material sort with
 // wave64 ballot + prefix popcounts, then one packed pass per BSDF).  Radiance is accumulated front-to-back (DESIGN.md §Radiance order).
-// k_path_fused runs the same four stages back to back in one persistent launch with the state in registers / LDS;
+// k_path_fused runs the same four stages back to back in one persistent launch with the state in registers / LDS — the form every
+// per-sample render takes by default (BSDF code specialised for single-BSDF scenes, a run-time switch otherwise);
 // k_pixel_mc is the `ao` / `direct` form.  This file holds the kernels and the host driver behind the C-ABI
 // (rl_context_*, rl_render_path / _ao / _direct, rl_trace_batch, rl_visible_batch); the device code it instantiates is in
 //   pathstate.hip.h  pool layout, state accessors, block-local statistics / compaction
