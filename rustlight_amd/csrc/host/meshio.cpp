@@ -12,6 +12,7 @@
 //   * images — .pfm (Bitmap::read_pfm) and 8/16-bit non-interlaced .png (value / 255, no gamma: read_ldr_image).
 #include <zlib.h>
 
+#include <algorithm>
 #include <cctype>
 #include <cmath>
 #include <cstdio>
@@ -368,6 +369,129 @@ int read_png(const std::string& path, HostBitmap* out, std::string* err) {
     }
     return RL_OK;
 }
+
+// OpenEXR (Bitmap::read_exr, structure.rs:607-640: the R, G, B channels as f32): single-part scanline files with NONE, RLE, ZIPS or
+// ZIP compression and HALF / FLOAT / UINT channels.  Tiled, multi-part, deep and PIZ / PXR24 / B44 / DWA files are refused.
+float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h >> 15) << 31, exp = (h >> 10) & 0x1f, man = h & 0x3ff;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else { int e = -1; uint32_t m = man; do { e++; m <<= 1; } while (!(m & 0x400)); bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((m & 0x3ff) << 13); }
+    } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+    else bits = sign | ((exp + 112) << 23) | (man << 13);
+    float f; std::memcpy(&f, &bits, 4); return f;
+}
+
+int read_exr(const std::string& path, HostBitmap* out, std::string* err) {
+    std::string src;
+    if (!slurp(path, &src)) { *err = "cannot open " + path; return RL_ERR_IO; }
+    const unsigned char* d = reinterpret_cast<const unsigned char*>(src.data());
+    const size_t n = src.size();
+    size_t p = 0;
+    auto bad = [&](const char* what) { *err = path + ": " + what; return RL_ERR_PARSE; };
+    auto u32 = [&](size_t o) { uint32_t v; std::memcpy(&v, d + o, 4); return v; };
+    if (n < 8 || u32(0) != 20000630u) return bad("not an OpenEXR file");
+    const uint32_t version = u32(4);
+    if ((version & 0xff) != 2 || (version & 0x1a00)) { *err = path + ": tiled / multi-part / deep OpenEXR files are not read"; return RL_ERR_UNSUPPORTED; }
+    p = 8;
+    struct Chan { std::string name; int type; };
+    std::vector<Chan> chans;
+    int compression = -1; int32_t win[4] = {0, 0, -1, -1}; bool have_win = false;
+    for (;;) {     // attributes: name\0 type\0 size value
+        if (p >= n) return bad("truncated header");
+        if (d[p] == 0) { p++; break; }
+        std::string name, type;
+        while (p < n && d[p]) name.push_back((char)d[p++]);
+        p++;
+        while (p < n && d[p]) type.push_back((char)d[p++]);
+        p++;
+        if (p + 4 > n) return bad("truncated header");
+        const uint32_t size = u32(p); p += 4;
+        if (size > n || p + size > n) return bad("truncated header");
+        if (name == "channels") {
+            size_t q = p;
+            while (q < p + size && d[q]) {
+                Chan c;
+                while (q < p + size && d[q]) c.name.push_back((char)d[q++]);
+                q++;
+                if (q + 16 > p + size) return bad("bad channel list");
+                c.type = (int)u32(q);
+                if (u32(q + 8) != 1 || u32(q + 12) != 1) { *err = path + ": subsampled OpenEXR channels are not read"; return RL_ERR_UNSUPPORTED; }
+                if (c.type < 0 || c.type > 2) return bad("bad channel type");
+                q += 16;
+                chans.push_back(c);
+            }
+        } else if (name == "compression" && size >= 1) compression = d[p];
+        else if (name == "dataWindow" && size >= 16) { std::memcpy(win, d + p, 16); have_win = true; }
+        p += size;
+    }
+    if (!have_win || chans.empty() || compression < 0) return bad("missing channels / compression / dataWindow");
+    if (compression > 3) { *err = path + ": only NONE / RLE / ZIPS / ZIP compressed OpenEXR files are read (no PIZ / PXR24 / B44 / DWA decoder)"; return RL_ERR_UNSUPPORTED; }
+    const int64_t w = (int64_t)win[2] - win[0] + 1, h = (int64_t)win[3] - win[1] + 1;
+    if (w <= 0 || h <= 0 || w * h > (1ll << 28)) return bad("bad dataWindow");
+    int idx[3] = {-1, -1, -1};
+    size_t line_bytes = 0;
+    std::vector<size_t> chan_off(chans.size());
+    for (size_t c = 0; c < chans.size(); c++) {
+        chan_off[c] = line_bytes;
+        line_bytes += (size_t)w * (chans[c].type == 1 ? 2 : 4);
+        if (chans[c].name == "R") idx[0] = (int)c; else if (chans[c].name == "G") idx[1] = (int)c; else if (chans[c].name == "B") idx[2] = (int)c;
+    }
+    if (idx[0] < 0 && idx[1] < 0 && idx[2] < 0) {      // luminance-only file: Y feeds all three
+        for (size_t c = 0; c < chans.size(); c++) if (chans[c].name == "Y") idx[0] = idx[1] = idx[2] = (int)c;
+        if (idx[0] < 0) return bad("no R / G / B channel");
+    }
+    const int lines_per_chunk = compression == 3 ? 16 : 1;
+    const size_t n_chunks = (size_t)((h + lines_per_chunk - 1) / lines_per_chunk);
+    if (p + 8 * n_chunks > n) return bad("truncated offset table");
+    out->w = (uint32_t)w; out->h = (uint32_t)h;
+    out->rgb.assign((size_t)3 * w * h, 0.0f);
+    std::vector<unsigned char> buf, tmp;
+    for (size_t k = 0; k < n_chunks; k++) {
+        uint64_t off; std::memcpy(&off, d + p + 8 * k, 8);
+        if (off + 8 > n) return bad("chunk offset out of range");
+        int32_t y0; std::memcpy(&y0, d + off, 4);
+        const uint32_t size = u32(off + 4);
+        if (off + 8 + size > n) return bad("truncated chunk");
+        const int64_t row0 = (int64_t)y0 - win[1];
+        if (row0 < 0 || row0 >= h) return bad("chunk outside the dataWindow");
+        const int64_t rows = std::min<int64_t>(lines_per_chunk, h - row0);
+        const size_t want = line_bytes * (size_t)rows;
+        const unsigned char* data = d + off + 8;
+        if (compression != 0 && size < want) {
+            tmp.clear();
+            if (compression == 1) {     // RLE: signed run lengths
+                for (size_t i = 0; i < size;) {
+                    const int c = (signed char)data[i++];
+                    if (c < 0) { const size_t m = (size_t)(-c); if (i + m > size) return bad("bad RLE run"); tmp.insert(tmp.end(), data + i, data + i + m); i += m; }
+                    else { if (i >= size) return bad("bad RLE run"); tmp.insert(tmp.end(), (size_t)c + 1, data[i++]); }
+                    if (tmp.size() > want) return bad("RLE chunk too long");
+                }
+            } else if (!inflate_all(data, size, &tmp)) return bad("zlib stream error");
+            if (tmp.size() != want) return bad("chunk has the wrong size");
+            for (size_t i = 1; i < want; i++) tmp[i] = (unsigned char)(tmp[i - 1] + tmp[i] - 128);     // predictor
+            buf.resize(want);
+            const size_t half = (want + 1) / 2;
+            for (size_t i = 0; i < want; i++) buf[i] = (i & 1) ? tmp[half + i / 2] : tmp[i / 2];     // de-interleave the two halves
+            data = buf.data();
+        } else if (size != want) return bad("chunk has the wrong size");
+        for (int64_t r = 0; r < rows; r++)
+            for (int c = 0; c < 3; c++) {
+                if (idx[c] < 0) continue;
+                const unsigned char* q = data + (size_t)r * line_bytes + chan_off[idx[c]];
+                const int type = chans[idx[c]].type;
+                for (int64_t x = 0; x < w; x++) {
+                    float v;
+                    if (type == 1) { uint16_t hv; std::memcpy(&hv, q + 2 * x, 2); v = half_to_float(hv); }
+                    else if (type == 2) std::memcpy(&v, q + 4 * x, 4);
+                    else { uint32_t uv; std::memcpy(&uv, q + 4 * x, 4); v = (float)uv; }
+                    out->rgb[(size_t)3 * ((size_t)(row0 + r) * w + x) + c] = v;
+                }
+            }
+    }
+    return RL_OK;
+}
 }  // namespace
 
 // Bitmap::read (structure.rs:670-683): by extension
@@ -381,7 +505,8 @@ int read_image(const std::string& path, HostBitmap* out, std::string* err) {
         return rc;
     }
     if (ext == "png") return read_png(path, out, err);
-    *err = path + ": only .pfm and .png images are read (no EXR / JPEG decoder in this build)";
+    if (ext == "exr") return read_exr(path, out, err);
+    *err = path + ": only .pfm, .exr and .png images are read (no JPEG / TGA decoder in this build)";
     return RL_ERR_UNSUPPORTED;
 }
 

@@ -381,9 +381,10 @@ int load_pbrt(const char* path, bool use_shading_normals, rl_scene** out, std::s
                     if (mp->strs.empty()) return fail(RL_ERR_PARSE, "LightSource infinite: mapname needs a file name");
                     if (sc.color0[0] != 1.0f || sc.color0[1] != 1.0f || sc.color0[2] != 1.0f) return fail(RL_ERR_UNSUPPORTED, "LightSource infinite: scale must be 1 with a mapname");
                     const std::string file = join_path(base_dir, mp->strs[0]);
-                    if (file.size() < 4 || file.substr(file.size() - 4) != ".pfm") return fail(RL_ERR_UNSUPPORTED, "LightSource infinite: only .pfm environment maps are read");
-                    uint32_t ew = 0, eh = 0; std::vector<float> texels;
-                    if (read_pfm(file.c_str(), &ew, &eh, &texels) != RL_OK) return fail(RL_ERR_IO, "cannot read environment map " + file);
+                    HostBitmap env; std::string ierr;                    // Bitmap::read: .pfm | .exr | LDR by extension
+                    int irc = read_image(file, &env, &ierr);
+                    if (irc != RL_OK) return fail(irc, "LightSource infinite: " + ierr);
+                    const uint32_t ew = env.w, eh = env.h; const std::vector<float>& texels = env.rgb;
                     rl_scene_set_environment_map(scene, ew, eh, texels.data());
                     continue;
                 }

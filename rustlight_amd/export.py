@@ -128,6 +128,64 @@ def write_png(img_u8: np.ndarray, path: str) -> None:
         f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
 
 
+def write_exr(img: np.ndarray, path: str, compression: str = "zip", half: bool = False, data_origin=(0, 0), extra_channel: bool = False) -> None:
+    """Single-part scanline OpenEXR (test fixture writer): R, G, B as FLOAT or HALF (plus an optional A channel the reader must
+    skip), compression none | rle | zips | zip, dataWindow starting at `data_origin`."""
+    a = np.ascontiguousarray(img, np.float32)
+    h, w, _ = a.shape
+    comp = {"none": 0, "rle": 1, "zips": 2, "zip": 3}[compression]
+    names = ["A", "B", "G", "R"] if extra_channel else ["B", "G", "R"]
+    src = {"R": 0, "G": 1, "B": 2}
+    ptype = 1 if half else 2
+
+    def attr(name, typ, val):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(val)) + val
+    chl = b"".join(n.encode() + b"\0" + struct.pack("<IBBBBii", ptype, 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
+    x0, y0 = data_origin
+    box = struct.pack("<iiii", x0, y0, x0 + w - 1, y0 + h - 1)
+    hdr = (struct.pack("<II", 20000630, 2) + attr("channels", "chlist", chl) + attr("compression", "compression", bytes([comp]))
+           + attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0")
+           + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0.0, 0.0))
+           + attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0")
+
+    def rle(b):
+        out = bytearray(); i = 0
+        while i < len(b):
+            j = i
+            while j + 1 < len(b) and b[j + 1] == b[i] and j - i < 126: j += 1
+            if j - i >= 2:
+                out += bytes([j - i, b[i]]); i = j + 1
+            else:
+                k = i
+                while k < len(b) and k - i < 127 and not (k + 2 < len(b) and b[k] == b[k + 1] == b[k + 2]): k += 1
+                out += bytes([(-(k - i)) & 0xFF]) + b[i:k]; i = k
+        return bytes(out)
+    lines = 16 if comp == 3 else 1
+    chunks = []
+    for r0 in range(0, h, lines):
+        raw = bytearray()
+        for y in range(r0, min(h, r0 + lines)):
+            for nme in names:
+                plane = a[y, :, src[nme]] if nme in src else np.ones(w, np.float32)
+                raw += (plane.astype(np.float16) if half else plane).tobytes()
+        raw = bytes(raw)
+        data = raw
+        if comp:
+            t = np.frombuffer(raw, np.uint8)
+            t = np.concatenate([t[0::2], t[1::2]])                                   # interleave: even bytes first, then odd
+            p = t.astype(np.int32)
+            p[1:] = (p[1:] - p[:-1] + 128 + 256) & 0xFF                              # predictor
+            enc = rle(bytes(p.astype(np.uint8))) if comp == 1 else zlib.compress(p.astype(np.uint8).tobytes())
+            if len(enc) < len(raw): data = enc
+        chunks.append(struct.pack("<iI", y0 + r0, len(data)) + data)
+    off = len(hdr) + 8 * len(chunks)
+    table = b""
+    for c in chunks:
+        table += struct.pack("<Q", off); off += len(c)
+    with open(path, "wb") as f:
+        f.write(hdr + table + b"".join(chunks))
+
+
 # ------------------------------------------------------------------------------------------ Mitsuba XML
 def _rgb(name, c):
     return f'<rgb name="{name}" value="{_r(c[0])}, {_r(c[1])}, {_r(c[2])}"/>'

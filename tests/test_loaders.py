@@ -188,3 +188,37 @@ def test_malformed_files_fail_with_an_error_not_a_crash(built, tmp_path):
         open(tmp_path / name, "wb").write(blob)
         with pytest.raises(api.RustlightError):
             api.load_image(str(tmp_path / name))
+
+
+def test_openexr_reader(built, tmp_path):
+    """Bitmap::read_exr (structure.rs:607-640): the R, G, B channels as f32 — scanline files, NONE / RLE / ZIPS / ZIP, HALF / FLOAT,
+    a dataWindow that does not start at the origin, an extra channel to skip; our own writer's files; PIZ is refused with an error."""
+    rng = np.random.default_rng(0)
+    img = (rng.uniform(0, 4, (37, 23, 3)) ** 3).astype(np.float32)
+    img[5:9] = 0.25                                     # long runs for the RLE / predictor paths
+    img[0, 0] = (1e-6, 65000.0, 0.0)
+    for comp in ("none", "rle", "zips", "zip"):
+        for half in (False, True):
+            for kw in (dict(), dict(data_origin=(-3, 7), extra_channel=True)):
+                p = str(tmp_path / f"t_{comp}_{int(half)}_{len(kw)}.exr")
+                export.write_exr(img, p, comp, half, **kw)
+                want = img.astype(np.float16).astype(np.float32) if half else img
+                np.testing.assert_array_equal(api.load_image(p), want, err_msg=p)
+    p = str(tmp_path / "own.exr")
+    api.save_image(p, img)
+    np.testing.assert_array_equal(api.load_image(p), img)
+    raw = bytearray(open(p, "rb").read())
+    k = raw.index(b"compression\0compression\0") + len(b"compression\0compression\0") + 4
+    raw[k] = 4                                          # PIZ
+    open(p, "wb").write(bytes(raw))
+    with pytest.raises(api.RustlightError, match="PIZ"):
+        api.load_image(p)
+    # an .exr environment map behaves like the .pfm one
+    sd = scenes.sky_scene(32, 24, keep_area_light=True)
+    pb = str(tmp_path / "sky.pbrt")
+    scenes.write_pbrt(sd, pb)
+    txt = open(pb).read()
+    env = [f for f in os.listdir(tmp_path) if f.endswith(".pfm")][0]
+    export.write_exr(api.load_image(str(tmp_path / env)), str(tmp_path / "env.exr"), "zip", False)
+    open(pb, "w").write(txt.replace(env, "env.exr"))
+    _same_scene(api.Scene.load(pb), api.Scene(sd))
