@@ -492,6 +492,265 @@ int read_exr(const std::string& path, HostBitmap* out, std::string* err) {
     }
     return RL_OK;
 }
+
+// JPEG (read_ldr_image's `image::open` for .jpg / .jpeg textures): baseline / extended sequential Huffman, 8-bit, grey or YCbCr with
+// any sampling factors, restart intervals; libjpeg's accurate integer IDCT ("islow") and triangle-filter ("fancy") chroma upsampling
+// for 2:1 factors, which is also what the reference's decoder (jpeg-decoder) does — decoders are only required to agree to +-1 level,
+// so textures read from a JPEG are the one input where bit-identity with the reference is not defined.  Progressive, arithmetic-coded,
+// lossless and 12-bit files are refused.
+struct JpegDecoder {
+    const unsigned char* d; size_t n, p = 0;
+    std::string err;
+    struct Huff { uint8_t bits[17] = {0}; uint8_t vals[256] = {0}; int mincode[17], maxcode[18], valptr[17]; bool set = false; };
+    struct Comp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0; int bw = 0, bh = 0; std::vector<uint8_t> plane; int pw = 0, ph = 0; };
+    uint16_t qt[4][64]; bool qt_set[4] = {false, false, false, false};
+    Huff dc[4], ac[4];
+    std::vector<Comp> comps;
+    int width = 0, height = 0, restart = 0;
+    uint32_t bitbuf = 0; int bitcnt = 0; bool hit_marker = false;
+
+    bool fail(const char* m) { if (err.empty()) err = m; return false; }
+    int u8() { return p < n ? d[p++] : -1; }
+    int u16() { int a = u8(), b = u8(); return (a < 0 || b < 0) ? -1 : (a << 8) | b; }
+
+    void build(Huff& h) {
+        int code = 0, k = 0;
+        for (int l = 1; l <= 16; l++) {
+            h.valptr[l] = k; h.mincode[l] = code;
+            code += h.bits[l]; k += h.bits[l];
+            h.maxcode[l] = h.bits[l] ? code - 1 : -1;
+            code <<= 1;
+        }
+        h.maxcode[17] = 0x7fffffff; h.set = true;
+    }
+    int bit() {
+        if (bitcnt == 0) {
+            int c = 0;
+            if (!hit_marker) {
+                c = u8();
+                if (c < 0) c = 0;
+                if (c == 0xff) {
+                    int c2 = u8();
+                    if (c2 != 0) { hit_marker = true; p -= 2; c = 0; }     // a marker: feed zeros until the caller handles it
+                }
+            }
+            bitbuf = (uint32_t)c; bitcnt = 8;
+        }
+        bitcnt--;
+        return (bitbuf >> bitcnt) & 1;
+    }
+    int receive(int s) { int v = 0; for (int i = 0; i < s; i++) v = (v << 1) | bit(); return v; }
+    static int extend(int v, int s) { return s && v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+    int decode(const Huff& h) {
+        int code = 0;
+        for (int l = 1; l <= 16; l++) {
+            code = (code << 1) | bit();
+            if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
+        }
+        return -1;
+    }
+    // libjpeg jidctint.c (accurate integer inverse DCT), CONST_BITS = 13, PASS1_BITS = 2
+    static void idct(const int* in, uint8_t* out, int stride) {
+        const int C0298 = 2446, C0390 = 3196, C0541 = 4433, C0765 = 6270, C0899 = 7373, C1175 = 9633, C1501 = 12299, C1847 = 15137, C1961 = 16069, C2053 = 16819, C2562 = 20995, C3072 = 25172;
+        long ws[64];
+        for (int c = 0; c < 8; c++) {
+            const int* i = in + c;
+            long z2 = i[16], z3 = i[48];
+            long z1 = (z2 + z3) * C0541;
+            long t2 = z1 + z3 * (-C1847), t3 = z1 + z2 * C0765;
+            z2 = i[0]; z3 = i[32];
+            long t0 = (z2 + z3) << 13, t1 = (z2 - z3) << 13;
+            long t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+            t0 = i[56]; t1 = i[40]; t2 = i[24]; t3 = i[8];
+            z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2; long z4 = t1 + t3, z5 = (z3 + z4) * C1175;
+            t0 *= C0298; t1 *= C2053; t2 *= C3072; t3 *= C1501;
+            z1 *= -C0899; z2 *= -C2562; z3 *= -C1961; z4 *= -C0390;
+            z3 += z5; z4 += z5;
+            t0 += z1 + z3; t1 += z2 + z4; t2 += z2 + z3; t3 += z1 + z4;
+            auto ds = [](long x) { return (x + (1L << 10)) >> 11; };
+            ws[c] = ds(t10 + t3); ws[56 + c] = ds(t10 - t3); ws[8 + c] = ds(t11 + t2); ws[48 + c] = ds(t11 - t2);
+            ws[16 + c] = ds(t12 + t1); ws[40 + c] = ds(t12 - t1); ws[24 + c] = ds(t13 + t0); ws[32 + c] = ds(t13 - t0);
+        }
+        for (int r = 0; r < 8; r++) {
+            const long* w = ws + 8 * r;
+            long z2 = w[2], z3 = w[6];
+            long z1 = (z2 + z3) * C0541;
+            long t2 = z1 + z3 * (-C1847), t3 = z1 + z2 * C0765;
+            long t0 = (w[0] + w[4]) << 13, t1 = (w[0] - w[4]) << 13;
+            long t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+            t0 = w[7]; t1 = w[5]; t2 = w[3]; t3 = w[1];
+            z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2; long z4 = t1 + t3, z5 = (z3 + z4) * C1175;
+            t0 *= C0298; t1 *= C2053; t2 *= C3072; t3 *= C1501;
+            z1 *= -C0899; z2 *= -C2562; z3 *= -C1961; z4 *= -C0390;
+            z3 += z5; z4 += z5;
+            t0 += z1 + z3; t1 += z2 + z4; t2 += z2 + z3; t3 += z1 + z4;
+            auto px = [](long x) { long v = ((x + (1L << 17)) >> 18) + 128; return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); };
+            uint8_t* o = out + (size_t)r * stride;
+            o[0] = px(t10 + t3); o[7] = px(t10 - t3); o[1] = px(t11 + t2); o[6] = px(t11 - t2);
+            o[2] = px(t12 + t1); o[5] = px(t12 - t1); o[3] = px(t13 + t0); o[4] = px(t13 - t0);
+        }
+    }
+    bool block(Comp& c, int bx, int by) {
+        static const uint8_t zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36,
+                                       29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+        int coef[64] = {0};
+        int t = decode(dc[c.td]);
+        if (t < 0 || t > 11) return fail("bad Huffman code (DC)");
+        c.pred += extend(receive(t), t);
+        coef[0] = c.pred * qt[c.tq][0];
+        for (int k = 1; k < 64;) {
+            int rs = decode(ac[c.ta]);
+            if (rs < 0) return fail("bad Huffman code (AC)");
+            int r = rs >> 4, s = rs & 15;
+            if (s == 0) { if (r == 15) { k += 16; continue; } break; }
+            k += r;
+            if (k > 63) return fail("AC run past the block");
+            coef[zz[k]] = extend(receive(s), s) * qt[c.tq][k];
+            k++;
+        }
+        idct(coef, &c.plane[(size_t)by * 8 * c.pw + (size_t)bx * 8], c.pw);
+        return true;
+    }
+    bool scan() {
+        int hmax = 1, vmax = 1;
+        for (Comp& c : comps) { hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
+        const int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
+        for (Comp& c : comps) {
+            if (!qt_set[c.tq] || !dc[c.td].set || !ac[c.ta].set) return fail("missing quantisation / Huffman table");
+            c.pw = mcux * c.h * 8; c.ph = mcuy * c.v * 8; c.plane.assign((size_t)c.pw * c.ph, 0); c.pred = 0;
+        }
+        int left = restart;
+        bitcnt = 0; hit_marker = false;
+        for (int my = 0; my < mcuy; my++)
+            for (int mx = 0; mx < mcux; mx++) {
+                if (restart && left == 0) {
+                    bitcnt = 0; hit_marker = false;
+                    if (p + 2 <= n && d[p] == 0xff && d[p + 1] >= 0xd0 && d[p + 1] <= 0xd7) p += 2; else return fail("missing restart marker");
+                    for (Comp& c : comps) c.pred = 0;
+                    left = restart;
+                }
+                for (Comp& c : comps)
+                    for (int v = 0; v < c.v; v++)
+                        for (int h = 0; h < c.h; h++)
+                            if (!block(c, mx * c.h + h, my * c.v + v)) return false;
+                left--;
+            }
+        return true;
+    }
+    // upsample one component to width x height (libjpeg: triangle filter for 2:1, replication otherwise)
+    std::vector<uint8_t> full(const Comp& c, int hmax, int vmax) const {
+        const int cw = (width * c.h + hmax - 1) / hmax, ch = (height * c.v + vmax - 1) / vmax;     // the component's own size
+        std::vector<uint8_t> out((size_t)width * height);
+        const int fx = hmax / c.h, fy = vmax / c.v;
+        auto at = [&](int x, int y) { x = x < 0 ? 0 : (x >= cw ? cw - 1 : x); y = y < 0 ? 0 : (y >= ch ? ch - 1 : y); return (int)c.plane[(size_t)y * c.pw + x]; };
+        for (int y = 0; y < height; y++)
+            for (int x = 0; x < width; x++) {
+                int v;
+                if (fx == 1 && fy == 1) v = at(x, y);
+                else if (fx == 2 && fy == 1 && hmax == 2 * c.h) {               // h2v1 fancy: (3 * near + far + 1|2) >> 2
+                    const int i = x >> 1;
+                    v = (x & 1) ? (3 * at(i, y) + at(i + 1, y) + 2) >> 2 : (3 * at(i, y) + at(i - 1, y) + 1) >> 2;
+                    if ((x & 1) == 0 && i == 0) v = at(0, y);
+                    if ((x & 1) && i == cw - 1) v = at(cw - 1, y);
+                } else if (fx == 2 && fy == 2 && hmax == 2 * c.h && vmax == 2 * c.v) {   // h2v2 fancy: 9/3/3/1 triangle
+                    const int i = x >> 1, j = y >> 1;
+                    const int jn = (y & 1) ? j + 1 : j - 1;
+                    auto col = [&](int xi) { return 3 * at(xi, j) + at(xi, jn); };
+                    const int cur = col(i);
+                    if ((x & 1) == 0) v = i == 0 ? (cur * 4 + 8) >> 4 : (cur * 3 + col(i - 1) + 8) >> 4;
+                    else v = i == cw - 1 ? (cur * 4 + 7) >> 4 : (cur * 3 + col(i + 1) + 7) >> 4;
+                } else v = at(x * c.h / hmax, y * c.v / vmax);
+                out[(size_t)y * width + x] = (uint8_t)v;
+            }
+        return out;
+    }
+    bool run(HostBitmap* out) {
+        if (u16() != 0xffd8) return fail("not a JPEG");
+        bool have_frame = false;
+        for (;;) {
+            int m = u8();
+            if (m < 0) return fail("truncated file");
+            if (m != 0xff) continue;
+            do { m = u8(); } while (m == 0xff);
+            if (m < 0) return fail("truncated file");
+            if (m == 0xd9) return fail("no image data");
+            if (m == 0x01 || (m >= 0xd0 && m <= 0xd7)) continue;
+            const int len = u16();
+            if (len < 2 || p + (size_t)len - 2 > n) return fail("bad segment length");
+            const size_t end = p + len - 2;
+            if (m == 0xdb) {
+                while (p < end) {
+                    int pq = u8(); int t = pq & 15;
+                    if (t > 3 || (pq >> 4) > 1) return fail("bad quantisation table");
+                    for (int i = 0; i < 64; i++) { int v = (pq >> 4) ? u16() : u8(); if (v < 0) return fail("truncated table"); qt[t][i] = (uint16_t)v; }
+                    qt_set[t] = true;
+                }
+            } else if (m == 0xc4) {
+                while (p < end) {
+                    int tc = u8(); int t = tc & 15;
+                    if (t > 3 || (tc >> 4) > 1) return fail("bad Huffman table");
+                    Huff& h = (tc >> 4) ? ac[t] : dc[t];
+                    int total = 0;
+                    for (int l = 1; l <= 16; l++) { int b = u8(); if (b < 0) return fail("truncated table"); h.bits[l] = (uint8_t)b; total += b; }
+                    if (total > 256 || p + total > end) return fail("bad Huffman table");
+                    for (int i = 0; i < total; i++) h.vals[i] = d[p++];
+                    build(h);
+                }
+            } else if (m == 0xc0 || m == 0xc1) {
+                if (u8() != 8) return fail("only 8-bit JPEGs are read");
+                height = u16(); width = u16();
+                int nc = u8();
+                if (width <= 0 || height <= 0 || (int64_t)width * height > (1 << 28) || (nc != 1 && nc != 3)) return fail("unsupported frame (size / component count)");
+                comps.resize(nc);
+                for (Comp& c : comps) { c.id = u8(); int hv = u8(); c.h = hv >> 4; c.v = hv & 15; c.tq = u8(); if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4 || c.tq < 0 || c.tq > 3) return fail("bad component"); }
+                if (nc == 1) { comps[0].h = comps[0].v = 1; }
+                have_frame = true;
+            } else if (m == 0xc2 || (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc)) {
+                return fail("progressive / lossless / arithmetic-coded JPEGs are not read");
+            } else if (m == 0xdd) restart = u16();
+            else if (m == 0xda) {
+                if (!have_frame) return fail("scan before frame");
+                int ns = u8();
+                if (ns != (int)comps.size()) return fail("non-interleaved scans are not read");
+                for (int i = 0; i < ns; i++) {
+                    int id = u8(), t = u8(); bool ok = false;
+                    for (Comp& c : comps) if (c.id == id) { c.td = t >> 4; c.ta = t & 15; ok = c.td < 4 && c.ta < 4; }
+                    if (!ok) return fail("bad scan header");
+                }
+                p = end;
+                if (!scan()) return false;
+                int hmax = 1, vmax = 1;
+                for (Comp& c : comps) { hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
+                out->w = (uint32_t)width; out->h = (uint32_t)height;
+                out->rgb.resize((size_t)3 * width * height);
+                std::vector<uint8_t> Y = full(comps[0], hmax, vmax), Cb, Cr;
+                if (comps.size() == 3) { Cb = full(comps[1], hmax, vmax); Cr = full(comps[2], hmax, vmax); }
+                for (size_t i = 0; i < (size_t)width * height; i++) {
+                    int r, g, b;
+                    if (comps.size() == 1) r = g = b = Y[i];
+                    else {       // JFIF YCbCr -> RGB with libjpeg's 16-bit fixed-point tables
+                        const int y = Y[i], cb = Cb[i] - 128, cr = Cr[i] - 128;
+                        r = y + ((91881 * cr + 32768) >> 16);
+                        g = y + ((-22554 * cb - 46802 * cr + 32768) >> 16);
+                        b = y + ((116130 * cb + 32768) >> 16);
+                        r = r < 0 ? 0 : r > 255 ? 255 : r; g = g < 0 ? 0 : g > 255 ? 255 : g; b = b < 0 ? 0 : b > 255 ? 255 : b;
+                    }
+                    out->rgb[3 * i] = (float)r / 255.0f; out->rgb[3 * i + 1] = (float)g / 255.0f; out->rgb[3 * i + 2] = (float)b / 255.0f;   // read_ldr_image
+                }
+                return true;
+            }
+            p = end;
+        }
+    }
+};
+
+int read_jpeg(const std::string& path, HostBitmap* out, std::string* err) {
+    std::string src;
+    if (!slurp(path, &src)) { *err = "cannot open " + path; return RL_ERR_IO; }
+    JpegDecoder dec{reinterpret_cast<const unsigned char*>(src.data()), src.size()};
+    if (!dec.run(out)) { *err = path + ": " + dec.err; return dec.err.find("not read") != std::string::npos ? RL_ERR_UNSUPPORTED : RL_ERR_PARSE; }
+    return RL_OK;
+}
 }  // namespace
 
 // Bitmap::read (structure.rs:670-683): by extension
@@ -506,7 +765,8 @@ int read_image(const std::string& path, HostBitmap* out, std::string* err) {
     }
     if (ext == "png") return read_png(path, out, err);
     if (ext == "exr") return read_exr(path, out, err);
-    *err = path + ": only .pfm, .exr and .png images are read (no JPEG / TGA decoder in this build)";
+    if (ext == "jpg" || ext == "jpeg") return read_jpeg(path, out, err);
+    *err = path + ": only .pfm, .exr, .png and baseline .jpg images are read";
     return RL_ERR_UNSUPPORTED;
 }
 

@@ -7,6 +7,8 @@ import pytest
 
 from rustlight_amd import api, export, scenes
 
+PROGRESSIVE_JPEG = False      # flips when read_jpeg learns progressive scans
+
 
 def _same_scene(loaded, direct):
     assert loaded.size == direct.size
@@ -222,3 +224,29 @@ def test_openexr_reader(built, tmp_path):
     export.write_exr(api.load_image(str(tmp_path / env)), str(tmp_path / "env.exr"), "zip", False)
     open(pb, "w").write(txt.replace(env, "env.exr"))
     _same_scene(api.Scene.load(pb), api.Scene(sd))
+
+
+def test_baseline_jpeg_reader(built, tmp_path):
+    """read_ldr_image for .jpg textures: files written by Pillow / libjpeg-turbo in the authoring container (tests/golden/jpeg_fixture.npz,
+    made by make_jpeg_fixture.py) decode to exactly the pixels Pillow gets — 4:4:4, 4:2:2 with optimised Huffman tables, 4:2:0 with
+    restart markers, greyscale; a progressive file is refused with an error (until a progressive decoder exists); value / 255 as
+    read_ldr_image does."""
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_fixture.npz"))
+    names = sorted(k[:-5] for k in fx.files if k.endswith("_file"))
+    assert len(names) == 5
+    for name in names:
+        p = str(tmp_path / (name + ".jpg"))
+        open(p, "wb").write(fx[name + "_file"].tobytes())
+        if name.startswith("progressive") and not PROGRESSIVE_JPEG:
+            with pytest.raises(api.RustlightError, match="progressive"):
+                api.load_image(p)
+            continue
+        got = api.load_image(p)
+        np.testing.assert_array_equal(got, fx[name + "_rgb"].astype(np.float32) / np.float32(255.0), err_msg=name)
+    for cut in (2, 200, 700):                       # truncated files: an error or a partial image, never a crash
+        p = str(tmp_path / f"cut{cut}.jpg")
+        open(p, "wb").write(fx["yuv420_q60_rst_file"].tobytes()[:cut])
+        try:
+            api.load_image(p)
+        except api.RustlightError:
+            pass
