@@ -493,11 +493,11 @@ int read_exr(const std::string& path, HostBitmap* out, std::string* err) {
     return RL_OK;
 }
 
-// JPEG (read_ldr_image's `image::open` for .jpg / .jpeg textures): baseline / extended sequential Huffman, 8-bit, grey or YCbCr with
+// JPEG (read_ldr_image's `image::open` for .jpg / .jpeg textures): baseline / extended sequential and progressive Huffman, 8-bit, grey or YCbCr with
 // any sampling factors, restart intervals; libjpeg's accurate integer IDCT ("islow") and triangle-filter ("fancy") chroma upsampling
 // for 2:1 factors, which is also what the reference's decoder (jpeg-decoder) does — decoders are only required to agree to +-1 level,
-// so textures read from a JPEG are the one input where bit-identity with the reference is not defined.  Progressive, arithmetic-coded,
-// lossless and 12-bit files are refused.
+// so textures read from a JPEG are the one input where bit-identity with the reference is not defined.  Arithmetic-coded, lossless,
+// hierarchical and 12-bit files are refused.
 struct JpegDecoder {
     const unsigned char* d; size_t n, p = 0;
     std::string err;
@@ -507,6 +507,8 @@ struct JpegDecoder {
     Huff dc[4], ac[4];
     std::vector<Comp> comps;
     int width = 0, height = 0, restart = 0;
+    bool progressive = false; int eobrun = 0;
+    std::vector<std::vector<int16_t>> coefs;      // progressive: [component][block * 64 + natural index], MCU-padded block grid
     uint32_t bitbuf = 0; int bitcnt = 0; bool hit_marker = false;
 
     bool fail(const char* m) { if (err.empty()) err = m; return false; }
@@ -637,6 +639,155 @@ struct JpegDecoder {
             }
         return true;
     }
+    static const uint8_t* zigzag() {
+        static const uint8_t zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36,
+                                       29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+        return zz;
+    }
+    void layout() {      // plane / coefficient storage on the MCU-padded grid
+        int hmax = 1, vmax = 1;
+        for (Comp& c : comps) { hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
+        const int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
+        coefs.resize(comps.size());
+        for (size_t i = 0; i < comps.size(); i++) {
+            Comp& c = comps[i];
+            c.pw = mcux * c.h * 8; c.ph = mcuy * c.v * 8;
+            c.plane.assign((size_t)c.pw * c.ph, 0);
+            if (progressive) coefs[i].assign((size_t)c.pw * c.ph, 0);
+        }
+    }
+    // one block of a progressive scan (ITU T.81 G.1.2; libjpeg jdphuff.c): spectral band [ss, se], successive approximation ah -> al
+    bool prog_block(Comp& c, int16_t* b, int ss, int se, int ah, int al) {
+        const uint8_t* zz = zigzag();
+        if (ss == 0) {
+            if (ah == 0) {
+                int t = decode(dc[c.td]);
+                if (t < 0 || t > 11) return fail("bad Huffman code (DC)");
+                c.pred += extend(receive(t), t);
+                b[0] = (int16_t)(c.pred * (1 << al));
+            } else if (bit()) b[0] |= (int16_t)(1 << al);
+            return true;
+        }
+        if (ah == 0) {
+            if (eobrun > 0) { eobrun--; return true; }
+            for (int k = ss; k <= se;) {
+                int rs = decode(ac[c.ta]);
+                if (rs < 0) return fail("bad Huffman code (AC)");
+                int r = rs >> 4, sz = rs & 15;
+                if (sz == 0) {
+                    if (r < 15) { eobrun = (1 << r) - 1; if (r) eobrun += receive(r); break; }
+                    k += 16; continue;
+                }
+                k += r;
+                if (k > se) return fail("AC run past the band");
+                b[zz[k]] = (int16_t)(extend(receive(sz), sz) * (1 << al));
+                k++;
+            }
+            return true;
+        }
+        const int p1 = 1 << al, m1 = -(1 << al);
+        int k = ss;
+        auto refine = [&](int16_t& cf) { if (bit() && (cf & p1) == 0) cf = (int16_t)(cf + (cf >= 0 ? p1 : m1)); };
+        if (eobrun == 0) {
+            for (; k <= se; k++) {
+                int rs = decode(ac[c.ta]);
+                if (rs < 0) return fail("bad Huffman code (AC)");
+                int r = rs >> 4, sz = rs & 15, value = 0;
+                if (sz) { if (sz != 1) return fail("bad refinement code"); value = bit() ? p1 : m1; }
+                else if (r != 15) { eobrun = 1 << r; if (r) eobrun += receive(r); break; }
+                for (; k <= se; k++) {
+                    int16_t& cf = b[zz[k]];
+                    if (cf != 0) refine(cf);
+                    else if (--r < 0) break;
+                }
+                if (sz && k <= se) b[zz[k]] = (int16_t)value;
+            }
+        }
+        if (eobrun > 0) {
+            for (; k <= se; k++) { int16_t& cf = b[zz[k]]; if (cf != 0) refine(cf); }
+            eobrun--;
+        }
+        return true;
+    }
+    bool prog_scan(const std::vector<int>& which, int ss, int se, int ah, int al) {
+        if (ss > se || se > 63 || (ss == 0 && se != 0) || (ss > 0 && which.size() != 1) || al > 13 || ah > 13) return fail("bad progressive scan parameters");
+        int hmax = 1, vmax = 1;
+        for (Comp& c : comps) { hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
+        for (int i : which) { Comp& c = comps[i]; c.pred = 0; if ((ss == 0 && ah == 0 && !dc[c.td].set) || (ss > 0 && !ac[c.ta].set)) return fail("missing Huffman table"); }
+        eobrun = 0; bitcnt = 0; hit_marker = false;
+        int left = restart;
+        auto maybe_restart = [&]() {
+            if (!restart || left > 0) return true;
+            bitcnt = 0; hit_marker = false;
+            if (p + 2 <= n && d[p] == 0xff && d[p + 1] >= 0xd0 && d[p + 1] <= 0xd7) p += 2; else return fail("missing restart marker");
+            for (int i : which) comps[i].pred = 0;
+            eobrun = 0; left = restart;
+            return true;
+        };
+        if (which.size() == 1) {       // non-interleaved: the component's own block grid
+            Comp& c = comps[which[0]];
+            const int cw = (width * c.h + hmax - 1) / hmax, ch = (height * c.v + vmax - 1) / vmax;
+            const int bw = (cw + 7) / 8, bh = (ch + 7) / 8, stride = c.pw / 8;
+            for (int by = 0; by < bh; by++)
+                for (int bx = 0; bx < bw; bx++) {
+                    if (!maybe_restart()) return false;
+                    if (!prog_block(c, &coefs[which[0]][((size_t)by * stride + bx) * 64], ss, se, ah, al)) return false;
+                    left--;
+                }
+        } else {
+            const int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
+            for (int my = 0; my < mcuy; my++)
+                for (int mx = 0; mx < mcux; mx++) {
+                    if (!maybe_restart()) return false;
+                    for (int i : which) {
+                        Comp& c = comps[i];
+                        for (int v = 0; v < c.v; v++)
+                            for (int h = 0; h < c.h; h++)
+                                if (!prog_block(c, &coefs[i][((size_t)(my * c.v + v) * (c.pw / 8) + (mx * c.h + h)) * 64], ss, se, ah, al)) return false;
+                    }
+                    left--;
+                }
+        }
+        return true;
+    }
+    bool prog_finish() {
+        const uint8_t* zz = zigzag();
+        for (size_t i = 0; i < comps.size(); i++) {
+            Comp& c = comps[i];
+            if (!qt_set[c.tq]) return fail("missing quantisation table");
+            int natq[64];
+            for (int k = 0; k < 64; k++) natq[zz[k]] = qt[c.tq][k];
+            const int bw = c.pw / 8, bh = c.ph / 8;
+            for (int by = 0; by < bh; by++)
+                for (int bx = 0; bx < bw; bx++) {
+                    const int16_t* b = &coefs[i][((size_t)by * bw + bx) * 64];
+                    int coef[64];
+                    for (int k = 0; k < 64; k++) coef[k] = b[k] * natq[k];
+                    idct(coef, &c.plane[(size_t)by * 8 * c.pw + (size_t)bx * 8], c.pw);
+                }
+        }
+        return true;
+    }
+    void emit(HostBitmap* out) {
+        int hmax = 1, vmax = 1;
+        for (Comp& c : comps) { hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
+        out->w = (uint32_t)width; out->h = (uint32_t)height;
+        out->rgb.resize((size_t)3 * width * height);
+        std::vector<uint8_t> Y = full(comps[0], hmax, vmax), Cb, Cr;
+        if (comps.size() == 3) { Cb = full(comps[1], hmax, vmax); Cr = full(comps[2], hmax, vmax); }
+        for (size_t i = 0; i < (size_t)width * height; i++) {
+            int r, g, b;
+            if (comps.size() == 1) r = g = b = Y[i];
+            else {       // JFIF YCbCr -> RGB with libjpeg's 16-bit fixed-point tables
+                const int y = Y[i], cb = Cb[i] - 128, cr = Cr[i] - 128;
+                r = y + ((91881 * cr + 32768) >> 16);
+                g = y + ((-22554 * cb - 46802 * cr + 32768) >> 16);
+                b = y + ((116130 * cb + 32768) >> 16);
+                r = r < 0 ? 0 : r > 255 ? 255 : r; g = g < 0 ? 0 : g > 255 ? 255 : g; b = b < 0 ? 0 : b > 255 ? 255 : b;
+            }
+            out->rgb[3 * i] = (float)r / 255.0f; out->rgb[3 * i + 1] = (float)g / 255.0f; out->rgb[3 * i + 2] = (float)b / 255.0f;   // read_ldr_image
+        }
+    }
     // upsample one component to width x height (libjpeg: triangle filter for 2:1, replication otherwise)
     std::vector<uint8_t> full(const Comp& c, int hmax, int vmax) const {
         const int cw = (width * c.h + hmax - 1) / hmax, ch = (height * c.v + vmax - 1) / vmax;     // the component's own size
@@ -666,15 +817,15 @@ struct JpegDecoder {
     }
     bool run(HostBitmap* out) {
         if (u16() != 0xffd8) return fail("not a JPEG");
-        bool have_frame = false;
+        bool have_frame = false, have_scan = false;
         for (;;) {
             int m = u8();
-            if (m < 0) return fail("truncated file");
+            if (m < 0) { if (progressive && have_scan) { if (!prog_finish()) return false; emit(out); return true; } return fail("truncated file"); }
             if (m != 0xff) continue;
             do { m = u8(); } while (m == 0xff);
             if (m < 0) return fail("truncated file");
-            if (m == 0xd9) return fail("no image data");
-            if (m == 0x01 || (m >= 0xd0 && m <= 0xd7)) continue;
+            if (m == 0xd9) { if (progressive && have_scan) { if (!prog_finish()) return false; emit(out); return true; } return fail("no image data"); }
+            if (m == 0x00 || m == 0x01 || (m >= 0xd0 && m <= 0xd7)) continue;
             const int len = u16();
             if (len < 2 || p + (size_t)len - 2 > n) return fail("bad segment length");
             const size_t end = p + len - 2;
@@ -696,7 +847,8 @@ struct JpegDecoder {
                     for (int i = 0; i < total; i++) h.vals[i] = d[p++];
                     build(h);
                 }
-            } else if (m == 0xc0 || m == 0xc1) {
+            } else if (m == 0xc0 || m == 0xc1 || m == 0xc2) {
+                progressive = m == 0xc2;
                 if (u8() != 8) return fail("only 8-bit JPEGs are read");
                 height = u16(); width = u16();
                 int nc = u8();
@@ -704,39 +856,31 @@ struct JpegDecoder {
                 comps.resize(nc);
                 for (Comp& c : comps) { c.id = u8(); int hv = u8(); c.h = hv >> 4; c.v = hv & 15; c.tq = u8(); if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4 || c.tq < 0 || c.tq > 3) return fail("bad component"); }
                 if (nc == 1) { comps[0].h = comps[0].v = 1; }
+                if (progressive) layout();
                 have_frame = true;
-            } else if (m == 0xc2 || (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc)) {
-                return fail("progressive / lossless / arithmetic-coded JPEGs are not read");
+            } else if (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc) {
+                return fail("lossless / hierarchical / arithmetic-coded JPEGs are not read");
             } else if (m == 0xdd) restart = u16();
             else if (m == 0xda) {
                 if (!have_frame) return fail("scan before frame");
                 int ns = u8();
-                if (ns != (int)comps.size()) return fail("non-interleaved scans are not read");
+                if (ns < 1 || ns > (int)comps.size() || (!progressive && ns != (int)comps.size())) return fail("non-interleaved baseline scans are not read");
+                std::vector<int> which;
                 for (int i = 0; i < ns; i++) {
                     int id = u8(), t = u8(); bool ok = false;
-                    for (Comp& c : comps) if (c.id == id) { c.td = t >> 4; c.ta = t & 15; ok = c.td < 4 && c.ta < 4; }
+                    for (size_t ci = 0; ci < comps.size(); ci++) if (comps[ci].id == id) { comps[ci].td = t >> 4; comps[ci].ta = t & 15; ok = comps[ci].td < 4 && comps[ci].ta < 4; which.push_back((int)ci); }
                     if (!ok) return fail("bad scan header");
+                }
+                if (progressive) {
+                    const int ss = u8(), se = u8(), a = u8();
+                    p = end;
+                    if (!prog_scan(which, ss, se, a >> 4, a & 15)) return false;
+                    have_scan = true;
+                    continue;
                 }
                 p = end;
                 if (!scan()) return false;
-                int hmax = 1, vmax = 1;
-                for (Comp& c : comps) { hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
-                out->w = (uint32_t)width; out->h = (uint32_t)height;
-                out->rgb.resize((size_t)3 * width * height);
-                std::vector<uint8_t> Y = full(comps[0], hmax, vmax), Cb, Cr;
-                if (comps.size() == 3) { Cb = full(comps[1], hmax, vmax); Cr = full(comps[2], hmax, vmax); }
-                for (size_t i = 0; i < (size_t)width * height; i++) {
-                    int r, g, b;
-                    if (comps.size() == 1) r = g = b = Y[i];
-                    else {       // JFIF YCbCr -> RGB with libjpeg's 16-bit fixed-point tables
-                        const int y = Y[i], cb = Cb[i] - 128, cr = Cr[i] - 128;
-                        r = y + ((91881 * cr + 32768) >> 16);
-                        g = y + ((-22554 * cb - 46802 * cr + 32768) >> 16);
-                        b = y + ((116130 * cb + 32768) >> 16);
-                        r = r < 0 ? 0 : r > 255 ? 255 : r; g = g < 0 ? 0 : g > 255 ? 255 : g; b = b < 0 ? 0 : b > 255 ? 255 : b;
-                    }
-                    out->rgb[3 * i] = (float)r / 255.0f; out->rgb[3 * i + 1] = (float)g / 255.0f; out->rgb[3 * i + 2] = (float)b / 255.0f;   // read_ldr_image
-                }
+                emit(out);
                 return true;
             }
             p = end;
@@ -766,7 +910,7 @@ int read_image(const std::string& path, HostBitmap* out, std::string* err) {
     if (ext == "png") return read_png(path, out, err);
     if (ext == "exr") return read_exr(path, out, err);
     if (ext == "jpg" || ext == "jpeg") return read_jpeg(path, out, err);
-    *err = path + ": only .pfm, .exr, .png and baseline .jpg images are read";
+    *err = path + ": only .pfm, .exr, .png and .jpg images are read";
     return RL_ERR_UNSUPPORTED;
 }
 

@@ -13,9 +13,9 @@ export.write_png(np.random.default_rng(0).integers(0, 256, (9, 7, 3), dtype=np.u
 img = np.random.default_rng(1).uniform(0, 3, (21, 13, 3)).astype(np.float32)
 export.write_exr(img, f'{D}/z.exr', 'zip', True); export.write_exr(img, f'{D}/r.exr', 'rle', False, extra_channel=True); export.write_exr(img, f'{D}/n.exr', 'none', False, data_origin=(2, -5))
 fx = np.load('/root/repo/tests/golden/jpeg_fixture.npz')
-for k in ('yuv420_q60_rst', 'yuv422_q75_opt', 'gray_q80'): open(f'{D}/{k}.jpg', 'wb').write(fx[k + '_file'].tobytes())
+for k in ('yuv420_q60_rst', 'yuv422_q75_opt', 'gray_q80', 'progressive_q80'): open(f'{D}/{k}.jpg', 'wb').write(fx[k + '_file'].tobytes())
 targets = [(f'{D}/obj.xml', 'scene'), (f'{D}/obj_3.obj', 'dep:obj.xml'), (f'{D}/ply_0.ply', 'dep:ply.xml'), (f'{D}/ply_1.ply', 'dep:ply.xml'),
-           (f'{D}/serialized.serialized', 'dep:serialized.xml'), (f'{D}/sky.pbrt', 'scene'), (f'{D}/sky_env.pfm', 'dep:sky.pbrt'), (f'{D}/t.png', 'image'), (f'{D}/z.exr', 'image'), (f'{D}/r.exr', 'image'), (f'{D}/n.exr', 'image'), (f'{D}/yuv420_q60_rst.jpg', 'image'), (f'{D}/yuv422_q75_opt.jpg', 'image'), (f'{D}/gray_q80.jpg', 'image')]
+           (f'{D}/serialized.serialized', 'dep:serialized.xml'), (f'{D}/sky.pbrt', 'scene'), (f'{D}/sky_env.pfm', 'dep:sky.pbrt'), (f'{D}/t.png', 'image'), (f'{D}/z.exr', 'image'), (f'{D}/r.exr', 'image'), (f'{D}/n.exr', 'image'), (f'{D}/yuv420_q60_rst.jpg', 'image'), (f'{D}/yuv422_q75_opt.jpg', 'image'), (f'{D}/gray_q80.jpg', 'image'), (f'{D}/progressive_q80.jpg', 'image')]
 code = '''
 import sys; sys.path.insert(0, "/root/repo")
 from rustlight_amd import api

@@ -7,7 +7,7 @@ import pytest
 
 from rustlight_amd import api, export, scenes
 
-PROGRESSIVE_JPEG = False      # flips when read_jpeg learns progressive scans
+PROGRESSIVE_JPEG = True
 
 
 def _same_scene(loaded, direct):
@@ -229,8 +229,7 @@ def test_openexr_reader(built, tmp_path):
 def test_baseline_jpeg_reader(built, tmp_path):
     """read_ldr_image for .jpg textures: files written by Pillow / libjpeg-turbo in the authoring container (tests/golden/jpeg_fixture.npz,
     made by make_jpeg_fixture.py) decode to exactly the pixels Pillow gets — 4:4:4, 4:2:2 with optimised Huffman tables, 4:2:0 with
-    restart markers, greyscale; a progressive file is refused with an error (until a progressive decoder exists); value / 255 as
-    read_ldr_image does."""
+    restart markers, greyscale, progressive (spectral selection + successive approximation); value / 255 as read_ldr_image does."""
     fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_fixture.npz"))
     names = sorted(k[:-5] for k in fx.files if k.endswith("_file"))
     assert len(names) == 5
