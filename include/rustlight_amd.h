@@ -305,7 +305,7 @@ int rl_visible_batch(rl_context* ctx, size_t n, const float* p0, const float* p1
  * top-down, RGB f32.  `rgb == NULL` only reports the size; otherwise `capacity_floats >= 3 * w * h`. */
 int rl_load_pfm(const char* path, uint32_t* width, uint32_t* height, float* rgb, size_t capacity_floats);
 /* Bitmap::read (src/structure.rs:670-683): by extension — .pfm, .exr (read_exr: R, G, B of a scanline file, NONE / RLE / ZIPS / ZIP,
- * HALF / FLOAT / UINT), .png (8/16-bit) or .jpg / .jpeg (baseline and progressive Huffman; value / 255 as read_ldr_image does). */
+ * HALF / FLOAT / UINT), .png (8/16-bit), .jpg / .jpeg (baseline and progressive Huffman) or .tga (value / 255 as read_ldr_image does). */
 int rl_load_image(const char* path, uint32_t* width, uint32_t* height, float* rgb, size_t capacity_floats);
 /* Bitmap::save_pfm (src/structure.rs:547-560): bottom-up rows, |value|, little-endian, "-1.0" scale. */
 int rl_save_pfm(const char* path, const float* rgb, uint32_t width, uint32_t height);

@@ -895,6 +895,56 @@ int read_jpeg(const std::string& path, HostBitmap* out, std::string* err) {
     if (!dec.run(out)) { *err = path + ": " + dec.err; return dec.err.find("not read") != std::string::npos ? RL_ERR_UNSUPPORTED : RL_ERR_PARSE; }
     return RL_OK;
 }
+
+// Truevision TGA (read_ldr_image): true-colour (24 / 32 bit) and grey (8 bit) images, raw or run-length encoded, either row order.
+int read_tga(const std::string& path, HostBitmap* out, std::string* err) {
+    std::string src;
+    if (!slurp(path, &src)) { *err = "cannot open " + path; return RL_ERR_IO; }
+    const unsigned char* d = reinterpret_cast<const unsigned char*>(src.data());
+    const size_t n = src.size();
+    if (n < 18) { *err = path + ": truncated TGA header"; return RL_ERR_PARSE; }
+    const int id_len = d[0], cmap_type = d[1], type = d[2], cmap_len = d[5] | (d[6] << 8), cmap_bits = d[7];
+    const int w = d[12] | (d[13] << 8), h = d[14] | (d[15] << 8), bpp = d[16], desc = d[17];
+    const bool rle = type == 10 || type == 11, grey = type == 3 || type == 11;
+    if (!(type == 2 || type == 3 || type == 10 || type == 11) || (grey ? bpp != 8 : (bpp != 24 && bpp != 32)) || w <= 0 || h <= 0) {
+        *err = path + ": unsupported TGA variant (true-colour 24/32-bit and 8-bit grey only)"; return RL_ERR_UNSUPPORTED;
+    }
+    size_t p = 18 + (size_t)id_len + (cmap_type ? (size_t)cmap_len * ((cmap_bits + 7) / 8) : 0);
+    const size_t px = (size_t)bpp / 8, total = (size_t)w * h;
+    std::vector<unsigned char> pix(total * px);
+    if (!rle) {
+        if (p + pix.size() > n) { *err = path + ": truncated TGA"; return RL_ERR_PARSE; }
+        std::memcpy(pix.data(), d + p, pix.size());
+    } else {
+        size_t o = 0;
+        while (o < total) {
+            if (p >= n) { *err = path + ": truncated TGA"; return RL_ERR_PARSE; }
+            const int c = d[p++], cnt = (c & 0x7f) + 1;
+            if (o + cnt > total) { *err = path + ": TGA run past the image"; return RL_ERR_PARSE; }
+            if (c & 0x80) {
+                if (p + px > n) { *err = path + ": truncated TGA"; return RL_ERR_PARSE; }
+                for (int i = 0; i < cnt; i++) std::memcpy(&pix[(o + i) * px], d + p, px);
+                p += px;
+            } else {
+                if (p + px * cnt > n) { *err = path + ": truncated TGA"; return RL_ERR_PARSE; }
+                std::memcpy(&pix[o * px], d + p, px * cnt);
+                p += px * cnt;
+            }
+            o += cnt;
+        }
+    }
+    out->w = (uint32_t)w; out->h = (uint32_t)h;
+    out->rgb.resize(total * 3);
+    const bool top_down = (desc & 0x20) != 0, right_left = (desc & 0x10) != 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const unsigned char* q = &pix[((size_t)(top_down ? y : h - 1 - y) * w + (right_left ? w - 1 - x : x)) * px];
+            const unsigned char r = grey ? q[0] : q[2], g = grey ? q[0] : q[1], b = q[0];       // stored B, G, R [, A]
+            float* o3 = &out->rgb[3 * ((size_t)y * w + x)];
+            o3[0] = (float)r / 255.0f; o3[1] = (float)g / 255.0f; o3[2] = (float)b / 255.0f;   // read_ldr_image
+        }
+    return RL_OK;
+}
 }  // namespace
 
 // Bitmap::read (structure.rs:670-683): by extension
@@ -910,7 +960,8 @@ int read_image(const std::string& path, HostBitmap* out, std::string* err) {
     if (ext == "png") return read_png(path, out, err);
     if (ext == "exr") return read_exr(path, out, err);
     if (ext == "jpg" || ext == "jpeg") return read_jpeg(path, out, err);
-    *err = path + ": only .pfm, .exr, .png and .jpg images are read";
+    if (ext == "tga") return read_tga(path, out, err);
+    *err = path + ": only .pfm, .exr, .png, .jpg and .tga images are read";
     return RL_ERR_UNSUPPORTED;
 }
 

@@ -249,3 +249,39 @@ def test_baseline_jpeg_reader(built, tmp_path):
             api.load_image(p)
         except api.RustlightError:
             pass
+
+
+def test_tga_reader(built, tmp_path):
+    """read_ldr_image for .tga: raw / run-length encoded, 24 / 32-bit true colour and 8-bit grey, bottom-up (default) and top-down."""
+    import struct
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (9, 7, 3), dtype=np.uint8)
+    img[3:6] = img[3, 0]                                  # runs
+
+    def tga(pixels_bgr, typ, bpp, top_down, rle):
+        h, w = pixels_bgr.shape[:2]
+        rows = pixels_bgr if top_down else pixels_bgr[::-1]
+        flat = rows.reshape(h * w, -1)
+        if rle:
+            body = bytearray(); i = 0
+            while i < len(flat):
+                j = i
+                while j + 1 < len(flat) and j - i < 127 and (flat[j + 1] == flat[i]).all(): j += 1
+                if j > i: body += bytes([0x80 | (j - i)]) + flat[i].tobytes(); i = j + 1
+                else: body += bytes([0]) + flat[i].tobytes(); i += 1
+        else:
+            body = flat.tobytes()
+        return struct.pack("<BBBHHBHHHHBB", 0, 0, typ, 0, 0, 0, 0, 0, w, h, bpp, 0x20 if top_down else 0) + bytes(body)
+    want = img.astype(np.float32) / np.float32(255.0)
+    bgr = img[:, :, ::-1]
+    bgra = np.concatenate([bgr, np.full((9, 7, 1), 200, np.uint8)], -1)
+    grey = img[:, :, :1]
+    for k, (px, typ, bpp, exp) in enumerate(((bgr, 2, 24, want), (bgra, 2, 32, want), (grey, 3, 8, np.repeat(want[:, :, :1], 3, -1)))):
+        for top_down in (False, True):
+            for rle in (False, True):
+                p = str(tmp_path / f"t{k}_{int(top_down)}_{int(rle)}.tga")
+                open(p, "wb").write(tga(px, typ + (8 if rle else 0), bpp, top_down, rle))
+                np.testing.assert_array_equal(api.load_image(p), exp, err_msg=p)
+    open(str(tmp_path / "bad.tga"), "wb").write(tga(bgr, 2, 24, False, False)[:40])
+    with pytest.raises(api.RustlightError):
+        api.load_image(str(tmp_path / "bad.tga"))
