@@ -561,7 +561,7 @@ struct JpegDecoder {
             long z1 = (z2 + z3) * C0541;
             long t2 = z1 + z3 * (-C1847), t3 = z1 + z2 * C0765;
             z2 = i[0]; z3 = i[32];
-            long t0 = (z2 + z3) << 13, t1 = (z2 - z3) << 13;
+            long t0 = (z2 + z3) * 8192, t1 = (z2 - z3) * 8192;
             long t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
             t0 = i[56]; t1 = i[40]; t2 = i[24]; t3 = i[8];
             z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2; long z4 = t1 + t3, z5 = (z3 + z4) * C1175;
@@ -578,7 +578,7 @@ struct JpegDecoder {
             long z2 = w[2], z3 = w[6];
             long z1 = (z2 + z3) * C0541;
             long t2 = z1 + z3 * (-C1847), t3 = z1 + z2 * C0765;
-            long t0 = (w[0] + w[4]) << 13, t1 = (w[0] - w[4]) << 13;
+            long t0 = (w[0] + w[4]) * 8192, t1 = (w[0] - w[4]) * 8192;
             long t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
             t0 = w[7]; t1 = w[5]; t2 = w[3]; t3 = w[1];
             z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2; long z4 = t1 + t3, z5 = (z3 + z4) * C1175;
