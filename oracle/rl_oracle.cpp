@@ -270,7 +270,7 @@ struct Distribution1D {
     size_t sample_discrete(float v) const {
         size_t lo = 0, hi = cdf.size();
         while (lo < hi) { size_t mid = lo + (hi - lo) / 2; if (cdf[mid] <= v) lo = mid + 1; else hi = mid; }
-        return lo - 1;
+        return lo ? lo - 1 : 0;      // (a NaN table makes the reference panic; stay in bounds)
     }
     float pdf(size_t i) const { return cdf[i + 1] - cdf[i]; }
     float total() const { return func_int * (float)(cdf.size() - 1); }

@@ -4,6 +4,7 @@
 #include "../detmath_shared.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 namespace rl {
@@ -245,6 +246,13 @@ int rl_scene_build_emitters(rl_scene* scene) {
         scene->emitters.push_back(e);
         // Mesh::flux = cdf.total() * e * PI (emitter.rs:591-599)
         float total = m.area_total();
+        // a NaN / infinite total leaves NaNs in the normalised area cdf (a zero total does not: Distribution1DConstruct::normalize skips
+        // the division, math.rs:417-441): the reference panics on them in sample_discrete (`partial_cmp(..).unwrap()`, math.rs:447-457)
+        // — here the scene is refused instead of rendered with garbage indices
+        if (!std::isfinite(total)) {
+            rl_set_error("emissive mesh " + std::to_string(i) + " has no finite area (NaN / infinite vertices)");
+            return RL_ERR_INVALID_ARGUMENT;
+        }
         float ch[3];
         for (int k = 0; k < 3; k++) ch[k] = (m.emission[k] * total) * kPi;
         flux.push_back(channel_max(ch));
@@ -297,6 +305,12 @@ int rl_scene_build_emitters(rl_scene* scene) {
     for (const EmitterRecord& o : scene->other_emitters) finish(o);
     scene->emitters_cdf.clear();
     if (!flux.empty()) {
+        float sum = 0.0f;
+        for (float f : flux) sum += f;
+        if (!std::isfinite(sum)) {      // same reason: the emitter-selection cdf would hold NaNs
+            rl_set_error("the emitters' total flux is not finite (NaN / infinite emission, or non-finite vertices inflating the scene's bounding sphere)");
+            return RL_ERR_INVALID_ARGUMENT;
+        }
         float fi;
         build_cdf(flux, &scene->emitters_cdf, &fi);
     }

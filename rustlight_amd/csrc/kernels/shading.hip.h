@@ -387,7 +387,7 @@ RL_DEV bool bsdf_sample(const DeviceScene& sc, const Material& mat, bool huv, V2
 RL_DEV unsigned int cdf_sample(const float* cdf, unsigned int n_entries, float v) {
     unsigned int lo = 0, hi = n_entries;
     while (lo < hi) { unsigned int mid = lo + (hi - lo) / 2; if (cdf[mid] <= v) lo = mid + 1; else hi = mid; }
-    return lo - 1;
+    return lo ? lo - 1 : 0u;     // cdf[0] = 0 <= v for every valid table; a NaN table (the reference panics there) must not index out of bounds
 }
 
 struct LightSample { float pdf; int pdf_kind; V3 p, n, d; Col weight; int kind; };

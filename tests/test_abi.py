@@ -172,3 +172,32 @@ def test_save_png_and_exr(built, tmp_path):
         np.testing.assert_array_equal(planes[::-1].T, img[y])
     with pytest.raises(api.RustlightError):
         api.save_image(str(tmp_path / "a.jpg"), img)
+
+
+def test_emitters_with_non_finite_area_or_flux_are_refused(built):
+    """An emissive mesh whose area is NaN / infinite (or emitters whose total flux is) would leave NaNs in the sampling cdfs — the
+    reference panics on those in `sample_discrete`; the drop-in refuses the scene when the emitters are built.  A zero area is fine
+    (Distribution1DConstruct::normalize skips the division)."""
+    for spoil in ("nan", "inf", "huge"):
+        sd = scenes.cbox(16, 16)
+        light = [m for m in sd.meshes if m.emission][0]
+        v = light.vertices.copy()
+        if spoil == "nan": v[1, 0] = np.nan
+        elif spoil == "inf": v[2, 1] = np.inf
+        else: v *= np.float32(1e30)
+        light.vertices = v
+        with pytest.raises(api.RustlightError, match="no finite area"):
+            api.Scene(sd)
+    sd = scenes.cbox(16, 16)
+    light = [m for m in sd.meshes if m.emission][0]
+    light.vertices = np.repeat(light.vertices[:1], len(light.vertices), 0)        # zero-area light: accepted
+    api.Scene(sd)
+    sd = scenes.cbox(16, 16)                        # NaN in a non-emissive mesh is tolerated (those triangles are never hit) ...
+    sd.meshes[0].vertices = sd.meshes[0].vertices.copy(); sd.meshes[0].vertices[0, 0] = np.nan
+    api.Scene(sd)
+    sd.environment = (0.5, 0.5, 0.5)                 # ... also next to an environment light: box unions skip NaNs, the bounding sphere stays finite
+    api.Scene(sd)
+    sd = scenes.cbox(16, 16)
+    [m for m in sd.meshes if m.emission][0].emission = (float("inf"), 1.0, 1.0)
+    with pytest.raises(api.RustlightError, match="total flux is not finite"):
+        api.Scene(sd)
