@@ -187,26 +187,28 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
     if (!MEDIUM && !hit) {
         // edge without a next vertex: Edge::contribution = weight * rr * scene.enviroment_luminance(d) (edge.rs:201-210)
         ended = true;
-        if (sc.env_emitter >= 0) {
-            Col contrib = (w_edge * rr) * env_eval(sc, rd);
-            const bool add_contrib = rc.has_min ? (depth - 1u) >= rc.min_depth : true;
-            if (prev == PREV_SENSOR) {
-                if (!is_zero(contrib) && add_contrib) L = L + contrib;
-            } else if (!zeroed) {
-                if (rc.strategy == RL_STRATEGY_EMITTER) contrib = czero();
-                if (!is_zero(contrib) && add_contrib) {
-                    float wmis = 1.0f;
-                    if (rc.strategy == RL_STRATEGY_ALL && (flags & ST_PDF_SA)) {
-                        // pdf_emitter, `None` next vertex: direct_pdf of the environment (emitters.rs:18-46)
-                        float p2 = (prev == PREV_SURFACE || prev == PREV_VOLUME) ? env_direct_pdf(sc, rd) : 0.0f;
-                        float total = (0.0f + pdf_edge) + p2;
-                        wmis = div_rn(pdf_edge, total);
-                    }
-                    L = L + beta * (contrib * wmis);
+        // A zero term is still added as beta * 0: with a NaN / infinite throughput (hostile textures) the reference's recursion turns the
+        // whole sample into NaN through `weight * evaluate(next)`, and the forward form keeps that by not skipping the product.
+        Col contrib = (w_edge * rr) * (sc.env_emitter >= 0 ? env_eval(sc, rd) : czero());      // enviroment_luminance is black without an environment
+        const bool add_contrib = rc.has_min ? (depth - 1u) >= rc.min_depth : true;
+        if (prev == PREV_SENSOR) {
+            if (!is_zero(contrib) && add_contrib) L = L + contrib;
+        } else if (!zeroed) {
+            if (rc.strategy == RL_STRATEGY_EMITTER) contrib = czero();
+            Col term = czero();
+            if (!is_zero(contrib) && add_contrib) {
+                float wmis = 1.0f;
+                if (rc.strategy == RL_STRATEGY_ALL && (flags & ST_PDF_SA)) {
+                    // pdf_emitter, `None` next vertex: direct_pdf of the environment (emitters.rs:18-46)
+                    float p2 = (prev == PREV_SURFACE || prev == PREV_VOLUME) ? env_direct_pdf(sc, rd) : 0.0f;
+                    float total = (0.0f + pdf_edge) + p2;
+                    wmis = div_rn(pdf_edge, total);
                 }
+                term = contrib * wmis;
             }
-            storec(ps, F_LR, L);
+            L = L + beta * term;
         }
+        storec(ps, F_LR, L);
     }
     if (!ended) {
         const Col W = w_edge * rr;                // edge.weight * edge.rr_weight (Color * f32, guarded)
@@ -228,6 +230,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
             if (!is_zero(contrib) && add_contrib) L = L + contrib;              // path.rs:152-166 (no MIS)
         } else if (!zeroed) {
             if (rc.strategy == RL_STRATEGY_EMITTER) contrib = czero();          // id_sampling 0 != 1
+            Col term = czero();
             if (!is_zero(contrib) && add_contrib) {
                 float wmis = 1.0f;
                 if (rc.strategy == RL_STRATEGY_ALL && (flags & ST_PDF_SA)) {
@@ -238,8 +241,9 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
                     float total = (0.0f + pdf_edge) + p2;
                     wmis = div_rn(pdf_edge, total);                             // balance heuristic (path.rs:80-98)
                 }
-                L = L + beta * (contrib * wmis);
+                term = contrib * wmis;
             }
+            L = L + beta * term;                                                // a zero term too: see the miss branch
         }
         beta = beta * W;
         if (rc.single_scattering && !is_volume) zeroed = true;                  // evaluate(): surface vertex => subtree is 0
@@ -319,14 +323,19 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
                     }
                     Col c_l = ls.weight * wl * 1.0f;                       // contrib * weight * rr_weight (edge.rs:204)
                     const bool add_l = rc.has_min ? (gen - 1u) >= rc.min_depth : true;
-                    if (!zeroed && !is_zero(c_l) && add_l) {
-                        float wmis = 1.0f;
-                        if (rc.strategy == RL_STRATEGY_ALL && ls.pdf_kind == PDF_SOLID_ANGLE) {   // Discrete (point / directional): no MIS
-                            float total = (0.0f + p_dir) + ls.pdf;
-                            wmis = div_rn(ls.pdf, total);
+                    if (!zeroed) {
+                        Col term = czero();
+                        if (!is_zero(c_l) && add_l) {
+                            float wmis = 1.0f;
+                            if (rc.strategy == RL_STRATEGY_ALL && ls.pdf_kind == PDF_SOLID_ANGLE) {   // Discrete (point / directional): no MIS
+                                float total = (0.0f + p_dir) + ls.pdf;
+                                wmis = div_rn(ls.pdf, total);
+                            }
+                            term = c_l * wmis;
                         }
-                        Col pending = beta * (c_l * wmis);
-                        // a zero contribution needs no visibility test: the image cannot change
+                        Col pending = beta * term;
+                        // a zero contribution needs no visibility test: the image cannot change (beta * 0 is NaN for a NaN / infinite
+                        // throughput — then the edge matters and is traced)
                         if (!is_zero(pending)) {
                             shadow = true;
                             store3(ps, F_SX, ls.p);
@@ -351,7 +360,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
         }
         storec(ps, F_BR, beta);
         storec(ps, F_LR, L);
-    } else if (primary && sc.env_emitter < 0) storec(ps, F_LR, L);   // camera ray left the scene: the sample is 0
+    }
     PU(U_FLAGS) = new_flags;
 }
 

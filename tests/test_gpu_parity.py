@@ -460,6 +460,56 @@ def test_non_finite_and_degenerate_geometry_parity(built):
             np.testing.assert_array_equal(g, r)
 
 
+def test_hostile_shading_inputs_parity(built):
+    """NaN / infinite / huge uv, NaN normals, NaN / infinite / negative texels, NaN or infinite roughness, an all-black or negative
+    environment map: no fault, and the image equals the oracle's bit for bit *including its NaNs* — a NaN throughput poisons the sample
+    exactly as the reference's `weight * evaluate(next)` does, zero terms are added as beta * 0 rather than skipped."""
+    S = scenes
+
+    def make(kind, seed):
+        rng = np.random.default_rng(seed)
+        sd = S.cbox(24, 20) if kind < 6 else S.sky_scene(24, 20, keep_area_light=bool(seed % 2))
+        bm = rng.uniform(0, 1, (5, 7, 3)).astype(np.float32)
+        if kind == 3:
+            bm[1, 2] = np.nan; bm[3, 3] = np.inf; bm[0, 0] = -1.0
+        sd.bitmaps = [(7, 5, bm)]
+        texs = [{"type": S.TEX_BITMAP, "bitmap_id": 0, "color0": (1, 1, 1), "scale": (2.0, 3.0)},
+                {"type": S.TEX_CHECKERBOARD, "color0": (0.8, 0.8, 0.8), "color1": (0.1, 0.2, 0.3), "scale": (4.0, 4.0)},
+                {"type": S.TEX_GRID, "color0": (0.9, 0.1, 0.1), "color1": (0.4, 0.4, 0.4), "line_width": 0.05, "scale": (3.0, 2.0)}]
+        for i, m in enumerate(sd.meshes):
+            if m.emission:
+                continue
+            n = len(m.vertices)
+            m.uv = rng.uniform(-3, 3, (n, 2)).astype(np.float32)
+            m.bsdf = (S.Bsdf(type=S.DIFFUSE, diffuse=texs[i % 3]) if i % 2 else
+                      S.Bsdf(type=S.SUBSTRATE, diffuse=texs[i % 3], specular=S.const_color((0.04, 0.04, 0.04)), distribution=S.MF_GGX, alpha_u=0.2, alpha_v=0.3))
+            if kind == 0: m.uv[rng.integers(0, n)] = np.nan
+            if kind == 1: m.uv[rng.integers(0, n)] = (np.inf, -np.inf)
+            if kind == 2: m.uv *= np.float32(1e30)
+            if kind == 4 and m.normals is not None:
+                m.normals = m.normals.copy(); m.normals[rng.integers(0, n)] = np.nan
+            if kind == 5: m.bsdf = S.Bsdf(type=S.METAL, distribution=S.MF_GGX, alpha_u=float("nan") if i % 2 else 0.0, alpha_v=0.0 if i % 2 else float("inf"))
+        if kind >= 6:
+            em = S.sky_map().copy()
+            if kind == 6: em[:, :] = 0.0
+            if kind == 7: em[1, 1] = -5.0
+            sd.environment_map = em
+        return sd
+    saw_nan = False
+    for kind in range(8):
+        for seed in range(2):
+            sd = make(kind, seed)
+            ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+            for kw in (dict(spp=2, max_depth=5), dict(spp=2, max_depth=3, strategy=api.STRATEGY_BSDF)):
+                ref, ost = osc.render(master_seed=seed, eval_order=1, **kw)
+                saw_nan |= bool(np.isnan(ref).any())
+                for pipeline in (api.PIPELINE_WAVEFRONT, api.PIPELINE_FUSED):
+                    img, st = ctx.render(api.IndependentSampler(seed).block_seeds(sd.width, sd.height), api.path_params(pipeline=pipeline, **kw))
+                    np.testing.assert_array_equal(img, ref, err_msg=f"kind {kind} seed {seed} pipeline {pipeline} {kw}")      # NaN == NaN here
+                    assert all(st[k] == ost[k] for k in ("vertices", "rng_draws", "shadow_rays")), (kind, seed, pipeline)
+    assert saw_nan
+
+
 def test_furnace_invariant_on_gpu(built):
     sd = scenes.furnace(albedo=0.5, le=1.0, width=16, height=16)
     ctx = api.Context(api.Scene(sd), 0)
