@@ -50,5 +50,12 @@ for kind in range(10):
                 img, st = api.Context(scene, 0).render(api.IndependentSampler(seed).block_seeds(sd.width, sd.height), api.path_params(spp=2, max_depth=5, pipeline=pl))
                 same = np.array_equal(img, ref, equal_nan=True) and all(st[k] == ost[k] for k in ("vertices", "rng_draws", "shadow_rays"))
                 msg += f" pl{pl} {'same' if same else 'DIFF'}"; bad += not same
+            seeds = api.IndependentSampler(seed).block_seeds(sd.width, sd.height)
+            ctx = api.Context(scene, 0)
+            for name, kw in (("direct", dict(spp=2, nb_bsdf_samples=1, nb_light_samples=2)), ("ao", dict(spp=2, max_distance=0.7))):
+                img, st = (ctx.render_direct if name == "direct" else ctx.render_ao)(seeds, **kw)
+                ref2, ost2 = (osc.render_direct if name == "direct" else osc.render_ao)(seeds=seeds, **kw)
+                same = np.array_equal(img, ref2, equal_nan=True) and st["rng_draws"] == ost2["rng_draws"]
+                msg += f" {name} {'same' if same else 'DIFF'}"; bad += not same
         print(msg, flush=True)
 print("failures", bad)
