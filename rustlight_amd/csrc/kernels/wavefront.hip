@@ -456,6 +456,7 @@ extern "C" const char* rl_last_error(void) { return g_last_error.c_str(); }
         hipError_t e_ = (expr);                                                                        \
         if (e_ != hipSuccess) {                                                                        \
             rl_set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                           \
+            (void)hipGetLastError();   /* the error is reported here; do not leave it for the next call */ \
             return RL_ERR_HIP;                                                                         \
         }                                                                                              \
     } while (0)
@@ -716,7 +717,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     // pipeline: 1 = wavefront stage kernels, 2 = persistent fused kernel, 0 = auto (fused for per-sample streams: measured at
     // 1080p x 32 spp, fused vs wavefront: 508 k-triangle / 6-BSDF scene 127 vs 202 ms, 4.9 k triangles 61 vs 153 ms, Cornell box
     // with mixed BSDFs 23 vs 70 ms, diffuse Cornell box 15 vs 35 ms)
-    if (params->pipeline > 2) return RL_ERR_INVALID_ARGUMENT;
+    if (params->pipeline > 2) { rl_set_error("pipeline must be 0 (auto), 1 (wavefront) or 2 (fused)"); return RL_ERR_INVALID_ARGUMENT; }
     const bool fused = params->pipeline == 2 || (params->pipeline == 0 && per_sample && params->pool_slots == 0);
     // sample-parallel pixels: `split` lanes per pixel, per-sample radiances parked in HBM ([spp][pixel][3] floats) and folded
     // in order.  Auto: scenes that traverse out of L2 / HBM want ~8 M paths in flight per wavefront launch (measured on the
@@ -738,8 +739,9 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         while (split > 1 && (size_t)n_pixels * split > (size_t)0x7fffff00u) split--;
     }
     const unsigned n_items = per_sample ? n_pixels * split : (unsigned)owned.size();
-    unsigned P = params->pool_slots ? params->pool_slots : std::min<unsigned>(n_items, 16u << 20);
-    P = std::max(256u, (P + 255u) / 256u * 256u);
+    // a pool never needs more slots than there are work items (and `pool_slots` is caller input: keep the rounding below from wrapping)
+    unsigned P = params->pool_slots ? std::min(params->pool_slots, std::max(n_items, 1u)) : std::min<unsigned>(n_items, 16u << 20);
+    P = std::max(256u, (unsigned)(((unsigned long long)P + 255ull) / 256ull * 256ull));
     if (fused) {
         // One lane per work item by default.  With a participating medium path lengths vary by orders of magnitude, and on scenes
         // that stream their BVH from L2 / HBM the cost per pixel varies as much, so there the grid is only what the chip keeps
@@ -765,9 +767,18 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         if (ctx->pool.u) hipFree(ctx->pool.u);
         if (ctx->pool.q) hipFree(ctx->pool.q);
         ctx->pool = Pool{};
-        HIP_OK(hipMalloc((void**)&ctx->pool.f, (size_t)F_COUNT * P * sizeof(float)));
-        HIP_OK(hipMalloc((void**)&ctx->pool.u, (size_t)U_COUNT * P * sizeof(unsigned)));
-        HIP_OK(hipMalloc((void**)&ctx->pool.q, (size_t)Q_COUNT * P * sizeof(unsigned long long)));
+        ctx->pool_capacity = 0;          // until all three planes exist: a failed allocation must not leave a half-built pool behind
+        if (hipMalloc((void**)&ctx->pool.f, (size_t)F_COUNT * P * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&ctx->pool.u, (size_t)U_COUNT * P * sizeof(unsigned)) != hipSuccess ||
+            hipMalloc((void**)&ctx->pool.q, (size_t)Q_COUNT * P * sizeof(unsigned long long)) != hipSuccess) {
+            (void)hipGetLastError();
+            if (ctx->pool.f) hipFree(ctx->pool.f);
+            if (ctx->pool.u) hipFree(ctx->pool.u);
+            if (ctx->pool.q) hipFree(ctx->pool.q);
+            ctx->pool = Pool{};
+            rl_set_error("out of device memory for a path-state pool of " + std::to_string(P) + " slots");
+            return RL_ERR_HIP;
+        }
         ctx->pool_capacity = P;
     }
     if (split > 1 && (rcode = ensure(&ctx->d_sample_buf, &ctx->sample_buf_capacity, (size_t)n_pixels * params->spp * 3)) != RL_OK) return rcode;

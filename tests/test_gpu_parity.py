@@ -510,6 +510,22 @@ def test_hostile_shading_inputs_parity(built):
     assert saw_nan
 
 
+def test_extreme_execution_parameters(built):
+    """Tuning parameters are caller input: absurd values give the same image (pool sizes are clamped to the work there is, lanes per
+    pixel to the samples there are), more shards than tiles still sum to the full image, an unknown pipeline is an error."""
+    sd = scenes.cbox(40, 24)
+    ctx = api.Context(api.Scene(sd), 0)
+    seeds = api.IndependentSampler(1).block_seeds(sd.width, sd.height)
+    ref = ctx.render(seeds, api.path_params(spp=3))[0]
+    for kw in (dict(pool_slots=1), dict(pool_slots=3), dict(pool_slots=257), dict(pool_slots=(1 << 31) - 1), dict(pool_slots=0xFFFFFFFF), dict(sample_split=1000000),
+               dict(sample_split=3, pipeline=1, pool_slots=7), dict(pipeline=2, pool_slots=5)):
+        np.testing.assert_array_equal(ctx.render(seeds, api.path_params(spp=3, **kw))[0], ref, err_msg=str(kw))
+    with pytest.raises(api.RustlightError, match="pipeline"):
+        ctx.render(seeds, api.path_params(spp=3, pipeline=3))
+    parts = [ctx.render(seeds, api.path_params(spp=3, shard_index=r, shard_count=50))[0] for r in range(50)]
+    np.testing.assert_array_equal(sum(parts[1:], parts[0]), ref)
+
+
 def test_furnace_invariant_on_gpu(built):
     sd = scenes.furnace(albedo=0.5, le=1.0, width=16, height=16)
     ctx = api.Context(api.Scene(sd), 0)
