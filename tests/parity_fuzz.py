@@ -46,8 +46,8 @@ def run(budget=20.0, seed=0, verbose=True):
     def rand_params(sd):
         has_emitter = any(m.emission for m in sd.meshes) or bool(sd.lights) or sd.environment is not None or getattr(sd, "environment_map", None) is not None
         kw = dict(spp=int(rng.integers(1, 6)))
-        kw["max_depth"] = None if rng.random() < 0.2 else int(rng.integers(1, 12))
-        kw["min_depth"] = None if rng.random() < 0.6 else int(rng.integers(0, 3))
+        kw["max_depth"] = None if rng.random() < 0.2 else int(rng.integers(0, 12))
+        kw["min_depth"] = None if rng.random() < 0.6 else int(rng.integers(0, 6))
         kw["rr_depth"] = None if rng.random() < 0.2 else int(rng.integers(0, 5))
         kw["strategy"] = int(rng.choice([api.STRATEGY_ALL, api.STRATEGY_BSDF, api.STRATEGY_EMITTER])) if has_emitter else api.STRATEGY_BSDF
         kw["single_scattering"] = bool(rng.random() < 0.15)
