@@ -143,7 +143,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             from oracle import orc
             orc.use_timing_build()        # -O3 / libm / FMA build of the same restatement; never the checker
-            cw, ch, cspp = args.width, args.height, max(1, args.spp // 8)   # bounded sample of the same workload: same scene and resolution, 1/8 of the spp
+            cw, ch, cspp = args.width, args.height, max(1, args.spp // 4)   # bounded sample of the same workload: same scene and resolution, 1/4 of the spp (~10 s of CPU work over three passes)
             osc = orc.Scene(scenes.cbox(cw, ch) if args.scene == "cbox" else (scenes.cbox_medium(cw, ch, 0.5) if args.scene == "cbox_medium" else scenes.living_room(cw, ch)))
             # cores this process may really use: the GPU boxes report 256 hardware threads but run under a cgroup CPU quota
             # (cpu.max = 16 CPUs); more runnable threads than quota only adds throttling
