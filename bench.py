@@ -1,7 +1,15 @@
 #!/usr/bin/env python
 """bench.py — Msamples/s of the `path` hot path on BASELINE.json configs[1]:
-cbox, 1920x1080, 128 spp, diffuse-only, per-sample stream mode, N x MI355X (pixel-tile shards +
+cbox, 1920x1080, 128 spp per GPU, diffuse-only, per-sample stream mode, N x MI355X (pixel-tile shards +
 one RCCL framebuffer reduce).  One "step" = one full render (W*H*spp camera samples).
+
+Timed region: rl_render_path (tile seeding -> kernels -> framebuffer in HBM) + the RCCL reduce
+(N > 1) + the framebuffer download to pinned host memory on rank 0.  Scene construction, BVH build and upload are
+outside, as in the reference (integrators/mod.rs:280 vs 324-334).
+
+`python bench.py --gpus N` starts its own N ranks (re-executes itself under torch.distributed.run) unless it already runs
+under a launcher (WORLD_SIZE set).  On a box with fewer GPUs than ranks the ranks share devices and the reduce goes
+through gloo — a plumbing mode, flagged in the JSON (`devices_shared`), never a scaling measurement.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_path_fused on this workload): algorithmic bytes
 per launch / mean launch duration from HIP events on the render stream.  `cpu_baseline` times the
@@ -12,8 +20,10 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -21,34 +31,69 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=128)
+    ap.add_argument("--spp", type=int, default=128, help="samples per pixel PER GPU (weak scaling: the render uses spp x N)")
     ap.add_argument("--scene", default="cbox", choices=["cbox", "cbox_medium", "living_room"])
     ap.add_argument("--pool", type=int, default=0)
     ap.add_argument("--pipeline", default="auto", choices=["auto", "wavefront", "fused"])
+    ap.add_argument("--stream-mode", default="per_sample", choices=["per_sample", "reference"],
+                    help="per_sample: one lane per pixel / sample (throughput decomposition); reference: one lane per 16x16 block, rustlight's own stream assignment")
+    ap.add_argument("--numerics", default="exact", choices=["exact", "fast"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-verify", action="store_true", help="skip the untimed single-GPU re-render that checks the N-GPU image CRC")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _respawn_under_launcher(args):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py <same args>`."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("OMP_NUM_THREADS", "4")
+    sys.stdout.flush()
+    os.execvp(cmd[0], cmd)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _respawn_under_launcher(args)
 
     import torch
     import torch.distributed as dist
 
-    from rustlight_amd import api, scenes
+    from rustlight_amd import api, provenance, scenes
     from rustlight_amd import distributed as rd
 
-    # RL_BENCH_SHARE_DEVICE=1 RL_BENCH_BACKEND=gloo: dev-only way to run the N > 1 code path on a 1-GPU box (all ranks on device 0)
-    rank, world, local_rank = rd.init_from_env(args.gpus, os.environ.get("RL_BENCH_BACKEND"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback path exists)")
-    if os.environ.get("RL_BENCH_SHARE_DEVICE"):
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    # fewer devices than ranks (or RL_BENCH_SHARE_DEVICE=1): ranks share devices, RCCL cannot (one rank per device), so the reduce goes through gloo
+    shared = env_world > n_dev or bool(os.environ.get("RL_BENCH_SHARE_DEVICE"))
+    backend = os.environ.get("RL_BENCH_BACKEND") or ("gloo" if shared else "nccl")
+    rank, world, local_rank = rd.init_from_env(args.gpus, backend)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} is running with WORLD_SIZE={world}: launch it with --nproc-per-node {args.gpus} (or without a launcher)")
+    if world > 1:
+        assert dist.is_initialized() and dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+    device_index = local_rank % n_dev
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
 
     if args.scene == "cbox":
         sd = scenes.cbox(args.width, args.height)
@@ -58,23 +103,32 @@ def main():
         workload = f"cbox + homogeneous medium sigma_s=0.5 {args.width}x{args.height}x{args.spp}spp (BASELINE configs[4])"
     else:
         sd = scenes.living_room(args.width, args.height)
-        workload = f"living-room-class {sd.n_triangles} tris {args.width}x{args.height}x{args.spp}spp (BASELINE configs[2])"
+        workload = (f"living-room-class synthetic stand-in ({sd.n_triangles} tris, 6 BSDF types; the real pbrt-v3 living-room is not available) "
+                    f"{args.width}x{args.height}x{args.spp}spp (BASELINE configs[2])")
     scene = api.Scene(sd)
-    ctx = api.Context(scene, local_rank)          # BVH build + upload: untimed, like the reference (mod.rs:280)
+    ctx = api.Context(scene, device_index)          # BVH build + upload: untimed, like the reference (mod.rs:280)
     fb = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device=dev)
+    host_fb = torch.zeros((args.height, args.width, 3), dtype=torch.float32).pin_memory() if rank == 0 else None
     stream = torch.cuda.current_stream().cuda_stream
 
     # weak scaling: the image is fixed and spp grows with the GPU count (128 spp at N=1 ... 1024 spp at N=8 =
     # BASELINE configs[3]), so every GPU always traces W*H*128 camera samples per step.
     spp_total = args.spp * world
+    stream_mode = api.STREAM_PER_SAMPLE if args.stream_mode == "per_sample" else api.STREAM_REFERENCE_ORDER
+    pipeline = {"auto": 0, "wavefront": 1, "fused": 2}[args.pipeline]
+    numerics = {"exact": 0, "fast": 1}[args.numerics]
+
+    def params(shard_index, shard_count):
+        return api.path_params(spp=spp_total, shard_index=shard_index, shard_count=shard_count, pool_slots=args.pool, pipeline=pipeline,
+                               stream_mode=stream_mode, numerics=numerics)
 
     def step(seed):
         seeds = api.IndependentSampler(seed).block_seeds(args.width, args.height)     # same master stream on every rank
-        p = api.path_params(spp=spp_total, shard_index=rank, shard_count=world, pool_slots=args.pool,
-                            pipeline={"auto": 0, "wavefront": 1, "fused": 2}[args.pipeline])
-        _, st = ctx.render(seeds, p, out_device_ptr=fb.data_ptr(), stream=stream)
+        _, st = ctx.render(seeds, params(rank, world), out_device_ptr=fb.data_ptr(), stream=stream)
         if world > 1:
             rd.reduce_framebuffer(fb)                                                   # one RCCL reduce over xGMI
+        if rank == 0:
+            host_fb.copy_(fb, non_blocking=True)                                        # framebuffer download (inside the timed region, §8(d))
         return st
 
     for w in range(args.warmup):
@@ -89,15 +143,27 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dt = rd.max_over_ranks(dt)
-    host_img = fb.cpu().numpy() if rank == 0 else None
+    host_img = host_fb.numpy() if rank == 0 else None
 
     samples_per_step = args.width * args.height * spp_total
     value = samples_per_step * args.steps / dt / 1e6
     agg = {k: sum(s[k] for s in stats) for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "iterations", "n_extend_launches", "kernel_launches")}
     ms = {k: sum(s[k] for s in stats) for k in ("ms_raygen", "ms_extend", "ms_shade", "ms_shadow", "ms_other")}
     agg_all = rd.sum_over_ranks(agg)
+    ranks = rd.gather_objects({"rank": rank, "device": device_index, "name": torch.cuda.get_device_name(device_index), "pid": os.getpid(),
+                               "kernel_ms_per_step": (ms["ms_other"] or sum(ms.values())) / max(1, args.steps)})
 
     if rank == 0:
+        # ---- the N-GPU image must be the 1-GPU image, bit for bit (sums with zeros are exact): re-render the last step's
+        # frame on this GPU alone, untimed, and compare CRCs
+        crc = zlib.crc32(host_img.tobytes())
+        crc_single = None
+        if world > 1 and not args.no_verify:
+            seeds = api.IndependentSampler(args.steps - 1).block_seeds(args.width, args.height)
+            single, _ = ctx.render(seeds, params(0, 1))
+            crc_single = zlib.crc32(single.tobytes())
+            if crc_single != crc:
+                raise SystemExit(f"{world}-GPU image CRC {crc:08x} != 1-GPU image CRC {crc_single:08x}")
         # ---- roofline.  Algorithmic bytes per unit:
         #   k_raygen 108 B/camera sample, k_extend 44 B/ray, k_shade 280 B/vertex, k_shadow 72 B/shadow ray,
         #   k_path_fused (all four stages in one persistent launch): the whole-pipeline figure
@@ -121,24 +187,29 @@ def main():
             kernels["k_path_fused"] = {"avg_launch_ms": avg, "launches": args.steps, "algorithmic_bytes_per_unit": "248/sample + 352/vertex + 12/pixel",
                                        "achieved_GBps": gbs, "frac": gbs / 8000.0}
         dominant = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches"])
-        traffic = None
+        # PMC numbers are NOT collected in this run (rocprofv3 --pmc needs its own passes: scratch/pmc_collect.sh).  They are quoted
+        # only when they were collected on this very kernel source (hash of csrc/kernels + flags), with their provenance.
+        src_hash = provenance.kernel_source_hash()
+        traffic, pmc_entry = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            traffic = pmc["kernels"].get(dominant, {}).get("hbm_bytes")
+            live = json.load(open(os.path.join(ROOT, "profiles", "pmc_live.json")))
+            key = f"{args.scene}:{args.width}x{args.height}x{args.spp}:{args.stream_mode}:{args.numerics}"
+            e = live.get(key)
+            if e and e.get("kernel") == dominant and world == 1:
+                pmc_entry = dict(e, current=(e.get("kernel_src_hash") == src_hash))
+                if pmc_entry["current"]:
+                    traffic = e.get("hbm_bytes_per_launch")
         except Exception:
             pass
-        pmc_summary = None          # SQ / TCC counters of the same workload, collected by scratch/pmc_fused.sh in its own rocprofv3 --pmc passes
-        try:
-            ps = json.load(open(os.path.join(ROOT, "profiles", "r01f_pmc_fused_summary.json")))
-            if ps.get("kernel") == dominant and args.scene == "cbox":
-                pmc_summary = {k: ps[k] for k in ("valu_issue_busy", "lane_utilisation", "l2_hit_rate", "waves")}
-        except Exception:
-            pass
-        roofline = {"bound": "hbm", "kernel": dominant, "achieved": kernels[dominant]["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
-                    "frac": kernels[dominant]["frac"], "traffic": traffic, "avg_launch_ms": kernels[dominant]["avg_launch_ms"],
+        roofline = {"bound": (pmc_entry or {}).get("bound", "valu"), "kernel": dominant,
+                    "achieved": kernels[dominant]["achieved_GBps"], "peak": 8000.0, "unit": "GB/s", "frac": kernels[dominant]["frac"],
+                    "note": "achieved = ALGORITHMIC bytes (SURVEY §8(d): state a wavefront pipeline would stream) / kernel time; the fused kernel keeps that state in "
+                            "registers / LDS, so measured HBM traffic (`traffic`) is far below it and the kernel is bound by VALU issue + latency, not by HBM",
+                    "traffic": traffic, "avg_launch_ms": kernels[dominant]["avg_launch_ms"],
                     "launches": kernels[dominant]["launches"], "kernels": kernels,
                     "pipeline_algorithmic_GBps": pipe_bytes / dt / 1e9, "pipeline_frac": pipe_bytes / dt / 1e9 / 8000.0,
-                    "rays_per_s": (agg_all["extension_rays"] + agg_all["shadow_rays"]) / dt, "pmc": pmc_summary}
+                    "rays_per_s": (agg_all["extension_rays"] + agg_all["shadow_rays"]) / dt,
+                    "kernel_src_hash": src_hash, "pmc": pmc_entry}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             from oracle import orc
@@ -164,14 +235,26 @@ def main():
                     break
             cpu = {"value": max(runs), "unit": "Msamples/s", "cores": ost["threads"], "kind": "port", "runs": [round(r, 2) for r in runs],
                    "sample": f"{args.scene} {cw}x{ch}x{cspp}spp, reference-order streams, CPU restatement of rustlight `path` (C++, -O3 timing build), {ost['threads']} threads = CPUs available to the process (affinity / cgroup quota; the host has {os.cpu_count()} hardware threads), best of {len(runs)}"}
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            rccl = None
         out = {"metric": "Msamples/s (paths/s) at 1080p x 128spp cbox", "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
-               "config": {"workload": workload, "spp_total": spp_total, "stream_mode": "per_sample", "pipeline": "fused (k_path_fused)" if fused else "wavefront (raygen/extend/shade/shadow)", "parallelism": f"tile-shard x{world} + 1 RCCL reduce",
+               "config": {"workload": workload, "spp_total": spp_total, "stream_mode": args.stream_mode, "numerics": args.numerics,
+                          "pipeline": "fused (k_path_fused)" if fused else "wavefront (raygen/extend/shade/shadow)",
+                          "parallelism": f"tile-shard x{world} + 1 RCCL reduce",
+                          "timed_region": "rl_render_path + framebuffer reduce (N > 1) + framebuffer download to pinned host memory (SURVEY §8(d))",
                           "mean_vertices_per_sample": agg_all["vertices"] / max(1, agg_all["camera_samples"]),
                           "image_mean": float(host_img.mean())},
+               "distributed": {"world_size": world, "backend": backend if world > 1 else None, "rccl_version": rccl, "devices_visible": n_dev, "devices_shared": bool(shared and world > 1),
+                               "ranks": ranks, "image_crc32": f"{crc:08x}", "single_gpu_image_crc32": None if crc_single is None else f"{crc_single:08x}",
+                               "crc_match": None if crc_single is None else crc_single == crc},
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))
+        sys.stdout.flush()
+    rd.barrier()
     rd.finalize()
 
 

@@ -187,6 +187,7 @@ typedef enum rl_path_strategy { RL_STRATEGY_ALL = 0, RL_STRATEGY_BSDF = 1, RL_ST
  *  RL_STREAM_PER_SAMPLE: the block stream is forked with the reference's own clone_box rule
  *      (samplers/independent.rs:18-22) once per pixel and once per sample — throughput mode. */
 typedef enum rl_stream_mode { RL_STREAM_REFERENCE_ORDER = 0, RL_STREAM_PER_SAMPLE = 1 } rl_stream_mode;
+typedef enum rl_numerics { RL_NUMERICS_EXACT = 0, RL_NUMERICS_FAST = 1 } rl_numerics;
 
 /* struct IntegratorPathTracing (explicit/path.rs:14-20) + scene.nb_samples + sharding. */
 typedef struct rl_path_params {
@@ -216,7 +217,11 @@ typedef struct rl_path_params {
      * per-sample radiances are parked in HBM and added up in sample order afterwards, so the sum keeps the reference's
      * association). 0 = auto, 1 = one lane per pixel. Does not change results. */
     uint32_t sample_split;
-    uint32_t reserved[1];
+    /* rl_numerics: 0 = exact (default; every f32 operation as the reference performs it — the only mode the parity tests bless),
+     * 1 = fast (opt-in: FMA contraction, v_rcp / v_rsq + one Newton step instead of the IEEE divide / sqrt sequences, hardware
+     * transcendentals; the RNG sequence stays bit-exact, pixels agree with the exact mode within BASELINE.json's per-pixel L2
+     * tolerance, not bit for bit — DESIGN.md §2 "Tolerance mode"). */
+    uint32_t numerics;
 } rl_path_params;
 
 void rl_path_params_default(rl_path_params* params);   /* CLI defaults: examples/cli.rs:53-61,167-168 */
@@ -265,6 +270,24 @@ int rl_generate_block_seeds(rl_sampler* master, uint32_t width, uint32_t height,
 int rl_render_path(rl_context* ctx, const rl_path_params* params, const uint64_t* block_seeds,
                    size_t n_blocks, float* out_rgb, int out_is_device, void* stream,
                    rl_render_stats* stats);
+
+/* ---- several GPUs of one node behind one call ------------------------------------------------------
+ * The reference merges its per-block bitmaps with `accumulate_bitmap` (src/integrators/mod.rs:445-448); here every GPU renders the
+ * blocks b % N == g into its own zeroed framebuffer in HBM and ONE ncclReduce(sum, root = first device) over xGMI merges them —
+ * device to device, no per-GPU download, no host adds; sums with zeros are exact, so the image equals the 1-GPU image bit for
+ * bit.  One process: rl_multi owns N device contexts (BVHAccel::new once per device, untimed), an RCCL communicator clique
+ * (ncclCommInitAll) and the per-device framebuffers.  `devices` = HIP ordinals, one per shard (NULL: round-robin over the
+ * visible devices).  Shards that share a device (more shards than GPUs: a plumbing mode for tests) are added on that device
+ * before the reduce; the communicator spans the distinct devices. */
+typedef struct rl_multi rl_multi;
+int rl_multi_create(const rl_scene* scene, const int* devices, int n_shards, rl_multi** out);
+void rl_multi_destroy(rl_multi* m);
+int rl_multi_info(const rl_multi* m, int* n_shards, int* n_comm_ranks, int* rccl_version);
+/* Integrator::compute over all shards: params->shard_index / shard_count are set per GPU by the call; `out_rgb` is a HOST
+ * buffer of W*H*3 f32 (the framebuffer download from the root GPU is part of the call); `stats` = sums over the shards
+ * (render_ms, ms_other: maximum).  Blocking. */
+int rl_multi_render_path(rl_multi* m, const rl_path_params* params, const uint64_t* block_seeds, size_t n_blocks,
+                         float* out_rgb, rl_render_stats* stats);
 
 /* ---- the two other `compute_mc` integrators that reuse this path's kernels ---- */
 

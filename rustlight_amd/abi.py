@@ -30,7 +30,7 @@ class PathParams(C.Structure):
                 ("has_max_depth", C.c_int32), ("max_depth", C.c_uint32), ("has_rr_depth", C.c_int32),
                 ("rr_depth", C.c_uint32), ("strategy", C.c_int32), ("single_scattering", C.c_int32),
                 ("stream_mode", C.c_int32), ("seed_variant", C.c_int32), ("shard_index", C.c_uint32),
-                ("shard_count", C.c_uint32), ("pool_slots", C.c_uint32), ("pipeline", C.c_uint32), ("sample_split", C.c_uint32), ("reserved", C.c_uint32 * 1)]
+                ("shard_count", C.c_uint32), ("pool_slots", C.c_uint32), ("pipeline", C.c_uint32), ("sample_split", C.c_uint32), ("numerics", C.c_uint32)]
 
 
 class McParams(C.Structure):

@@ -24,6 +24,7 @@ RL_ERR_NO_DEVICE = -2
 STRATEGY_ALL, STRATEGY_BSDF, STRATEGY_EMITTER = 0, 1, 2
 STREAM_REFERENCE_ORDER, STREAM_PER_SAMPLE = 0, 1
 PIPELINE_AUTO, PIPELINE_WAVEFRONT, PIPELINE_FUSED = 0, 1, 2
+NUMERICS_EXACT, NUMERICS_FAST = 0, 1
 
 # every symbol include/rustlight_amd.h declares (tests check the .so exports all of them)
 PUBLIC_SYMBOLS = [
@@ -32,7 +33,7 @@ PUBLIC_SYMBOLS = [
     "rl_scene_set_environment", "rl_scene_set_environment_map", "rl_scene_build_emitters", "rl_scene_enable_ats", "rl_scene_load_pbrt", "rl_scene_load_mitsuba", "rl_scene_load",
     "rl_scene_image_size", "rl_scene_counts", "rl_sampler_seed", "rl_sampler_next_u64", "rl_sampler_next_f32",
     "rl_path_params_default", "rl_device_count", "rl_context_create", "rl_context_destroy", "rl_last_error", "rl_block_count",
-    "rl_generate_block_seeds", "rl_render_path", "rl_render_ao", "rl_render_direct", "rl_trace_batch", "rl_visible_batch", "rl_load_pfm", "rl_load_image", "rl_save_pfm", "rl_save_png", "rl_save_exr", "rl_save_image", "rl_build_info",
+    "rl_generate_block_seeds", "rl_render_path", "rl_multi_create", "rl_multi_destroy", "rl_multi_info", "rl_multi_render_path", "rl_render_ao", "rl_render_direct", "rl_trace_batch", "rl_visible_batch", "rl_load_pfm", "rl_load_image", "rl_save_pfm", "rl_save_png", "rl_save_exr", "rl_save_image", "rl_build_info",
 ]
 
 
@@ -94,6 +95,11 @@ def lib():
     L.rl_render_path.argtypes = [vp, C.POINTER(abi.PathParams), u64p, C.c_size_t, vp, C.c_int, vp, C.POINTER(abi.RenderStats)]
     for fn in (L.rl_render_ao, L.rl_render_direct):
         fn.argtypes = [vp, C.POINTER(abi.McParams), u64p, C.c_size_t, vp, C.c_int, vp, C.POINTER(abi.RenderStats)]
+    L.rl_multi_create.argtypes = [vp, C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.rl_multi_destroy.argtypes = [vp]
+    L.rl_multi_destroy.restype = None
+    L.rl_multi_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.rl_multi_render_path.argtypes = [vp, C.POINTER(abi.PathParams), u64p, C.c_size_t, vp, C.POINTER(abi.RenderStats)]
     L.rl_trace_batch.argtypes = [vp, C.c_size_t, f32p, f32p, f32p, f32p, f32p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rl_visible_batch.argtypes = [vp, C.c_size_t, f32p, f32p, C.POINTER(C.c_uint8)]
     for fn in (L.rl_save_pfm, L.rl_save_png, L.rl_save_exr, L.rl_save_image):
@@ -259,7 +265,7 @@ class Scene:
 
 
 def path_params(spp=1, min_depth=0, max_depth=None, rr_depth=0, strategy=STRATEGY_ALL, single_scattering=False,
-                stream_mode=STREAM_PER_SAMPLE, seed_variant=0, shard_index=0, shard_count=1, pool_slots=0, pipeline=0, sample_split=0) -> abi.PathParams:
+                stream_mode=STREAM_PER_SAMPLE, seed_variant=0, shard_index=0, shard_count=1, pool_slots=0, pipeline=0, sample_split=0, numerics=0) -> abi.PathParams:
     p = abi.PathParams()
     lib().rl_path_params_default(C.byref(p))
     p.spp = spp
@@ -274,6 +280,7 @@ def path_params(spp=1, min_depth=0, max_depth=None, rr_depth=0, strategy=STRATEG
     p.pool_slots = pool_slots
     p.pipeline = pipeline
     p.sample_split = sample_split
+    p.numerics = numerics
     return p
 
 
@@ -356,6 +363,42 @@ class Context:
         l = C.c_int()
         _check(lib().rl_debug_bvh_sizes(self.h, C.byref(a), C.byref(b), C.byref(d), C.byref(l)))
         return {"ref_nodes": a.value, "prims": b.value, "stack_depth": d.value, "lds_scene": bool(l.value)}
+
+
+class MultiContext:
+    """N device contexts of one node + an RCCL communicator clique in ONE process (rl_multi_*): shard renders on one host thread
+    per GPU, a single ncclReduce over xGMI, one download from the root."""
+
+    def __init__(self, scene: Scene, n_shards: int, devices=None):
+        self.scene = scene
+        h = C.c_void_p()
+        dv = None if devices is None else (C.c_int * n_shards)(*devices)
+        _check(lib().rl_multi_create(scene.h, dv, n_shards, C.byref(h)))
+        self.h = h
+        self.width, self.height = scene.size
+
+    def info(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().rl_multi_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"shards": a.value, "comm_ranks": b.value, "rccl_version": c.value}
+
+    def render(self, seeds: np.ndarray, params: abi.PathParams):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        st = abi.RenderStats()
+        img = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        _check(lib().rl_multi_render_path(self.h, C.byref(params), abi.u64ptr(seeds), seeds.shape[0], img.ctypes.data_as(C.c_void_p), C.byref(st)))
+        return img, st.as_dict()
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rl_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class IntegratorPathTracing:

@@ -12,7 +12,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "librustlight_amd.so")
 BIN = os.path.join(LIB_DIR, "rustlight-amd")
 
-HIP_SOURCES = ["kernels/wavefront.hip"]
+HIP_SOURCES = ["kernels/wavefront.hip", "host/multigpu.hip"]     # multigpu.hip: N device contexts + the RCCL framebuffer reduce
 CXX_SOURCES = ["host/scene.cpp", "host/bvh.cpp", "host/io.cpp", "host/pbrt.cpp", "host/meshio.cpp", "host/mitsuba.cpp", "host/lighttree.cpp"]
 # -ffp-contract=off: rustlight's f32 arithmetic is never contracted into FMAs
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-value", "-Wno-unused-function"]
@@ -58,7 +58,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-o", LIB, *objs, "-lz"]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-o", LIB, *objs, "-lz", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     # the CLI (examples/cli.rs counterpart)
     cli = os.path.join(CSRC, "host", "cli.cpp")

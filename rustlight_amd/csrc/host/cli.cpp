@@ -1,7 +1,7 @@
 // cli.cpp — `rustlight-amd`: the reference CLI's flags for the `path` subcommand (examples/cli.rs:
 // global flags 106-145, `path` 162-169, medium 355-399, sampler 876-896, run/save 898-923).
 //   rustlight-amd <scene.pbrt|scene.xml> -n SPP -o out.pfm [-r independent:SEED] [-m s[:a[:g]]] [-s SCALE] [-t N]
-//                 [--device D] [--stream-mode reference|per-sample]
+//                 [--device D] [--gpus N] [--stream-mode reference|per-sample] [--numerics exact|fast]
 //                 path [-m MAX|inf] [-n MIN] [-r RR|inf] [-x] [-s all|bsdf|emitter]
 //               | ao [-d DIST|inf] [-n]            (examples/cli.rs:149-154)
 //               | direct [-b NB_BSDF] [-l NB_LIGHT] (examples/cli.rs:155-160)
@@ -38,6 +38,7 @@ int main(int argc, char** argv) {
     bool ao_normal_correction = false;
     size_t nb_bsdf = 1, nb_light = 1;
     rl_stream_mode mode = RL_STREAM_PER_SAMPLE;
+    uint32_t numerics = RL_NUMERICS_EXACT;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() -> std::string { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -52,6 +53,7 @@ int main(int argc, char** argv) {
             else if (a == "--device") device = std::atoi(val().c_str());
             else if (a == "--gpus") gpus = std::atoi(val().c_str());
             else if (a == "--stream-mode") mode = val() == "reference" ? RL_STREAM_REFERENCE_ORDER : RL_STREAM_PER_SAMPLE;
+            else if (a == "--numerics") numerics = val() == "fast" ? RL_NUMERICS_FAST : RL_NUMERICS_EXACT;
             else if (a == "-a" || a == "--average") average = val();
             else if (a == "-e" || a == "--equal-time") equal_time = val();
             else if (a == "-x" || a == "--xtra-options") {   // ExtraOptions (cli.rs:41-50): ats | no-shading are honoured
@@ -99,10 +101,10 @@ int main(int argc, char** argv) {
             if (sigma_a + sigma_s != 0.0f) {
                 float sa[3] = {sigma_a, sigma_a, sigma_a}, s3[3] = {sigma_s, sigma_s, sigma_s};
                 float g = parts.size() > 2 ? std::strtof(parts[2].c_str(), nullptr) : 0.0f;
-                rl_scene_set_medium(scene->handle, sa, s3, parts.size() > 2 ? RL_PHASE_HG : RL_PHASE_ISOTROPIC, g);
+                if (rl_scene_set_medium(scene->handle, sa, s3, parts.size() > 2 ? RL_PHASE_HG : RL_PHASE_ISOTROPIC, g) != RL_OK) { std::fprintf(stderr, "invalid medium_density\n"); return 2; }
             }
         }
-        if (scale_image != 1.0f) rl_scene_scale_image(scene->handle, scale_image);
+        if (scale_image != 1.0f && rl_scene_scale_image(scene->handle, scale_image) != RL_OK) { std::fprintf(stderr, "invalid image scale: %s\n", rl_last_error()); return 2; }
         scene->build_emitters(use_ats);      // scene.build_emitters(use_ats) (cli.rs:432)
         IntegratorPathTracing integrator;
         integrator.min_depth = match_infinity(min_depth);
@@ -114,8 +116,9 @@ int main(int argc, char** argv) {
         else { std::fprintf(stderr, "invalid strategy: %s\n", strategy.c_str()); return 2; }
         integrator.single_scattering = single_scattering;
         integrator.device = device;
-        integrator.n_gpus = gpus;      // --gpus N: blocks dealt round-robin over N devices, framebuffers added on the host
+        integrator.n_gpus = gpus;      // --gpus N: blocks dealt round-robin over N devices, one RCCL reduce of the framebuffers over xGMI
         integrator.stream_mode = mode;
+        integrator.numerics = numerics;
         uint64_t seed;
         if (rng == "independent") seed = std::random_device{}();   // IndependentSampler::default(): OS entropy
         else if (rng.rfind("independent:", 0) == 0) seed = std::strtoull(rng.c_str() + 12, nullptr, 10);

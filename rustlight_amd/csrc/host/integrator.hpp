@@ -67,35 +67,41 @@ struct IntegratorPathTracing {
     // MI355X-specific knobs (not in the reference)
     int device = 0;
     rl_stream_mode stream_mode = RL_STREAM_PER_SAMPLE;
+    uint32_t numerics = RL_NUMERICS_EXACT;      // RL_NUMERICS_FAST: opt-in tolerance mode
     uint32_t shard_index = 0, shard_count = 1;
     rl_render_stats last_stats{};
 
     // several GPUs of one node from one process (the CLI's --gpus N): GPU g renders the blocks b % N == g on its
-    // own host thread, the per-GPU framebuffers — zero outside their own blocks — are added on the host (exact)
+    // own host thread into its own framebuffer in HBM; ONE ncclReduce over xGMI merges them on the first GPU (rl_multi_*)
     int n_gpus = 1;
 
     // the device contexts (BVH + uploaded scene) are built once per scene, like `BVHAccel::new` in IntegratorType::compute
-    std::vector<rl_context*> ctxs;
+    rl_context* ctx = nullptr;
+    rl_multi* multi = nullptr;
     const Scene* ctx_scene = nullptr;
+    int ctx_gpus = 0;
     IntegratorPathTracing() = default;
     IntegratorPathTracing(const IntegratorPathTracing&) = delete;
-    ~IntegratorPathTracing() { for (rl_context* c : ctxs) rl_context_destroy(c); }
+    ~IntegratorPathTracing() { release(); }
+    void release() { if (ctx) rl_context_destroy(ctx); if (multi) rl_multi_destroy(multi); ctx = nullptr; multi = nullptr; }
 
     // IntegratorType::compute + Integrator::compute: builds the BVH (untimed, first call), renders, returns the image
     BufferCollection compute(IndependentSampler& sampler, Scene& scene) {
         const int n = std::max(1, n_gpus);
-        if (ctxs.size() != (size_t)n || ctx_scene != &scene) {
-            for (rl_context* c : ctxs) rl_context_destroy(c);
-            ctxs.clear();
-            int n_dev = 0;
-            rl_device_count(&n_dev);
-            for (int g = 0; g < n; g++) {
-                rl_context* c = nullptr;
-                int rc = rl_context_create(scene.handle, n_dev > 0 ? (device + g) % n_dev : device + g, &c);
+        if (ctx_scene != &scene || ctx_gpus != n || (!ctx && !multi)) {
+            release();
+            if (n == 1) {
+                int rc = rl_context_create(scene.handle, device, &ctx);
                 if (rc != RL_OK) throw std::runtime_error(std::string("rl_context_create: ") + rl_last_error());
-                ctxs.push_back(c);
+            } else {
+                int n_dev = 0;
+                rl_device_count(&n_dev);
+                std::vector<int> devs(n);
+                for (int g = 0; g < n; g++) devs[g] = n_dev > 0 ? (device + g) % n_dev : device + g;
+                int rc = rl_multi_create(scene.handle, devs.data(), n, &multi);
+                if (rc != RL_OK) throw std::runtime_error(std::string("rl_multi_create: ") + rl_last_error());
             }
-            ctx_scene = &scene;
+            ctx_scene = &scene; ctx_gpus = n;
         }
         BufferCollection img;
         rl_scene_image_size(scene.handle, &img.width, &img.height);
@@ -109,33 +115,18 @@ struct IntegratorPathTracing {
         p.strategy = (int)strategy;
         p.single_scattering = single_scattering;
         p.stream_mode = stream_mode;
+        p.numerics = numerics;
         p.seed_variant = sampler.variant;
         std::vector<uint64_t> seeds(rl_block_count(img.width, img.height));
         rl_generate_block_seeds(&sampler.rnd, img.width, img.height, seeds.data(), seeds.size());   // generate_img_blocks
         if (n == 1) {
             p.shard_index = shard_index; p.shard_count = shard_count;
-            int rc = rl_render_path(ctxs[0], &p, seeds.data(), seeds.size(), img.primal.data(), 0, nullptr, &last_stats);
+            int rc = rl_render_path(ctx, &p, seeds.data(), seeds.size(), img.primal.data(), 0, nullptr, &last_stats);
             if (rc != RL_OK) throw std::runtime_error(std::string("rl_render_path: ") + rl_last_error());
             return img;
         }
-        std::vector<std::vector<float>> part(n, std::vector<float>(img.primal.size()));
-        std::vector<rl_render_stats> st(n);
-        std::vector<std::string> errs(n);
-        std::vector<std::thread> th;
-        for (int g = 0; g < n; g++)
-            th.emplace_back([&, g]() {
-                rl_path_params q = p;
-                q.shard_index = (uint32_t)g; q.shard_count = (uint32_t)n;
-                if (rl_render_path(ctxs[g], &q, seeds.data(), seeds.size(), part[g].data(), 0, nullptr, &st[g]) != RL_OK) errs[g] = rl_last_error();
-            });
-        for (std::thread& t : th) t.join();
-        for (int g = 0; g < n; g++) if (!errs[g].empty()) throw std::runtime_error("rl_render_path (gpu " + std::to_string(g) + "): " + errs[g]);
-        last_stats = st[0];
-        for (int g = 0; g < n; g++) {
-            for (size_t i = 0; i < img.primal.size(); i++) img.primal[i] += part[g][i];
-            if (g) { last_stats.camera_samples += st[g].camera_samples; last_stats.vertices += st[g].vertices; last_stats.extension_rays += st[g].extension_rays;
-                     last_stats.shadow_rays += st[g].shadow_rays; last_stats.rng_draws += st[g].rng_draws; last_stats.render_ms = std::max(last_stats.render_ms, st[g].render_ms); }
-        }
+        int rc = rl_multi_render_path(multi, &p, seeds.data(), seeds.size(), img.primal.data(), &last_stats);
+        if (rc != RL_OK) throw std::runtime_error(std::string("rl_multi_render_path: ") + rl_last_error());
         return img;
     }
 };
@@ -198,6 +189,7 @@ struct IntegratorAverage {
         if (dot == std::string::npos) throw std::runtime_error("No file extension provided");
         const std::string base = out.substr(0, dot), ext = out.substr(dot + 1);
         FILE* csv = dump_all ? std::fopen((base + "_time.csv").c_str(), "w") : nullptr;
+        if (dump_all && !csv) throw std::runtime_error("cannot write " + base + "_time.csv");
         BufferCollection bitmap;
         size_t iteration = 1;
         double elapsed = 0.0;

@@ -151,8 +151,10 @@ int rl_scene_set_camera(rl_scene* scene, uint32_t width, uint32_t height, float 
 int rl_scene_scale_image(rl_scene* scene, float s) {
     if (!scene || !scene->has_camera || s == 0.0f) return RL_ERR_INVALID_ARGUMENT;
     // Camera::scale_image only rescales `img`; the matrices keep the original aspect (camera.rs:73-78)
-    scene->width = (uint32_t)(s * (float)scene->width);
-    scene->height = (uint32_t)(s * (float)scene->height);
+    const uint32_t w = (uint32_t)(s * (float)scene->width), h = (uint32_t)(s * (float)scene->height);
+    if (!(s > 0.0f) || w == 0 || h == 0) { rl_set_error("image scale leaves no pixels"); return RL_ERR_INVALID_ARGUMENT; }
+    scene->width = w;
+    scene->height = h;
     return RL_OK;
 }
 
@@ -171,7 +173,14 @@ int rl_scene_add_mesh(rl_scene* scene, const float* vertices, size_t n_vertices,
     if (n_triangles == 0 || n_vertices == 0) return RL_ERR_INVALID_ARGUMENT;   // "Empty meshs": Mesh::new returns None
     for (size_t i = 0; i < 3 * n_triangles; i++)
         if (indices[i] >= n_vertices) return RL_ERR_INVALID_ARGUMENT;
-    if (bsdf->type < RL_BSDF_DIFFUSE || bsdf->type > RL_BSDF_SUBSTRATE) return RL_ERR_INVALID_ARGUMENT;
+    if (bsdf->type < RL_BSDF_DIFFUSE || bsdf->type > RL_BSDF_SUBSTRATE) { rl_set_error("unknown BSDF type"); return RL_ERR_INVALID_ARGUMENT; }
+    if (bsdf->distribution < RL_MICROFACET_NONE || bsdf->distribution > RL_MICROFACET_GGX) { rl_set_error("unknown microfacet distribution"); return RL_ERR_INVALID_ARGUMENT; }
+    // the device indexes textures by these ids without a bounds check: every enum / id of the five colour slots is validated here
+    // (bitmaps may still be added after the mesh: the upper bound of bitmap_id is checked again when the emitters are built)
+    for (const rl_color_desc* c : {&bsdf->diffuse, &bsdf->specular, &bsdf->transmittance, &bsdf->eta, &bsdf->k}) {
+        if (c->type < RL_TEX_CONSTANT || c->type > RL_TEX_BITMAP) { rl_set_error("unknown texture type in a BSDF colour"); return RL_ERR_INVALID_ARGUMENT; }
+        if (c->type == RL_TEX_BITMAP && c->bitmap_id < 0) { rl_set_error("RL_TEX_BITMAP colour without a bitmap id"); return RL_ERR_INVALID_ARGUMENT; }
+    }
     HostMesh m;
     m.positions.resize(n_vertices);
     for (size_t i = 0; i < n_vertices; i++) m.positions[i] = {vertices[3 * i], vertices[3 * i + 1], vertices[3 * i + 2]};
@@ -223,6 +232,15 @@ int rl_scene_set_medium(rl_scene* scene, const float sigma_a[3], const float sig
 // Scene::build_emitters(false) (src/scene.rs:53-123)
 int rl_scene_build_emitters(rl_scene* scene) {
     if (!scene || !scene->has_camera) return RL_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < scene->meshes.size(); i++) {
+        const rl_bsdf_desc& b = scene->meshes[i].bsdf;
+        for (const rl_color_desc* c : {&b.diffuse, &b.specular, &b.transmittance, &b.eta, &b.k})
+            if (c->type == RL_TEX_BITMAP && (c->bitmap_id < 0 || (size_t)c->bitmap_id >= scene->bitmaps.size())) {
+                rl_set_error("mesh " + std::to_string(i) + " references bitmap " + std::to_string(c->bitmap_id) + " but the scene has " +
+                             std::to_string(scene->bitmaps.size()) + " bitmaps");
+                return RL_ERR_INVALID_ARGUMENT;
+            }
+    }
     Box3 box;
     for (const HostMesh& m : scene->meshes) {
         Box3 b;

@@ -596,6 +596,13 @@ extern "C" int rl_context_create(const rl_scene* scene, int device, rl_context**
         ctx->scene_lds_bytes = 64 * ((size_t)ds.n_nodes + ds.n_prims);
         // LDS-staged scenes also keep their whole traversal stack in LDS (TravStackT<true>)
         ctx->lds_scene = ctx->scene_lds_bytes <= 48 * 1024 && ds.stack_depth <= (uint32_t)kLdsStackLevels;
+        {   // worst-case dynamic LDS of any kernel that stages the scene: [scene][compaction list | cold path state][12 stack levels];
+            // it must fit what a workgroup may ask for on this device, else the scene streams from L2 / HBM instead
+            int lds_limit = 64 * 1024;
+            hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
+            const size_t worst = ctx->scene_lds_bytes + std::max<size_t>(272 * sizeof(unsigned), kFusedColdBytes) + (size_t)2 * kLdsStackLevels * 256 * sizeof(int);
+            if (worst > (size_t)lds_limit) ctx->lds_scene = false;
+        }
         if (hipMalloc((void**)&ctx->d_counters, sizeof(Counters)) != hipSuccess) { rl_set_error("hipMalloc counters"); rc = RL_ERR_HIP; break; }
         if (hipHostMalloc((void**)&ctx->h_counters, sizeof(Counters)) != hipSuccess) { rl_set_error("hipHostMalloc counters"); rc = RL_ERR_HIP; break; }
     } while (0);
@@ -695,6 +702,8 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     if (params->spp == 0) { rl_set_error("spp must be > 0 (assert_ne!(scene.nb_samples, 0), mod.rs:410)"); return RL_ERR_INVALID_ARGUMENT; }
     if (params->strategy < 0 || params->strategy > 2) return RL_ERR_INVALID_ARGUMENT;
     if (params->stream_mode != RL_STREAM_REFERENCE_ORDER && params->stream_mode != RL_STREAM_PER_SAMPLE) return RL_ERR_INVALID_ARGUMENT;
+    if (params->numerics > RL_NUMERICS_FAST) { rl_set_error("numerics must be 0 (exact) or 1 (fast)"); return RL_ERR_INVALID_ARGUMENT; }
+    if (params->numerics == RL_NUMERICS_FAST) { rl_set_error("numerics = fast is not built into this library"); return RL_ERR_UNSUPPORTED; }
     const uint32_t shard_count = params->shard_count ? params->shard_count : 1;
     if (params->shard_index >= shard_count) return RL_ERR_INVALID_ARGUMENT;
     if (params->strategy != RL_STRATEGY_BSDF && ctx->ds.n_emitters == 0) { rl_set_error("light sampling requested but the scene has no emitter"); return RL_ERR_NO_EMITTER; }
@@ -864,6 +873,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         if (timing) hipEventRecord(ctx->events[0], st);
         launch_fused_type(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, ctx->lds_scene, grid_all, block, lds_fused, st, rc, ds, stc);
         if (timing) hipEventRecord(ctx->events[1], st);
+        HIP_OK(hipGetLastError());          // a refused launch configuration is not sticky: without this the sync below would "succeed"
         HIP_OK(hipStreamSynchronize(st));
         if (timing) { float t = 0.0f; HIP_OK(hipEventElapsedTime(&t, ctx->events[0], ctx->events[1])); ms_fused = t; }
 #ifdef RL_STAGE_TIMERS
@@ -905,6 +915,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         iterations++;
         in_batch++;
         if (in_batch == poll_every) {
+            HIP_OK(hipGetLastError());      // launch-configuration errors of the batch (non-sticky): never spin on a counter no kernel updates
             HIP_OK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, st));
             HIP_OK(hipStreamSynchronize(st));
             if (timing) { int r = flush_events(in_batch); if (r != RL_OK) return r; }
@@ -1039,46 +1050,58 @@ extern "C" int rl_render_direct(rl_context* ctx, const rl_mc_params* params, con
                                 void* stream, rl_render_stats* stats) { return render_mc(ctx, 1, params, block_seeds, n_blocks, out_rgb, out_is_device, stream, stats); }
 
 // ---- batched Acceleration::{trace, visible}
+namespace {
+struct DevBuf {     // frees on every exit path of the batch entry points
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+constexpr size_t kMaxBatch = 0x7fffff00u;   // grid and kernel argument are 32-bit
+}  // namespace
 extern "C" int rl_trace_batch(rl_context* ctx, size_t n, const float* origins, const float* directions, float* t_out, float* u_out,
                               float* v_out, int32_t* mesh_out, int32_t* tri_out) {
     if (!ctx || (n && (!origins || !directions || !t_out || !u_out || !v_out || !mesh_out || !tri_out))) return RL_ERR_INVALID_ARGUMENT;
     if (n == 0) return RL_OK;
+    if (n > kMaxBatch) { rl_set_error("batch too large"); return RL_ERR_INVALID_ARGUMENT; }
     HIP_OK(hipSetDevice(ctx->device));
-    float *d_o, *d_d, *d_t, *d_u, *d_v; int *d_m, *d_tr;
-    HIP_OK(hipMalloc((void**)&d_o, 3 * n * 4)); HIP_OK(hipMalloc((void**)&d_d, 3 * n * 4));
-    HIP_OK(hipMalloc((void**)&d_t, n * 4)); HIP_OK(hipMalloc((void**)&d_u, n * 4)); HIP_OK(hipMalloc((void**)&d_v, n * 4));
-    HIP_OK(hipMalloc((void**)&d_m, n * 4)); HIP_OK(hipMalloc((void**)&d_tr, n * 4));
+    DevBuf b_o, b_d, b_t, b_u, b_v, b_m, b_tr;
+    HIP_OK(b_o.alloc(3 * n * 4)); HIP_OK(b_d.alloc(3 * n * 4));
+    HIP_OK(b_t.alloc(n * 4)); HIP_OK(b_u.alloc(n * 4)); HIP_OK(b_v.alloc(n * 4));
+    HIP_OK(b_m.alloc(n * 4)); HIP_OK(b_tr.alloc(n * 4));
+    float *d_o = b_o.as<float>(), *d_d = b_d.as<float>(), *d_t = b_t.as<float>(), *d_u = b_u.as<float>(), *d_v = b_v.as<float>();
+    int *d_m = b_m.as<int>(), *d_tr = b_tr.as<int>();
     HIP_OK(hipMemcpy(d_o, origins, 3 * n * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_d, directions, 3 * n * 4, hipMemcpyHostToDevice));
     size_t lds = traversal_lds_bytes(ctx, false, 256, false);
     StackConf stc;
     { int r = stack_conf(ctx, (n + 255) / 256 * 256, &stc); if (r != RL_OK) return r; }
     hipLaunchKernelGGL(k_trace_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, ctx->stream, ctx->ds, stc, (unsigned)n, d_o, d_d, d_t, d_u, d_v, d_m, d_tr);
-    HIP_OK(hipStreamSynchronize(ctx->stream));
     HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(ctx->stream));
     HIP_OK(hipMemcpy(t_out, d_t, n * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(u_out, d_u, n * 4, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(v_out, d_v, n * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(mesh_out, d_m, n * 4, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(tri_out, d_tr, n * 4, hipMemcpyDeviceToHost));
-    hipFree(d_o); hipFree(d_d); hipFree(d_t); hipFree(d_u); hipFree(d_v); hipFree(d_m); hipFree(d_tr);
     return RL_OK;
 }
 
 extern "C" int rl_visible_batch(rl_context* ctx, size_t n, const float* p0, const float* p1, uint8_t* visible_out) {
     if (!ctx || (n && (!p0 || !p1 || !visible_out))) return RL_ERR_INVALID_ARGUMENT;
     if (n == 0) return RL_OK;
+    if (n > kMaxBatch) { rl_set_error("batch too large"); return RL_ERR_INVALID_ARGUMENT; }
     HIP_OK(hipSetDevice(ctx->device));
-    float *d_a, *d_b; unsigned char* d_o;
-    HIP_OK(hipMalloc((void**)&d_a, 3 * n * 4)); HIP_OK(hipMalloc((void**)&d_b, 3 * n * 4)); HIP_OK(hipMalloc((void**)&d_o, n));
+    DevBuf b_a, b_b, b_o;
+    HIP_OK(b_a.alloc(3 * n * 4)); HIP_OK(b_b.alloc(3 * n * 4)); HIP_OK(b_o.alloc(n));
+    float *d_a = b_a.as<float>(), *d_b = b_b.as<float>(); unsigned char* d_o = b_o.as<unsigned char>();
     HIP_OK(hipMemcpy(d_a, p0, 3 * n * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_b, p1, 3 * n * 4, hipMemcpyHostToDevice));
     size_t lds = traversal_lds_bytes(ctx, false, 256, false);
     StackConf stc;
     { int r = stack_conf(ctx, (n + 255) / 256 * 256, &stc); if (r != RL_OK) return r; }
     hipLaunchKernelGGL(k_visible_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, ctx->stream, ctx->ds, stc, (unsigned)n, d_a, d_b, d_o);
-    HIP_OK(hipStreamSynchronize(ctx->stream));
     HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(ctx->stream));
     HIP_OK(hipMemcpy(visible_out, d_o, n, hipMemcpyDeviceToHost));
-    hipFree(d_a); hipFree(d_b); hipFree(d_o);
     return RL_OK;
 }
 
@@ -1086,15 +1109,17 @@ extern "C" int rl_visible_batch(rl_context* ctx, size_t n, const float* p0, cons
 extern "C" int rl_debug_numerics(int device, size_t n, const float* a, const float* b, float* out8) {
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return RL_ERR_NO_DEVICE;
+    if (n > kMaxBatch / 16) return RL_ERR_INVALID_ARGUMENT;
     HIP_OK(hipSetDevice(device));
-    float *d_a, *d_b, *d_out;
-    HIP_OK(hipMalloc((void**)&d_a, n * 4)); HIP_OK(hipMalloc((void**)&d_b, n * 4)); HIP_OK(hipMalloc((void**)&d_out, 10 * n * 4));
+    DevBuf b_a, b_b, b_out;
+    HIP_OK(b_a.alloc(n * 4)); HIP_OK(b_b.alloc(n * 4)); HIP_OK(b_out.alloc(10 * n * 4));
+    float *d_a = b_a.as<float>(), *d_b = b_b.as<float>(), *d_out = b_out.as<float>();
     HIP_OK(hipMemcpy(d_a, a, n * 4, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(d_b, b, n * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_numerics_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (unsigned)n, d_a, d_b, d_out, d_out + n, d_out + 2 * n,
                        d_out + 3 * n, d_out + 4 * n, d_out + 5 * n, d_out + 6 * n, d_out + 7 * n, d_out + 8 * n, d_out + 9 * n);
+    HIP_OK(hipGetLastError());
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemcpy(out8, d_out, 10 * n * 4, hipMemcpyDeviceToHost));
-    hipFree(d_a); hipFree(d_b); hipFree(d_out);
     return RL_OK;
 }
 

@@ -35,9 +35,17 @@ def shard_of(rank: int, world: int):
 
 
 def reduce_framebuffer(fb: torch.Tensor, dst: int = 0) -> torch.Tensor:
-    """The single exchange step: sum the per-rank framebuffers onto `dst`."""
+    """The single exchange step: sum the per-rank framebuffers onto `dst` (ncclReduce over xGMI with backend "nccl").
+    gloo cannot reduce device tensors: in the shared-device plumbing mode (more ranks than GPUs) the buffer is staged
+    through the host — same sum, same bits."""
     if is_dist():
-        dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
+        if fb.is_cuda and dist.get_backend() != "nccl":
+            host = fb.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+            if dist.get_rank() == dst:
+                fb.copy_(host)
+        else:
+            dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
     return fb
 
 
@@ -63,6 +71,15 @@ def sum_over_ranks(d: dict) -> dict:
     t = torch.tensor([float(d[k]) for k in keys], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return {k: float(v) for k, v in zip(keys, t.tolist())}
+
+
+def gather_objects(obj):
+    """Every rank's `obj`, in rank order, on every rank (rank / device report of bench.py)."""
+    if not is_dist():
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
 
 
 def finalize():

@@ -554,3 +554,117 @@ def test_full_size_properties(built):
         ref, _ = osc.render(seeds=seeds, spp=4, stream_mode=1, eval_order=1, shard_index=bidx, shard_count=120 * 68)
         x0, y0 = (bidx // 68) * 16, (bidx % 68) * 16
         np.testing.assert_array_equal(a[y0:y0 + 16, x0:x0 + 16], ref[y0:y0 + 16, x0:x0 + 16])
+
+
+def _oracle_blocks_match(sd, osc, img, seeds, blocks, **okw):
+    """`blocks`: indices b = (x/16) * ceil(H/16) + y/16 — each is rendered alone by the oracle (a shard of one block) and compared bit for bit."""
+    nby = (sd.height + 15) // 16
+    nb = ((sd.width + 15) // 16) * nby
+    verts = 0
+    for b in blocks:
+        ref, ost = osc.render(seeds=seeds, stream_mode=1, eval_order=1, shard_index=int(b), shard_count=nb, **okw)
+        x0, y0 = (b // nby) * 16, (b % nby) * 16
+        np.testing.assert_array_equal(img[y0:y0 + 16, x0:x0 + 16], ref[y0:y0 + 16, x0:x0 + 16], err_msg=f"block {b} at ({x0}, {y0})")
+        verts += ost["vertices"]
+    return verts
+
+
+def _busiest_blocks(img, n):
+    """The n 16x16 blocks with the largest pixel variance (geometry edges, glass, caustic noise) — 'blocks over geometry'."""
+    H, W = img.shape[:2]
+    nby = (H + 15) // 16
+    lum = img.sum(-1)
+    scores = []
+    for bx in range((W + 15) // 16):
+        for by in range(nby):
+            t = lum[by * 16:by * 16 + 16, bx * 16:bx * 16 + 16]
+            scores.append((float(np.var(t)) if np.isfinite(t).all() else 0.0, bx * nby + by))
+    scores.sort(reverse=True)
+    return [b for _, b in scores[:n]]
+
+
+def test_full_size_mixed_materials(built):
+    """BASELINE cfg 3 at full size (1920x1080, 508 k triangles, 6 BSDF types; 4 spp): deep BVH streamed from L2 / HBM, global stack
+    overflow levels, the dynamic pixel dispenser and the run-time BSDF switch at scale.  fused == wavefront (material sort) bitwise
+    with equal counters, and 6 blocks over geometry equal the oracle's bits (src/accel.rs:243-343)."""
+    sd = scenes.living_room(1920, 1080)
+    assert sd.n_triangles > 500000
+    ctx = api.Context(api.Scene(sd), 0)
+    assert not ctx.debug_sizes()["lds_scene"]
+    seeds = api.IndependentSampler(0).block_seeds(1920, 1080)
+    a, st = ctx.render(seeds, api.path_params(spp=4))
+    assert st["iterations"] == 1                                   # auto = the persistent fused kernel
+    c, stc = ctx.render(seeds, api.path_params(spp=4, pipeline=api.PIPELINE_WAVEFRONT))
+    np.testing.assert_array_equal(a, c)
+    assert all(st[k] == stc[k] for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws"))
+    assert st["camera_samples"] == 1920 * 1080 * 4 and np.isfinite(a).all()
+    osc = orc.Scene(sd)
+    blocks = _busiest_blocks(a, 4) + [60 * 68 + 34, 30 * 68 + 50]
+    assert _oracle_blocks_match(sd, osc, a, seeds, blocks, spp=4) > 4000
+
+
+def test_full_size_medium(built):
+    """BASELINE cfg 5 at full size (cbox + homogeneous medium sigma_s = 0.5, 1920x1080, 2 spp; mean path length ~19 vertices):
+    fused (pixel dispenser) == wavefront bitwise, counters equal, 6 blocks equal the oracle's bits (src/volume.rs:95-141)."""
+    sd = scenes.cbox_medium(1920, 1080, 0.5)
+    ctx = api.Context(api.Scene(sd), 0)
+    seeds = api.IndependentSampler(0).block_seeds(1920, 1080)
+    a, st = ctx.render(seeds, api.path_params(spp=2))
+    c, stc = ctx.render(seeds, api.path_params(spp=2, pipeline=api.PIPELINE_WAVEFRONT))
+    np.testing.assert_array_equal(a, c)
+    assert all(st[k] == stc[k] for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws"))
+    assert st["vertices"] > 10 * st["camera_samples"] and np.isfinite(a).all()
+    osc = orc.Scene(sd)
+    blocks = _busiest_blocks(a, 4) + [60 * 68 + 34, 10 * 68 + 5]
+    assert _oracle_blocks_match(sd, osc, a, seeds, blocks, spp=2) > 20000
+
+
+def test_cfg1_reference_order_whole_frame(built):
+    """BASELINE cfg 1 exactly: cbox 256x256x16 spp in RL_STREAM_REFERENCE_ORDER — the one mode that is rustlight's own stream
+    assignment (one SmallRng per 16x16 block consumed over (iy, ix, sample), src/integrators/mod.rs:357-371,420-435) — whole frame
+    against the oracle, both pipelines."""
+    sd = scenes.cbox(256, 256)
+    ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+    ref_fwd, ost = osc.render(master_seed=0, spp=16, stream_mode=0, eval_order=1)
+    ref_rec, _ = osc.render(master_seed=0, spp=16, stream_mode=0, eval_order=0)
+    for pipeline in (api.PIPELINE_AUTO, api.PIPELINE_FUSED):
+        img, st = ctx.render(api.IndependentSampler(0).block_seeds(256, 256), api.path_params(spp=16, stream_mode=api.STREAM_REFERENCE_ORDER, pipeline=pipeline))
+        _assert_parity(img, st, ref_fwd, ref_rec, ost)
+    assert st["camera_samples"] == 256 * 256 * 16
+
+
+def test_multi_context_rccl_reduce(built, cbox64, ctx_cbox):
+    """rl_multi_*: N shards from ONE process — one device context + host thread per shard, per-device framebuffers in HBM, shards that
+    share a device added on the device, ONE ncclReduce over the distinct devices (a 1-rank clique on this box: the RCCL call path
+    itself runs), one download.  The image is the single-context image bit for bit, counters add up."""
+    seeds = api.IndependentSampler(5).block_seeds(64, 64)
+    full, st = ctx_cbox.render(seeds, api.path_params(spp=4))
+    scene = api.Scene(cbox64)
+    for n in (1, 3):
+        mc = api.MultiContext(scene, n)
+        info = mc.info()
+        assert info["shards"] == n and info["comm_ranks"] >= 1 and info["rccl_version"] > 0
+        img, mst = mc.render(seeds, api.path_params(spp=4))
+        np.testing.assert_array_equal(img, full)
+        assert all(mst[k] == st[k] for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws"))
+        mc.close()
+
+
+def test_bench_two_ranks_on_one_gpu(built):
+    """`python bench.py --gpus 2` starts its own two ranks; on a one-GPU box they share the device and reduce through gloo (plumbing
+    mode, flagged).  Both ranks render their tiles with the KERNELS; the reduced image must carry the CRC of the 1-GPU render."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--width", "320", "--height", "200", "--spp", "4", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["distributed"]["world_size"] == 2 and len(out["distributed"]["ranks"]) == 2
+    assert out["distributed"]["crc_match"] is True and out["config"]["spp_total"] == 8
+    assert out["value"] > 0 and out["roofline"]["kernel"] == "k_path_fused"
