@@ -12,7 +12,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "librustlight_amd.so")
 BIN = os.path.join(LIB_DIR, "rustlight-amd")
 
-HIP_SOURCES = ["kernels/wavefront.hip", "host/multigpu.hip"]     # multigpu.hip: N device contexts + the RCCL framebuffer reduce
+HIP_SOURCES = ["kernels/wavefront.hip", "kernels/fused_lds.hip", "kernels/fused_stream.hip", "kernels/shade.hip", "kernels/mc.hip", "host/multigpu.hip"]     # multigpu.hip: N device contexts + the RCCL framebuffer reduce
 CXX_SOURCES = ["host/scene.cpp", "host/bvh.cpp", "host/io.cpp", "host/pbrt.cpp", "host/meshio.cpp", "host/mitsuba.cpp", "host/lighttree.cpp"]
 # -ffp-contract=off: rustlight's f32 arithmetic is never contracted into FMAs
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-value", "-Wno-unused-function"]
@@ -21,6 +21,11 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unus
 HIP_EXTRA = ["-fno-slp-vectorize"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXX = os.environ.get("CXX", "g++")
+
+
+def extra_hip_flags():
+    """Dev builds: RL_HIP_FLAGS="-DRL_STAGE_TIMERS ..." adds flags to every kernel translation unit."""
+    return [f for f in os.environ.get("RL_HIP_FLAGS", "").split() if f]
 
 
 def _deps():
@@ -43,21 +48,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
     deps = _deps()
     if not force and not _stale(LIB, deps) and not _stale(BIN, deps):
         return LIB
-    objs = []
+    # every translation unit is independent: compile them side by side (the kernel families take ~1 min each)
+    jobs = []
     for src in HIP_SOURCES:
         obj = os.path.join(LIB_DIR, os.path.basename(src) + ".o")
-        cmd = [HIPCC, "--offload-arch=gfx950", *COMMON, *HIP_EXTRA, "-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        objs.append(obj)
+        jobs.append((obj, [HIPCC, "--offload-arch=gfx950", *COMMON, *HIP_EXTRA, *extra_hip_flags(), "-c", os.path.join(CSRC, src), "-o", obj]))
     for src in CXX_SOURCES:
         obj = os.path.join(LIB_DIR, os.path.basename(src) + ".o")
-        cmd = [CXX, *COMMON, "-c", os.path.join(CSRC, src), "-o", obj]
+        jobs.append((obj, [CXX, *COMMON, "-c", os.path.join(CSRC, src), "-o", obj]))
+
+    def run(job):
         if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        objs.append(obj)
+            print(" ".join(job[1]))
+        subprocess.check_call(job[1])
+        return job[0]
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(run, jobs))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-o", LIB, *objs, "-lz", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     # the CLI (examples/cli.rs counterpart)

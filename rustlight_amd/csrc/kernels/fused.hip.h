@@ -1,0 +1,123 @@
+// fused.hip.h — k_path_fused, the persistent form of the pipeline, and its launcher; instantiated by fused_lds.hip (scene staged in LDS)
+// and fused_stream.hip (BVH streamed from L2 / HBM) so that the two families compile in parallel.
+#pragma once
+
+namespace rl {
+
+// ------------------------------------------------------------------------------------------
+// k_path_fused<MAT, MEDIUM, LDS> — the persistent form of the pipeline for scenes with one BSDF type: one
+// launch, one lane per pixel item, the four stage functions above run back-to-back per iteration
+// (raygen -> extend -> shade -> shadow) with the whole path state in registers (RegState) and the scene +
+// traversal stacks in LDS.  Same functions, same order of operations, same results as the wavefront kernels;
+// what disappears is ~1.4 KB/sample of state traffic through HBM and ~2000 kernel boundaries per render.
+#ifdef RL_STAGE_TIMERS
+__device__ unsigned long long g_stage_timers[16];
+#endif
+template <int MAT, bool MEDIUM, bool LDS_SCENE, int LIGHTS>
+__global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAVES_STREAMING) k_path_fused(RenderConst rc, DeviceScene sc, StackConf stc) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    SceneRecs recs;
+    float4* after_scene = smem;
+    if (LDS_SCENE) {
+        stage_scene_lds(sc, smem, smem + 4 * sc.n_nodes);
+        recs.nodes = smem; recs.tris = smem + 4 * sc.n_nodes;
+        after_scene = smem + 4 * (sc.n_nodes + sc.n_prims);
+    } else {
+        recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
+        recs.tris = reinterpret_cast<const float4*>(sc.tris);
+    }
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+    // LDS: [scene][cold path state (u64 | f32 | u32 planes)][per-lane stacks]
+    unsigned long long* cold_q = reinterpret_cast<unsigned long long*>(after_scene);
+    float* cold_f = reinterpret_cast<float*>(cold_q + 256 * FusedState::kColdQ);
+    unsigned* cold_u = reinterpret_cast<unsigned*>(cold_f + 256 * FusedState::kColdF);
+    const TravStackT<LDS_SCENE> stack = make_stack<LDS_SCENE>(stc, cold_u + 256 * FusedState::kColdU, tid);
+    FusedState ps;
+    ps.cold_q = cold_q + threadIdx.x; ps.cold_f = cold_f + threadIdx.x; ps.cold_u = cold_u + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < F_COUNT; i++) ps.fv[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < U_COUNT; i++) ps.uv[i] = 0u;
+#pragma unroll
+    for (int i = 0; i < Q_COUNT; i++) ps.qv[i] = 0ull;
+    storec(ps, F_AR, czero());
+    PU(U_CURSOR) = 0u; PU(U_SAMPLE) = 0u;
+    PU(U_ITEM) = tid;
+    PU(U_PRIM) = 0xffffffffu;
+    PU(U_FLAGS) = tid < rc.n_items ? (ST_REGEN | ST_FRESH) : ST_FINISHED;
+    unsigned n_samples = 0, n_draws = 0, n_vertices = 0, n_shadow = 0, n_ext = 0;
+#ifdef RL_STAGE_TIMERS
+    unsigned long long tm[4] = {0, 0, 0, 0}, ln[5] = {0, 0, 0, 0, 0};
+#define RL_T0 { t0 = __builtin_readcyclecounter(); }
+#define RL_T1(K, COND) { unsigned long long t1 = __builtin_readcyclecounter(); tm[K] += t1 - t0; ln[K] += __popcll(__ballot(COND)); t0 = t1; }
+    unsigned long long t0;
+#else
+#define RL_T0
+#define RL_T1(K, COND)
+#endif
+    while (!(PU(U_FLAGS) & ST_FINISHED)) {
+        RL_T0
+#ifdef RL_STAGE_TIMERS
+        ln[4] += 64;
+        const bool c0 = PU(U_FLAGS) & ST_REGEN;
+#endif
+        if (PU(U_FLAGS) & ST_REGEN) raygen_slot<true>(rc, sc, ps, n_samples, n_draws);   // work items from the global dispenser
+        RL_T1(0, c0)
+#ifdef RL_STAGE_TIMERS
+        const bool c1 = PU(U_FLAGS) & ST_RAY;
+#endif
+        if (PU(U_FLAGS) & ST_RAY) {
+            extend_slot(sc, recs, stack, ps);
+            RL_T1(1, c1)
+            shade_slot<MAT, MEDIUM, LIGHTS>(rc, sc, ps, PU(U_FLAGS), n_vertices, n_draws, n_shadow, n_ext);
+        }
+        RL_T1(2, c1)
+#ifdef RL_STAGE_TIMERS
+        const bool c3 = PU(U_FLAGS) & ST_SHADOW;
+#endif
+        if (PU(U_FLAGS) & ST_SHADOW) shadow_slot(sc, recs, stack, ps);
+        RL_T1(3, c3)
+    }
+#ifdef RL_STAGE_TIMERS
+    if ((threadIdx.x & 63u) == 0u) { for (int k = 0; k < 4; k++) { atomicAdd(&g_stage_timers[k], tm[k]); atomicAdd(&g_stage_timers[4 + k], ln[k]); } atomicAdd(&g_stage_timers[8], ln[4]); }
+#endif
+    {
+        const int which[5] = {STAT_SAMPLES, STAT_VERTICES, STAT_DRAWS, STAT_SHADOW_RAYS, STAT_EXT_RAYS};
+        const unsigned vals[5] = {n_samples, n_vertices, n_draws, n_shadow, n_ext};
+        block_stats<5>(rc.partials, which, vals);
+    }
+}
+
+
+template <bool LDS_SCENE, int MAT>
+static void launch_fused_mat(bool medium, bool area_only, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc) {
+    if (medium) { if (area_only) hipLaunchKernelGGL((k_path_fused<MAT, true, LDS_SCENE, LIGHTS_AREA_ONLY>), grid, block, lds_bytes, st, rc, ds, stc);
+                  else hipLaunchKernelGGL((k_path_fused<MAT, true, LDS_SCENE, LIGHTS_ANY>), grid, block, lds_bytes, st, rc, ds, stc); }
+    else { if (area_only) hipLaunchKernelGGL((k_path_fused<MAT, false, LDS_SCENE, LIGHTS_AREA_ONLY>), grid, block, lds_bytes, st, rc, ds, stc);
+           else hipLaunchKernelGGL((k_path_fused<MAT, false, LDS_SCENE, LIGHTS_ANY>), grid, block, lds_bytes, st, rc, ds, stc); }
+}
+template <bool LDS_SCENE>
+static void launch_fused_impl(int mat, bool medium, bool area_only, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc) {
+    switch (mat) {
+        case BSDF_DIFFUSE: launch_fused_mat<LDS_SCENE, BSDF_DIFFUSE>(medium, area_only, grid, block, lds_bytes, st, rc, ds, stc); break;
+        case BSDF_PHONG: launch_fused_mat<LDS_SCENE, BSDF_PHONG>(medium, area_only, grid, block, lds_bytes, st, rc, ds, stc); break;
+        case BSDF_METAL: launch_fused_mat<LDS_SCENE, BSDF_METAL>(medium, area_only, grid, block, lds_bytes, st, rc, ds, stc); break;
+        case BSDF_GLASS: launch_fused_mat<LDS_SCENE, BSDF_GLASS>(medium, area_only, grid, block, lds_bytes, st, rc, ds, stc); break;
+        case -1: launch_fused_mat<LDS_SCENE, -1>(medium, area_only, grid, block, lds_bytes, st, rc, ds, stc); break;      // several BSDF types: run-time switch per vertex
+        default: launch_fused_mat<LDS_SCENE, BSDF_SUBSTRATE>(medium, area_only, grid, block, lds_bytes, st, rc, ds, stc); break;
+    }
+}
+template <bool LDS_SCENE>
+static void dump_stage_timers_impl() {
+#ifdef RL_STAGE_TIMERS
+    // dev-only build: per-stage cycle shares and active-lane fractions of the fused loop
+    unsigned long long h[16];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stage_timers), sizeof(h));
+    const double tot = (double)(h[0] + h[1] + h[2] + h[3]);
+    const char* names[4] = {"raygen", "extend", "shade", "shadow"};
+    for (int k = 0; k < 4; k++) std::fprintf(stderr, "[stage] %-7s cycles %5.1f %%  lanes %5.1f %%\n", names[k], 100.0 * h[k] / tot, 100.0 * h[4 + k] / (double)h[8]);
+    std::memset(h, 0, sizeof(h)); hipMemcpyToSymbol(HIP_SYMBOL(g_stage_timers), h, sizeof(h));
+#endif
+}
+
+}  // namespace rl

@@ -1,0 +1,23 @@
+// launch.h — host-side launchers of the kernel families that live in their own translation units (fused_lds.hip, fused_stream.hip,
+// shade.hip, mc.hip), so that the families compile in parallel.  Launch errors are picked up by the caller's hipGetLastError().
+#pragma once
+
+namespace rl {
+
+// IntegratorAO / IntegratorDirect parameters (ao.rs:4-7, direct.rs:5-8)
+struct McConst {
+    int has_max_distance; float max_distance; int normal_correction;
+    unsigned nb_bsdf_samples, nb_light_samples;
+};
+
+// mat: the scene's one BSDF type, or -1 = run-time switch per vertex.  area_only: every emitter is a mesh area light and there is no light
+// tree (the NEE code of the other emitter kinds is compiled out: same results, 84 -> 21 spilled VGPRs on the diffuse Cornell box)
+void launch_fused_lds(int mat, bool medium, bool area_only, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc);
+void launch_fused_stream(int mat, bool medium, bool area_only, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc);
+void launch_shade_type(int type, bool medium, dim3 grid, dim3 block, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const Pool& pool);
+void launch_shade_sorted(bool medium, unsigned chunks, dim3 grid, dim3 block, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const Pool& pool);
+void launch_pixel_mc(int kind, bool lds_scene, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc, const McConst& mp);
+void dump_stage_timers(bool lds_scene);   // dev-only (-DRL_STAGE_TIMERS)
+void dump_stage_timers_stream();
+
+}  // namespace rl

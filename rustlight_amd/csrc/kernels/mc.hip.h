@@ -1,5 +1,5 @@
 // mc.hip.h — device side of the `ao` and `direct` integrators (ao.rs:20-70, direct.rs:21-233).
-// Part of the single translation unit wavefront.hip (included once, after devmath / shading / trace).
+// Included by mc.hip after common.hip.h (McConst: launch.h).
 #pragma once
 
 namespace rl {
@@ -9,10 +9,6 @@ namespace rl {
 // (pixel, or block in reference-order mode), samples folded in order:
 //   KIND 0  IntegratorAO::compute_pixel      src/integrators/ao.rs:20-70
 //   KIND 1  IntegratorDirect::compute_pixel  src/integrators/direct.rs:21-233 (power heuristic, mod.rs:462-478)
-struct McConst {
-    int has_max_distance; float max_distance; int normal_correction;
-    unsigned nb_bsdf_samples, nb_light_samples;
-};
 RL_DEV float mis_weight_power(float pdf_a, float pdf_b) {
     if (pdf_a == 0.0f) return 0.0f;
     if (!finite_f(pdf_a) || !finite_f(pdf_b)) return 0.0f;

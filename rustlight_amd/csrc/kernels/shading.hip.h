@@ -578,8 +578,12 @@ RL_DEV float ats_pdf(const DeviceScene& sc, unsigned int leaf, V3 p, bool has_n,
 
 // EmitterSampler::sample_light (src/emitter.rs:1604-1639) -> Emitter::direct_sample of the emitter picked from the flux cdf,
 // or direct_sample_tri of the (emitter, triangle) picked by the light tree.  `n`: Some(&its.n_s) at surfaces, None in the medium.
+// LIGHTS: what the scene's emitter set may contain, known when the kernel is picked — LIGHTS_AREA_ONLY compiles the light tree, point,
+// directional and environment code out of the caller (the emitter kinds are then not even looked at); results are those of LIGHTS_ANY.
+enum { LIGHTS_ANY = 0, LIGHTS_AREA_ONLY = 1 };
+template <int LIGHTS = LIGHTS_ANY>
 RL_DEV LightSample sample_light(const DeviceScene& sc, V3 p, bool has_n, V3 n, float r_sel, float r, V2 uv) {
-    if (sc.ats_root >= 0) {
+    if (LIGHTS != LIGHTS_AREA_ONLY && sc.ats_root >= 0) {
         float pdf_sel;
         int li = ats_sample(sc, r_sel, p, has_n, n, &pdf_sel);
         LightSample ls;
@@ -593,8 +597,8 @@ RL_DEV LightSample sample_light(const DeviceScene& sc, V3 p, bool has_n, V3 n, f
     float pdf_sel = sc.emitters_cdf[id + 1] - sc.emitters_cdf[id];
     const EmitterRecord em = sc.emitters[id];
     LightSample ls;
-    ls.kind = em.kind;
-    if (em.kind == EMITTER_MESH) {
+    ls.kind = LIGHTS == LIGHTS_AREA_ONLY ? (int)EMITTER_MESH : em.kind;
+    if (LIGHTS == LIGHTS_AREA_ONLY || em.kind == EMITTER_MESH) {
         // Mesh::direct_sample -> Mesh::sample: triangle by area cdf, pdf = Area(1 / cdf.total()) (emitter.rs:652-688, geometry.rs:340-348)
         MeshRecord mr = sc.meshes[em.mesh];
         unsigned int prim = cdf_sample(sc.mesh_cdf + mr.cdf_base, mr.n_tris + 1, r);
@@ -634,9 +638,10 @@ RL_DEV LightSample sample_light(const DeviceScene& sc, V3 p, bool has_n, V3 n, f
 // EmitterSampler::direct_pdf for a mesh light hit by a BSDF-sampled ray (emitter.rs:571-589, 1566-1603).  With the light
 // tree: pdf of the hit triangle (1 / its area) x the probability of reaching its leaf; `n` as the caller passes it
 // (None from the path tracer's MIS, Some(&its.n_s) from `direct`).
+template <int LIGHTS = LIGHTS_ANY>
 RL_DEV float light_direct_pdf(const DeviceScene& sc, const MeshRecord& mr, int prim_in_mesh, V3 o, V3 p, V3 n, V3 dir, bool has_ns, V3 ns) {
     float cos_light = rmax(dot(n, -dir), 0.0f);
-    if (sc.ats_root >= 0) {
+    if (LIGHTS != LIGHTS_AREA_ONLY && sc.ats_root >= 0) {
         float tri = 0.0f;
         if (cos_light != 0.0f) {
             float geom = div_rn(cos_light, length2(p - o));

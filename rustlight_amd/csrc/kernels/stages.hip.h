@@ -155,7 +155,7 @@ RL_DEV void shadow_slot(const DeviceScene& sc, const SceneRecs& recs, const Stac
 
 // shade_slot<MAT, MEDIUM> — one path vertex of one slot.  MAT >= 0: the hit material is known to have that
 // BSDF type (per-BSDF code path, uniform over the calling lanes); MAT = -1: generic (run-time switch).
-template <int MAT, bool MEDIUM, class PS>
+template <int MAT, bool MEDIUM, int LIGHTS = LIGHTS_ANY, class PS>
 RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, unsigned flags,
                        unsigned& n_vertices, unsigned& n_draws, unsigned& n_shadow, unsigned& n_ext) {
     n_ext += 1;      // every shaded slot carried exactly one extension ray through k_extend
@@ -189,7 +189,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
         ended = true;
         // A zero term is still added as beta * 0: with a NaN / infinite throughput (hostile textures) the reference's recursion turns the
         // whole sample into NaN through `weight * evaluate(next)`, and the forward form keeps that by not skipping the product.
-        Col contrib = (w_edge * rr) * (sc.env_emitter >= 0 ? env_eval(sc, rd) : czero());      // enviroment_luminance is black without an environment
+        Col contrib = (w_edge * rr) * (LIGHTS != LIGHTS_AREA_ONLY && sc.env_emitter >= 0 ? env_eval(sc, rd) : czero());      // enviroment_luminance is black without an environment
         const bool add_contrib = rc.has_min ? (depth - 1u) >= rc.min_depth : true;
         if (prev == PREV_SENSOR) {
             if (!is_zero(contrib) && add_contrib) L = L + contrib;
@@ -200,7 +200,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
                 float wmis = 1.0f;
                 if (rc.strategy == RL_STRATEGY_ALL && (flags & ST_PDF_SA)) {
                     // pdf_emitter, `None` next vertex: direct_pdf of the environment (emitters.rs:18-46)
-                    float p2 = (prev == PREV_SURFACE || prev == PREV_VOLUME) ? env_direct_pdf(sc, rd) : 0.0f;
+                    float p2 = (LIGHTS != LIGHTS_AREA_ONLY && (prev == PREV_SURFACE || prev == PREV_VOLUME)) ? env_direct_pdf(sc, rd) : 0.0f;
                     float total = (0.0f + pdf_edge) + p2;
                     wmis = div_rn(pdf_edge, total);
                 }
@@ -237,7 +237,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
                     // LightSamplingStrategy::pdf -> pdf_emitter (strategies/emitters.rs:10-92,250-282)
                     float p2 = 0.0f;
                     if (!is_volume && (mr.flags & MESH_IS_LIGHT) && (prev == PREV_SURFACE || prev == PREV_VOLUME))
-                        p2 = light_direct_pdf(sc, mr, sc.tris[prim].tri, ro, sp.p, sp.n_g, rd, false, mk3(0.0f, 0.0f, 0.0f));   // n = None (emitters.rs:52-57)
+                        p2 = light_direct_pdf<LIGHTS>(sc, mr, sc.tris[prim].tri, ro, sp.p, sp.n_g, rd, false, mk3(0.0f, 0.0f, 0.0f));   // n = None (emitters.rs:52-57)
                     float total = (0.0f + pdf_edge) + p2;
                     wmis = div_rn(pdf_edge, total);                             // balance heuristic (path.rs:80-98)
                 }
@@ -303,7 +303,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
                 V2 c; c.x = rng_next_f32(rng); c.y = rng_next_f32(rng);
                 n_draws += 4;
                 n_shadow += 1;     // the reference always traces the shadow ray (emitters.rs:125-126)
-                LightSample ls = sample_light(sc, vp, !is_volume, is_volume ? mk3(0.0f, 0.0f, 0.0f) : sp.n_s, a, b, c);   // Some(&its.n_s) | None
+                LightSample ls = sample_light<LIGHTS>(sc, vp, !is_volume, is_volume ? mk3(0.0f, 0.0f, 0.0f) : sp.n_s, a, b, c);   // Some(&its.n_s) | None
                 if (ls.pdf != 0.0f) {
                     Col wl;
                     float p_dir;
@@ -314,7 +314,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
                         // the MIS pdf is asked along Edge::from_vertex's own direction (p_light - p) / |..| (edge.rs:37-39):
                         // bitwise equal to ls.d for mesh lights, recomputed for the environment
                         V3 wo_edge = wo;
-                        if (ls.kind == EMITTER_ENV) { V3 ed = ls.p - vp; ed = ed / length(ed); wo_edge = to_local(sp.frame, ed); }
+                        if (LIGHTS != LIGHTS_AREA_ONLY && ls.kind == EMITTER_ENV) { V3 ed = ls.p - vp; ed = ed / length(ed); wo_edge = to_local(sp.frame, ed); }
                         p_dir = bsdf_pdf<MAT>(sc, *mat, sp.has_uv, sp.uv, sp.wi, wo_edge, false);
                     }
                     if (MEDIUM) {
@@ -327,7 +327,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
                         Col term = czero();
                         if (!is_zero(c_l) && add_l) {
                             float wmis = 1.0f;
-                            if (rc.strategy == RL_STRATEGY_ALL && ls.pdf_kind == PDF_SOLID_ANGLE) {   // Discrete (point / directional): no MIS
+                            if (rc.strategy == RL_STRATEGY_ALL && (LIGHTS == LIGHTS_AREA_ONLY || ls.pdf_kind == PDF_SOLID_ANGLE)) {   // Discrete (point / directional): no MIS
                                 float total = (0.0f + p_dir) + ls.pdf;
                                 wmis = div_rn(ls.pdf, total);
                             }

@@ -35,16 +35,9 @@
 #include <string>
 #include <vector>
 
-#include "../../../include/rustlight_amd.h"
-#include "../device_types.h"
+#include "common.hip.h"
 #include "../host/scene.h"
-#include "devmath.hip.h"
-#include "shading.hip.h"
-#include "trace.hip.h"
 #include "wavefront.h"
-#include "pathstate.hip.h"
-#include "stages.hip.h"
-#include "mc.hip.h"
 
 namespace rl {
 
@@ -158,229 +151,6 @@ __global__ void __launch_bounds__(256) k_extend(RenderConst rc, DeviceScene sc, 
 template <bool LDS_SCENE>
 __global__ void __launch_bounds__(256) k_shadow(RenderConst rc, DeviceScene sc, Pool pool, StackConf stc) { trace_kernel_body<LDS_SCENE, true>(sc, pool, stc); }
 
-// k_shade<MAT, MEDIUM>: scenes with a single BSDF type — every live slot goes straight to that BSDF's code.
-template <int MAT, bool MEDIUM>
-__global__ void __launch_bounds__(256) k_shade(RenderConst rc, DeviceScene sc, Pool pool) {
-    unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned n_vertices = 0, n_draws = 0, n_shadow = 0, n_ext = 0;
-    PoolState ps{pool, slot};
-    unsigned flags = slot < pool.P ? PU(U_FLAGS) : 0u;
-    if (flags & ST_RAY) shade_slot<MAT, MEDIUM>(rc, sc, ps, flags, n_vertices, n_draws, n_shadow, n_ext);
-    {
-        const int which[4] = {STAT_VERTICES, STAT_DRAWS, STAT_SHADOW_RAYS, STAT_EXT_RAYS};
-        const unsigned vals[4] = {n_vertices, n_draws, n_shadow, n_ext};
-        block_stats<4>(rc.partials, which, vals);
-    }
-}
-
-// k_shade_sorted<MEDIUM>: mixed-material scenes.  Stream compaction + material sort with wave64 ballot and
-// prefix popcounts, local to the workgroup's 256 slots (no global atomics, no queue in HBM): live slots are
-// binned by the BSDF type of the surface they hit, then each BSDF's code runs once over its packed bin, so
-// a wave never mixes two BSDFs.
-static constexpr int kNumBins = 5;
-// CHUNKS: 256-slot chunks of the pool per workgroup.  With sample-parallel pixels on a scene most camera rays miss, only one
-// slot in eight carries a vertex; one chunk would leave a single part-filled wave per workgroup (and this kernel's register
-// footprint allows 3 workgroups per CU), so sparse pools are gathered four chunks at a time into full waves
-// (508 k-triangle scene, 128 spp: 781 -> 645 ms; the traversal kernels gain nothing from the same trick).
-// 3 waves/SIMD (168 VGPRs, 11 spilled) beat the unconstrained 182-VGPR build at 2 waves and a 128-VGPR build at 4 (647 / 621 / 653 ms)
-#ifndef RL_SORT_WAVES
-#define RL_SORT_WAVES 3
-#endif
-template <bool MEDIUM, unsigned CHUNKS>
-__global__ void __launch_bounds__(256, RL_SORT_WAVES) k_shade_sorted(RenderConst rc, DeviceScene sc, Pool pool) {
-    __shared__ unsigned s_list[256 * CHUNKS];
-    __shared__ unsigned s_cnt[kNumBins][CHUNKS][4];
-    unsigned n_vertices = 0, n_draws = 0, n_shadow = 0, n_ext = 0;
-    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    unsigned slot[CHUNKS], rank[CHUNKS];
-    int bin[CHUNKS];
-#pragma unroll
-    for (unsigned c = 0; c < CHUNKS; c++) {
-        slot[c] = (blockIdx.x * CHUNKS + c) * blockDim.x + threadIdx.x;
-        const unsigned flags = slot[c] < pool.P ? pool.u[(size_t)U_FLAGS * pool.P + slot[c]] : 0u;
-        bin[c] = -1;
-        if (flags & ST_RAY) {
-            const int prim = (int)pool.u[(size_t)U_PRIM * pool.P + slot[c]];
-            bin[c] = 0;
-            if (prim >= 0) bin[c] = sc.materials[sc.meshes[sc.tris[prim].mesh].material].type;
-        }
-        rank[c] = 0;
-#pragma unroll
-        for (int b = 0; b < kNumBins; b++) {
-            const unsigned long long mask = __ballot(bin[c] == b);
-            if (bin[c] == b) rank[c] = __popcll(mask & ((1ull << lane) - 1ull));
-            if (lane == 0u) s_cnt[b][c][wave] = (unsigned)__popcll(mask);
-        }
-    }
-    __syncthreads();
-    unsigned bin_begin[kNumBins + 1];
-    unsigned my_off[CHUNKS];
-    unsigned run = 0;
-#pragma unroll
-    for (int b = 0; b < kNumBins; b++) {
-        bin_begin[b] = run;
-#pragma unroll
-        for (unsigned c = 0; c < CHUNKS; c++)
-#pragma unroll
-            for (unsigned w = 0; w < 4u; w++) { if (b == bin[c] && w == wave) my_off[c] = run; run += s_cnt[b][c][w]; }
-    }
-    bin_begin[kNumBins] = run;
-#pragma unroll
-    for (unsigned c = 0; c < CHUNKS; c++) if (bin[c] >= 0) s_list[my_off[c] + rank[c]] = slot[c];
-    __syncthreads();
-#define RL_SHADE_BIN(B)                                                                                       \
-    { const unsigned n = bin_begin[(B) + 1] - bin_begin[B];                                                   \
-      for (unsigned i = threadIdx.x; i < n; i += blockDim.x) { PoolState pb{pool, s_list[bin_begin[B] + i]};    \
-          shade_slot<B, MEDIUM>(rc, sc, pb, pb.u(U_FLAGS), n_vertices, n_draws, n_shadow, n_ext); } }
-    RL_SHADE_BIN(0) RL_SHADE_BIN(1) RL_SHADE_BIN(2) RL_SHADE_BIN(3) RL_SHADE_BIN(4)
-#undef RL_SHADE_BIN
-    {
-        const int which[4] = {STAT_VERTICES, STAT_DRAWS, STAT_SHADOW_RAYS, STAT_EXT_RAYS};
-        const unsigned vals[4] = {n_vertices, n_draws, n_shadow, n_ext};
-        block_stats<4>(rc.partials, which, vals);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_path_fused<MAT, MEDIUM, LDS> — the persistent form of the pipeline for scenes with one BSDF type: one
-// launch, one lane per pixel item, the four stage functions above run back-to-back per iteration
-// (raygen -> extend -> shade -> shadow) with the whole path state in registers (RegState) and the scene +
-// traversal stacks in LDS.  Same functions, same order of operations, same results as the wavefront kernels;
-// what disappears is ~1.4 KB/sample of state traffic through HBM and ~2000 kernel boundaries per render.
-#ifdef RL_STAGE_TIMERS
-__device__ unsigned long long g_stage_timers[16];
-#endif
-template <int MAT, bool MEDIUM, bool LDS_SCENE>
-__global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAVES_STREAMING) k_path_fused(RenderConst rc, DeviceScene sc, StackConf stc) {
-    extern __shared__ __attribute__((aligned(16))) float4 smem[];
-    SceneRecs recs;
-    float4* after_scene = smem;
-    if (LDS_SCENE) {
-        stage_scene_lds(sc, smem, smem + 4 * sc.n_nodes);
-        recs.nodes = smem; recs.tris = smem + 4 * sc.n_nodes;
-        after_scene = smem + 4 * (sc.n_nodes + sc.n_prims);
-    } else {
-        recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
-        recs.tris = reinterpret_cast<const float4*>(sc.tris);
-    }
-    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
-    // LDS: [scene][cold path state (u64 | f32 | u32 planes)][per-lane stacks]
-    unsigned long long* cold_q = reinterpret_cast<unsigned long long*>(after_scene);
-    float* cold_f = reinterpret_cast<float*>(cold_q + 256 * FusedState::kColdQ);
-    unsigned* cold_u = reinterpret_cast<unsigned*>(cold_f + 256 * FusedState::kColdF);
-    const TravStackT<LDS_SCENE> stack = make_stack<LDS_SCENE>(stc, cold_u + 256 * FusedState::kColdU, tid);
-    FusedState ps;
-    ps.cold_q = cold_q + threadIdx.x; ps.cold_f = cold_f + threadIdx.x; ps.cold_u = cold_u + threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < F_COUNT; i++) ps.fv[i] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < U_COUNT; i++) ps.uv[i] = 0u;
-#pragma unroll
-    for (int i = 0; i < Q_COUNT; i++) ps.qv[i] = 0ull;
-    storec(ps, F_AR, czero());
-    PU(U_CURSOR) = 0u; PU(U_SAMPLE) = 0u;
-    PU(U_ITEM) = tid;
-    PU(U_PRIM) = 0xffffffffu;
-    PU(U_FLAGS) = tid < rc.n_items ? (ST_REGEN | ST_FRESH) : ST_FINISHED;
-    unsigned n_samples = 0, n_draws = 0, n_vertices = 0, n_shadow = 0, n_ext = 0;
-#ifdef RL_STAGE_TIMERS
-    unsigned long long tm[4] = {0, 0, 0, 0}, ln[5] = {0, 0, 0, 0, 0};
-#define RL_T0 { t0 = __builtin_readcyclecounter(); }
-#define RL_T1(K, COND) { unsigned long long t1 = __builtin_readcyclecounter(); tm[K] += t1 - t0; ln[K] += __popcll(__ballot(COND)); t0 = t1; }
-    unsigned long long t0;
-#else
-#define RL_T0
-#define RL_T1(K, COND)
-#endif
-    while (!(PU(U_FLAGS) & ST_FINISHED)) {
-        RL_T0
-#ifdef RL_STAGE_TIMERS
-        ln[4] += 64;
-        const bool c0 = PU(U_FLAGS) & ST_REGEN;
-#endif
-        if (PU(U_FLAGS) & ST_REGEN) raygen_slot<true>(rc, sc, ps, n_samples, n_draws);   // work items from the global dispenser
-        RL_T1(0, c0)
-#ifdef RL_STAGE_TIMERS
-        const bool c1 = PU(U_FLAGS) & ST_RAY;
-#endif
-        if (PU(U_FLAGS) & ST_RAY) {
-            extend_slot(sc, recs, stack, ps);
-            RL_T1(1, c1)
-            shade_slot<MAT, MEDIUM>(rc, sc, ps, PU(U_FLAGS), n_vertices, n_draws, n_shadow, n_ext);
-        }
-        RL_T1(2, c1)
-#ifdef RL_STAGE_TIMERS
-        const bool c3 = PU(U_FLAGS) & ST_SHADOW;
-#endif
-        if (PU(U_FLAGS) & ST_SHADOW) shadow_slot(sc, recs, stack, ps);
-        RL_T1(3, c3)
-    }
-#ifdef RL_STAGE_TIMERS
-    if ((threadIdx.x & 63u) == 0u) { for (int k = 0; k < 4; k++) { atomicAdd(&g_stage_timers[k], tm[k]); atomicAdd(&g_stage_timers[4 + k], ln[k]); } atomicAdd(&g_stage_timers[8], ln[4]); }
-#endif
-    {
-        const int which[5] = {STAT_SAMPLES, STAT_VERTICES, STAT_DRAWS, STAT_SHADOW_RAYS, STAT_EXT_RAYS};
-        const unsigned vals[5] = {n_samples, n_vertices, n_draws, n_shadow, n_ext};
-        block_stats<5>(rc.partials, which, vals);
-    }
-}
-
-// same occupancy targets as the fused path kernel (`direct`, 1080p x 16 spp, unconstrained 191 VGPRs = 2 waves/SIMD vs 4 / 6: cbox 6.7 vs 5.2 / 5.7 ms,
-// 508 k triangles 36.1 vs 22.2 / 21.4 ms)
-template <int KIND, bool LDS_SCENE>
-__global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAVES_STREAMING) k_pixel_mc(RenderConst rc, DeviceScene sc, StackConf stc, McConst mp) {
-    extern __shared__ __attribute__((aligned(16))) float4 smem[];
-    SceneRecs recs;
-    float4* after_scene = smem;
-    if (LDS_SCENE) {
-        stage_scene_lds(sc, smem, smem + 4 * sc.n_nodes);
-        recs.nodes = smem; recs.tris = smem + 4 * sc.n_nodes;
-        after_scene = smem + 4 * (sc.n_nodes + sc.n_prims);
-    } else {
-        recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
-        recs.tris = reinterpret_cast<const float4*>(sc.tris);
-    }
-    const unsigned item = blockIdx.x * blockDim.x + threadIdx.x;
-    const TravStackT<LDS_SCENE> stack = make_stack<LDS_SCENE>(stc, reinterpret_cast<unsigned*>(after_scene), item);
-    unsigned n_samples = 0, n_draws = 0, n_ext = 0, n_shadow = 0, n_vertices = 0;
-    if (item < rc.n_items) {
-        const float inv = rc.inv_spp;
-        if (rc.stream_mode == RL_STREAM_PER_SAMPLE) {
-            Rng pixel_rng = rng_seed(rc.item_seed[item], rc.seed_variant);
-            const unsigned pix = rc.item_pixel[item];
-            Col acc = czero();
-            for (unsigned s = 0; s < rc.spp; s++) {
-                Rng rng = rng_seed(rng_next_u64(pixel_rng), rc.seed_variant);
-                acc = acc + mc_compute_pixel<KIND>(sc, recs, stack, mp, pix % rc.W, pix / rc.W, rng, n_draws, n_ext, n_shadow, n_vertices);
-                n_samples++;
-            }
-            Col px = scale_unguarded(acc, inv);
-            rc.out[3 * (size_t)pix] = px.r; rc.out[3 * (size_t)pix + 1] = px.g; rc.out[3 * (size_t)pix + 2] = px.b;
-        } else {
-            unsigned bx, by, bw, bh;
-            const unsigned b = rc.owned_blocks[item];
-            block_geometry(rc, b, &bx, &by, &bw, &bh);
-            Rng rng = rng_seed(rc.block_seeds[b], rc.seed_variant);
-            for (unsigned iy = 0; iy < bh; iy++)
-                for (unsigned ix = 0; ix < bw; ix++) {
-                    Col acc = czero();
-                    for (unsigned s = 0; s < rc.spp; s++) {
-                        acc = acc + mc_compute_pixel<KIND>(sc, recs, stack, mp, bx + ix, by + iy, rng, n_draws, n_ext, n_shadow, n_vertices);
-                        n_samples++;
-                    }
-                    Col px = scale_unguarded(acc, inv);
-                    const size_t pix = (size_t)(by + iy) * rc.W + (bx + ix);
-                    rc.out[3 * pix] = px.r; rc.out[3 * pix + 1] = px.g; rc.out[3 * pix + 2] = px.b;
-                }
-        }
-    }
-    {
-        const int which[5] = {STAT_SAMPLES, STAT_VERTICES, STAT_DRAWS, STAT_SHADOW_RAYS, STAT_EXT_RAYS};
-        const unsigned vals[5] = {n_samples, n_vertices, n_draws, n_shadow, n_ext};
-        block_stats<5>(rc.partials, which, vals);
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // operator-level kernels: batched Acceleration::trace / visible for the parity tests
 __global__ void __launch_bounds__(256) k_trace_batch(DeviceScene sc, StackConf stc, unsigned n, const float* o, const float* d, float* t_out, float* u_out,
@@ -470,6 +240,7 @@ struct rl_context {
     bool single_bsdf = true;
     int bsdf_type = 0;
     bool lds_scene = false;
+    bool area_lights_only = false;   // every emitter is a mesh area light, no light tree: the fused kernel's NEE code is specialised (same results)
     size_t scene_lds_bytes = 0;
     // render scratch (grown on demand)
     Pool pool{};
@@ -589,6 +360,8 @@ extern "C" int rl_context_create(const rl_scene* scene, int device, rl_context**
         ds.camera.position[0] = scene->cam_pos.x; ds.camera.position[1] = scene->cam_pos.y; ds.camera.position[2] = scene->cam_pos.z;
         ds.camera.width = scene->width; ds.camera.height = scene->height;
         ds.medium = scene->medium;
+        ctx->area_lights_only = scene->ats_root < 0 && !getenv("RL_GENERIC_LIGHTS");
+        for (const EmitterRecord& e : scene->emitters) if (e.kind != EMITTER_MESH) ctx->area_lights_only = false;
         ctx->single_bsdf = true;
         ctx->bsdf_type = flat.materials.empty() ? 0 : flat.materials[0].type;
         for (const Material& m : flat.materials) if (m.type != ctx->bsdf_type) ctx->single_bsdf = false;
@@ -660,37 +433,6 @@ static int stack_conf(rl_context* ctx, size_t n_threads, StackConf* out) {
         out->overflow = ctx->d_overflow;
     }
     return RL_OK;
-}
-
-template <int MAT>
-static void launch_shade(bool medium, dim3 grid, dim3 block, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const Pool& pool) {
-    if (medium) hipLaunchKernelGGL((k_shade<MAT, true>), grid, block, 0, st, rc, ds, pool);
-    else hipLaunchKernelGGL((k_shade<MAT, false>), grid, block, 0, st, rc, ds, pool);
-}
-static void launch_shade_type(int type, bool medium, dim3 grid, dim3 block, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const Pool& pool) {
-    switch (type) {
-        case BSDF_DIFFUSE: launch_shade<BSDF_DIFFUSE>(medium, grid, block, st, rc, ds, pool); break;
-        case BSDF_PHONG: launch_shade<BSDF_PHONG>(medium, grid, block, st, rc, ds, pool); break;
-        case BSDF_METAL: launch_shade<BSDF_METAL>(medium, grid, block, st, rc, ds, pool); break;
-        case BSDF_GLASS: launch_shade<BSDF_GLASS>(medium, grid, block, st, rc, ds, pool); break;
-        default: launch_shade<BSDF_SUBSTRATE>(medium, grid, block, st, rc, ds, pool); break;
-    }
-}
-
-template <int MAT>
-static void launch_fused(bool medium, bool lds, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc) {
-    if (medium) { if (lds) hipLaunchKernelGGL((k_path_fused<MAT, true, true>), grid, block, lds_bytes, st, rc, ds, stc); else hipLaunchKernelGGL((k_path_fused<MAT, true, false>), grid, block, lds_bytes, st, rc, ds, stc); }
-    else { if (lds) hipLaunchKernelGGL((k_path_fused<MAT, false, true>), grid, block, lds_bytes, st, rc, ds, stc); else hipLaunchKernelGGL((k_path_fused<MAT, false, false>), grid, block, lds_bytes, st, rc, ds, stc); }
-}
-static void launch_fused_type(int type, bool medium, bool lds, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc) {
-    switch (type) {
-        case BSDF_DIFFUSE: launch_fused<BSDF_DIFFUSE>(medium, lds, grid, block, lds_bytes, st, rc, ds, stc); break;
-        case BSDF_PHONG: launch_fused<BSDF_PHONG>(medium, lds, grid, block, lds_bytes, st, rc, ds, stc); break;
-        case BSDF_METAL: launch_fused<BSDF_METAL>(medium, lds, grid, block, lds_bytes, st, rc, ds, stc); break;
-        case BSDF_GLASS: launch_fused<BSDF_GLASS>(medium, lds, grid, block, lds_bytes, st, rc, ds, stc); break;
-        case -1: launch_fused<-1>(medium, lds, grid, block, lds_bytes, st, rc, ds, stc); break;      // several BSDF types: run-time switch per vertex
-        default: launch_fused<BSDF_SUBSTRATE>(medium, lds, grid, block, lds_bytes, st, rc, ds, stc); break;
-    }
 }
 
 extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, const uint64_t* block_seeds, size_t n_blocks, float* out_rgb,
@@ -871,21 +613,12 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     if (fused) {
         const size_t lds_fused = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + kFusedColdBytes;
         if (timing) hipEventRecord(ctx->events[0], st);
-        launch_fused_type(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, ctx->lds_scene, grid_all, block, lds_fused, st, rc, ds, stc);
+        (ctx->lds_scene ? launch_fused_lds : launch_fused_stream)(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, ctx->area_lights_only, grid_all, block, lds_fused, st, rc, ds, stc);
         if (timing) hipEventRecord(ctx->events[1], st);
         HIP_OK(hipGetLastError());          // a refused launch configuration is not sticky: without this the sync below would "succeed"
         HIP_OK(hipStreamSynchronize(st));
         if (timing) { float t = 0.0f; HIP_OK(hipEventElapsedTime(&t, ctx->events[0], ctx->events[1])); ms_fused = t; }
-#ifdef RL_STAGE_TIMERS
-        {   // dev-only build: per-stage cycle shares and active-lane fractions of the fused loop
-            unsigned long long h[16];
-            hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stage_timers), sizeof(h));
-            const double tot = (double)(h[0] + h[1] + h[2] + h[3]);
-            const char* names[4] = {"raygen", "extend", "shade", "shadow"};
-            for (int k = 0; k < 4; k++) std::fprintf(stderr, "[stage] %-7s cycles %5.1f %%  lanes %5.1f %%\n", names[k], 100.0 * h[k] / tot, 100.0 * h[4 + k] / (double)h[8]);
-            std::memset(h, 0, sizeof(h)); hipMemcpyToSymbol(HIP_SYMBOL(g_stage_timers), h, sizeof(h));
-        }
-#endif
+        dump_stage_timers(ctx->lds_scene);     // dev-only build (-DRL_STAGE_TIMERS): per-stage cycle shares of the fused loop
         launches += 1;
         iterations = 1;
     } else for (;;) {
@@ -896,15 +629,8 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         if (ctx->lds_scene) hipLaunchKernelGGL((k_extend<true>), grid_all, block, lds_trav, st, rc, ds, pool, stc);
         else hipLaunchKernelGGL((k_extend<false>), grid_all, block, lds_trav, st, rc, ds, pool, stc);
         if (timing) { hipEventRecord(ev[3], st); hipEventRecord(ev[4], st); }
-        if (use_sort) {
-            if (sort_chunks == 4u) {
-                if (medium) hipLaunchKernelGGL((k_shade_sorted<true, 4>), grid_sort, block, 0, st, rc, ds, pool);
-                else hipLaunchKernelGGL((k_shade_sorted<false, 4>), grid_sort, block, 0, st, rc, ds, pool);
-            } else {
-                if (medium) hipLaunchKernelGGL((k_shade_sorted<true, 1>), grid_all, block, 0, st, rc, ds, pool);
-                else hipLaunchKernelGGL((k_shade_sorted<false, 1>), grid_all, block, 0, st, rc, ds, pool);
-            }
-        } else launch_shade_type(ctx->bsdf_type, medium, grid_all, block, st, rc, ds, pool);
+        if (use_sort) launch_shade_sorted(medium, sort_chunks, sort_chunks == 4u ? grid_sort : grid_all, block, st, rc, ds, pool);
+        else launch_shade_type(ctx->bsdf_type, medium, grid_all, block, st, rc, ds, pool);
         launches += 1;
         if (timing) { hipEventRecord(ev[5], st); hipEventRecord(ev[6], st); }
         if (ctx->lds_scene) hipLaunchKernelGGL((k_shadow<true>), grid_all, block, lds_trav, st, rc, ds, pool, stc);
@@ -1026,8 +752,7 @@ static int render_mc(rl_context* ctx, int kind, const rl_mc_params* params, cons
     const size_t lds = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false);
     const dim3 grid(n_threads / 256), block(256);
     if (per_sample && !owned.empty()) hipLaunchKernelGGL(k_seed_pixels, dim3(((unsigned)owned.size() + 63) / 64), dim3(64), 0, st, rc);
-    if (kind == 0) { if (ctx->lds_scene) hipLaunchKernelGGL((k_pixel_mc<0, true>), grid, block, lds, st, rc, ctx->ds, stc, mp); else hipLaunchKernelGGL((k_pixel_mc<0, false>), grid, block, lds, st, rc, ctx->ds, stc, mp); }
-    else { if (ctx->lds_scene) hipLaunchKernelGGL((k_pixel_mc<1, true>), grid, block, lds, st, rc, ctx->ds, stc, mp); else hipLaunchKernelGGL((k_pixel_mc<1, false>), grid, block, lds, st, rc, ctx->ds, stc, mp); }
+    launch_pixel_mc(kind, ctx->lds_scene, grid, block, lds, st, rc, ctx->ds, stc, mp);
     if (!out_is_device) HIP_OK(hipMemcpyAsync(out_rgb, d_out, (size_t)3 * W * H * sizeof(float), hipMemcpyDeviceToHost, st));
     std::vector<unsigned long long> partials(n_rows * STAT_COUNT);
     HIP_OK(hipMemcpyAsync(partials.data(), ctx->d_partials, partials.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
