@@ -210,8 +210,9 @@ typedef struct rl_path_params {
     uint32_t pool_slots;
     /* 0 = auto, 1 = wavefront stage kernels (raygen / extend / shade / shadow per iteration, state in HBM),
      * 2 = persistent fused kernel (same stages in one launch, state in registers; the BSDF code is specialised when the scene has
-     * one BSDF type and switches per vertex otherwise).  Auto takes the fused kernel for per-sample streams with pool_slots = 0
-     * and the wavefront kernels otherwise.  Does not change results. */
+     * one BSDF type and switches per vertex otherwise).  Auto takes the fused kernel whenever pool_slots = 0 (reference-order
+     * streams too: their few work items — one per 16x16 block — are spread over every 32nd lane so that all SIMDs have waves) and the
+     * wavefront kernels otherwise.  Does not change results. */
     uint32_t pipeline;
     /* per-sample stream mode: lanes working on one pixel at a time (sample s of a pixel runs on lane s % sample_split; the
      * per-sample radiances are parked in HBM and added up in sample order afterwards, so the sum keeps the reference's

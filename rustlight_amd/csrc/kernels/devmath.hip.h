@@ -13,7 +13,16 @@
 
 #include "../detmath_shared.h"
 
+// RL_FAST_MATH (fused_*_fast.hip only): the opt-in tolerance mode `numerics = fast` — FMA contraction, v_rcp / v_rsq / v_sqrt (1 ulp) instead of
+// the correctly rounded sequences, hardware sin / cos / exp2 / log2.  The RNG and every integer operation are untouched (the draw sequence of
+// a path stays bit-exact as long as its branch decisions do); pixels agree with the exact build within BASELINE.json's tolerance, not bit for bit.
+#ifdef RL_FAST_MATH
+#pragma clang fp contract(fast)
+#define RL_NUMERICS_ID 1
+#else
 #pragma clang fp contract(off)
+#define RL_NUMERICS_ID 0
+#endif
 
 #define RL_DEV __device__ __forceinline__
 
@@ -32,8 +41,13 @@ RL_DEV bool finite_f(float x) { return x - x == 0.0f; }
 RL_DEV float rmax(float a, float b) { return fmaxf(a, b); }     // Rust f32::max (non-NaN operand wins)
 RL_DEV float rmin(float a, float b) { return fminf(a, b); }
 RL_DEV float signum_f(float x) { return x != x ? x : copysignf(1.0f, x); }   // Rust f32::signum
+#ifdef RL_FAST_MATH
+RL_DEV float sqrt_rn(float x) { return __builtin_amdgcn_sqrtf(x); }              // v_sqrt_f32, 1 ulp
+RL_DEV float div_rn(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }   // v_rcp_f32 (1 ulp) + one multiply
+#else
 RL_DEV float sqrt_rn(float x) { return __builtin_sqrtf(x); }   // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt, the default); __fsqrt_rn is the 1-ulp native sqrt
 RL_DEV float div_rn(float a, float b) { return a / b; }             // correctly rounded under the same default
+#endif
 
 // ------------------------------------------------------------------------------------------
 struct V2 { float x, y; };
@@ -44,12 +58,20 @@ RL_DEV V3 operator-(V3 a, V3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 RL_DEV V3 operator-(V3 a) { return mk3(-a.x, -a.y, -a.z); }
 RL_DEV V3 operator*(V3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 RL_DEV V3 operator*(float s, V3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+#ifdef RL_FAST_MATH
+RL_DEV V3 operator/(V3 a, float s) { const float r = __builtin_amdgcn_rcpf(s); return mk3(a.x * r, a.y * r, a.z * r); }
+#else
 RL_DEV V3 operator/(V3 a, float s) { return mk3(div_rn(a.x, s), div_rn(a.y, s), div_rn(a.z, s)); }
+#endif
 RL_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RL_DEV V3 cross(V3 a, V3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 RL_DEV float length2(V3 a) { return dot(a, a); }
 RL_DEV float length(V3 a) { return sqrt_rn(dot(a, a)); }
+#ifdef RL_FAST_MATH
+RL_DEV V3 normalize(V3 a) { return a * __builtin_amdgcn_rsqf(dot(a, a)); }
+#else
 RL_DEV V3 normalize(V3 a) { return a * div_rn(1.0f, length(a)); }   // cgmath: v * (1 / |v|)
+#endif
 
 // Color with rustlight's guards (src/structure.rs:249-303)
 struct Col { float r, g, b; };
@@ -143,6 +165,29 @@ RL_DEV float powf_det(float x, float y) {
 // atan_d / sqrt_d / atan2f_det / acosf_det / asinf_det: ../detmath_shared.h (the host builds the light tree with them)
 }  // namespace dm
 
+// transcendentals as the stage functions call them: the deterministic f64 recipes above, or the hardware units in the tolerance build
+#ifdef RL_FAST_MATH
+RL_DEV void m_sincosf(float x, float* s, float* c) { const float r = x * 0.15915494309189535f; *s = __builtin_amdgcn_sinf(r); *c = __builtin_amdgcn_cosf(r); }
+RL_DEV float m_sinf(float x) { return __builtin_amdgcn_sinf(x * 0.15915494309189535f); }
+RL_DEV float m_cosf(float x) { return __builtin_amdgcn_cosf(x * 0.15915494309189535f); }
+RL_DEV float m_expf(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+RL_DEV float m_logf(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+RL_DEV float m_powf(float x, float y) {
+    if (y == 0.0f || x == 1.0f) return 1.0f;
+    if (x != x || y != y) return x + y;
+    if (x < 0.0f) return f32_nan();
+    if (x == 0.0f) return y > 0.0f ? 0.0f : f32_inf();
+    return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+}
+#else
+RL_DEV void m_sincosf(float x, float* s, float* c) { dm::sincosf_det(x, s, c); }
+RL_DEV float m_sinf(float x) { return dm::sinf_det(x); }
+RL_DEV float m_cosf(float x) { return dm::cosf_det(x); }
+RL_DEV float m_expf(float x) { return dm::expf_det(x); }
+RL_DEV float m_logf(float x) { return dm::logf_det(x); }
+RL_DEV float m_powf(float x, float y) { return dm::powf_det(x, y); }
+#endif
+
 // f32::powi = llvm.powi (binary exponentiation, compiler-rt __powisf2)
 RL_DEV float powi_f(float a, int b) {
     float r = 1.0f;
@@ -210,7 +255,7 @@ RL_DEV V2 concentric_sample_disk(V2 u) {
     if (fabsf(o.x) > fabsf(o.y)) { r = o.x; theta = kPi4 * div_rn(o.y, o.x); }
     else { r = o.y; theta = kPi2 - kPi4 * div_rn(o.x, o.y); }
     float s, c;
-    dm::sincosf_det(theta, &s, &c);
+    m_sincosf(theta, &s, &c);
     V2 out; out.x = c * r; out.y = s * r;
     return out;
 }
@@ -224,7 +269,7 @@ RL_DEV V3 sample_uniform_sphere(V2 u) {
     float r = sqrt_rn(rmax(1.0f - z * z, 0.0f));
     float phi = 2.0f * kPi * u.y;
     float s, c;
-    dm::sincosf_det(phi, &s, &c);
+    m_sincosf(phi, &s, &c);
     return mk3(r * c, r * s, z);
 }
 RL_DEV V2 uniform_sample_triangle(V2 u) {

@@ -1,5 +1,6 @@
 // fused.hip.h — k_path_fused, the persistent form of the pipeline, and its launcher; instantiated by fused_lds.hip (scene staged in LDS)
-// and fused_stream.hip (BVH streamed from L2 / HBM) so that the two families compile in parallel.
+// and fused_stream.hip (BVH streamed from L2 / HBM) so that the two families compile in parallel, and once more each by fused_*_fast.hip with
+// RL_FAST_MATH (NUM = 1: the opt-in tolerance build; the template parameter only keeps the kernel symbols of the two builds apart).
 #pragma once
 
 namespace rl {
@@ -13,15 +14,15 @@ namespace rl {
 #ifdef RL_STAGE_TIMERS
 __device__ unsigned long long g_stage_timers[16];
 #endif
-template <int MAT, bool MEDIUM, bool LDS_SCENE, int LIGHTS>
+template <int MAT, bool MEDIUM, bool LDS_SCENE, int LIGHTS, int NUM>
 __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAVES_STREAMING) k_path_fused(RenderConst rc, DeviceScene sc, StackConf stc) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneRecs recs;
     float4* after_scene = smem;
     if (LDS_SCENE) {
-        stage_scene_lds(sc, smem, smem + 4 * sc.n_nodes);
-        recs.nodes = smem; recs.tris = smem + 4 * sc.n_nodes;
-        after_scene = smem + 4 * (sc.n_nodes + sc.n_prims);
+        stage_scene_lds(sc, smem, smem + lds_nodes_float4s(sc.n_nodes));
+        recs.nodes = smem; recs.tris = smem + lds_nodes_float4s(sc.n_nodes);
+        after_scene = smem + lds_scene_float4s(sc.n_nodes, sc.n_prims);
     } else {
         recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
         recs.tris = reinterpret_cast<const float4*>(sc.tris);
@@ -42,9 +43,13 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
     for (int i = 0; i < Q_COUNT; i++) ps.qv[i] = 0ull;
     storec(ps, F_AR, czero());
     PU(U_CURSOR) = 0u; PU(U_SAMPLE) = 0u;
-    PU(U_ITEM) = tid;
+    // few work items (reference-order streams: one per 16x16 block, 8160 at 1080p): they are dealt to every 2^item_shift-th lane, so that
+    // they spread over as many waves as the chip holds — a wave's speed does not depend on how many of its lanes are live, and a SIMD
+    // needs 2-3 ready waves to issue at its rate (profiles/r02_valu_calibration.json)
+    const unsigned item0 = (tid & ((1u << rc.item_shift) - 1u)) == 0u ? (tid >> rc.item_shift) : 0xffffffffu;
+    PU(U_ITEM) = item0;
     PU(U_PRIM) = 0xffffffffu;
-    PU(U_FLAGS) = tid < rc.n_items ? (ST_REGEN | ST_FRESH) : ST_FINISHED;
+    PU(U_FLAGS) = item0 < rc.n_items ? (ST_REGEN | ST_FRESH) : ST_FINISHED;
     unsigned n_samples = 0, n_draws = 0, n_vertices = 0, n_shadow = 0, n_ext = 0;
 #ifdef RL_STAGE_TIMERS
     unsigned long long tm[4] = {0, 0, 0, 0}, ln[5] = {0, 0, 0, 0, 0};
@@ -91,10 +96,10 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
 
 template <bool LDS_SCENE, int MAT>
 static void launch_fused_mat(bool medium, bool area_only, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc) {
-    if (medium) { if (area_only) hipLaunchKernelGGL((k_path_fused<MAT, true, LDS_SCENE, LIGHTS_AREA_ONLY>), grid, block, lds_bytes, st, rc, ds, stc);
-                  else hipLaunchKernelGGL((k_path_fused<MAT, true, LDS_SCENE, LIGHTS_ANY>), grid, block, lds_bytes, st, rc, ds, stc); }
-    else { if (area_only) hipLaunchKernelGGL((k_path_fused<MAT, false, LDS_SCENE, LIGHTS_AREA_ONLY>), grid, block, lds_bytes, st, rc, ds, stc);
-           else hipLaunchKernelGGL((k_path_fused<MAT, false, LDS_SCENE, LIGHTS_ANY>), grid, block, lds_bytes, st, rc, ds, stc); }
+    if (medium) { if (area_only) hipLaunchKernelGGL((k_path_fused<MAT, true, LDS_SCENE, LIGHTS_AREA_ONLY, RL_NUMERICS_ID>), grid, block, lds_bytes, st, rc, ds, stc);
+                  else hipLaunchKernelGGL((k_path_fused<MAT, true, LDS_SCENE, LIGHTS_ANY, RL_NUMERICS_ID>), grid, block, lds_bytes, st, rc, ds, stc); }
+    else { if (area_only) hipLaunchKernelGGL((k_path_fused<MAT, false, LDS_SCENE, LIGHTS_AREA_ONLY, RL_NUMERICS_ID>), grid, block, lds_bytes, st, rc, ds, stc);
+           else hipLaunchKernelGGL((k_path_fused<MAT, false, LDS_SCENE, LIGHTS_ANY, RL_NUMERICS_ID>), grid, block, lds_bytes, st, rc, ds, stc); }
 }
 template <bool LDS_SCENE>
 static void launch_fused_impl(int mat, bool medium, bool area_only, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc) {

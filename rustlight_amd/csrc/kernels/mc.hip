@@ -12,9 +12,9 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
     SceneRecs recs;
     float4* after_scene = smem;
     if (LDS_SCENE) {
-        stage_scene_lds(sc, smem, smem + 4 * sc.n_nodes);
-        recs.nodes = smem; recs.tris = smem + 4 * sc.n_nodes;
-        after_scene = smem + 4 * (sc.n_nodes + sc.n_prims);
+        stage_scene_lds(sc, smem, smem + lds_nodes_float4s(sc.n_nodes));
+        recs.nodes = smem; recs.tris = smem + lds_nodes_float4s(sc.n_nodes);
+        after_scene = smem + lds_scene_float4s(sc.n_nodes, sc.n_prims);
     } else {
         recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
         recs.tris = reinterpret_cast<const float4*>(sc.tris);

@@ -83,6 +83,7 @@ struct RenderConst {
     // image / work decomposition
     unsigned W, H, nby;
     unsigned n_items;
+    unsigned item_shift;                // persistent kernel: item i starts on thread i << item_shift (sparse item sets are spread over more waves)
     unsigned split;                     // per-sample mode: lanes per pixel (sample s of a pixel runs on lane s % split)
     float* sample_buf;                  // split > 1: [spp][n_items / split][3] per-sample radiance, folded in order by k_fold_samples
     const unsigned* owned_blocks;       // block ids of this shard, in creation order

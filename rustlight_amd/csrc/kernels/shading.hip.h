@@ -149,7 +149,7 @@ RL_DEV float micro_eval(const Micro& d, V3 m) {
     float c2 = m.z * m.z;
     float bexp = div_rn(div_rn(m.x * m.x, d.au * d.au) + div_rn(m.y * m.y, d.av * d.av), c2);
     float res;
-    if (d.type == MICRO_BECKMANN) res = div_rn(dm::expf_det(-bexp), kPi * d.au * d.av * c2 * c2);
+    if (d.type == MICRO_BECKMANN) res = div_rn(m_expf(-bexp), kPi * d.au * d.av * c2 * c2);
     else { float root = (1.0f + bexp) * c2; res = div_rn(1.0f, kPi * d.au * d.av * root * root); }
     if (res * m.z < 1e-20f) return 0.0f;
     return res;
@@ -157,11 +157,11 @@ RL_DEV float micro_eval(const Micro& d, V3 m) {
 RL_DEV float micro_pdf(const Micro& d, V3 m) { return micro_eval(d, m) * m.z; }
 RL_DEV void micro_sample(const Micro& d, V2 s, V3* m, float* pdf_out) {
     float sin_phi, cos_phi;
-    dm::sincosf_det(2.0f * kPi * s.y, &sin_phi, &cos_phi);
+    m_sincosf(2.0f * kPi * s.y, &sin_phi, &cos_phi);
     float alpha_sqr = d.au * d.av;
     float cos_m, pdf;
     if (d.type == MICRO_BECKMANN) {
-        float tan2 = alpha_sqr * -dm::logf_det(1.0f - s.x);
+        float tan2 = alpha_sqr * -m_logf(1.0f - s.x);
         cos_m = div_rn(1.0f, sqrt_rn(1.0f + tan2));
         pdf = div_rn(1.0f - s.x, kPi * d.au * d.av * powi_f(cos_m, 3));
     } else {
@@ -211,7 +211,7 @@ RL_DEV float bsdf_pdf(const DeviceScene& sc, const Material& mat, bool huv, V2 u
         if (wi.z <= 0.0f || wo.z <= 0.0f) return 0.0f;
         float alpha = dot(reflect_z(wi), wo);
         float ps = 0.0f;
-        if (alpha > 0.0f) ps = div_rn(mat.weight_specular * dm::powf_det(alpha, mat.exponent) * (mat.exponent + 1.0f), 2.0f * kPi);
+        if (alpha > 0.0f) ps = div_rn(mat.weight_specular * m_powf(alpha, mat.exponent) * (mat.exponent + 1.0f), 2.0f * kPi);
         float pd = (1.0f - mat.weight_specular) * wo.z * kInvPi;
         return ps + pd;
     }
@@ -251,7 +251,7 @@ RL_DEV Col bsdf_eval(const DeviceScene& sc, const Material& mat, bool huv, V2 uv
         if (wi.z <= 0.0f || wo.z <= 0.0f) return czero();
         float alpha = dot(reflect_z(wi), wo);
         Col spec = czero();
-        if (alpha > 0.0f) spec = tex_color(sc, mat.specular, huv, uv) * div_rn(dm::powf_det(alpha, mat.exponent) * (mat.exponent + 2.0f), 2.0f * kPi);
+        if (alpha > 0.0f) spec = tex_color(sc, mat.specular, huv, uv) * div_rn(m_powf(alpha, mat.exponent) * (mat.exponent + 2.0f), 2.0f * kPi);
         Col diff = tex_color(sc, mat.diffuse, huv, uv) * wo.z * kInvPi;
         return spec + diff;
     }
@@ -302,10 +302,10 @@ RL_DEV bool bsdf_sample(const DeviceScene& sc, const Material& mat, bool huv, V2
         V3 d;
         if (s.x < mat.weight_specular) {
             s.x = div_rn(s.x, mat.weight_specular);
-            float sin_a = sqrt_rn(1.0f - dm::powf_det(s.y, div_rn(2.0f, mat.exponent + 1.0f)));
-            float cos_a = dm::powf_det(s.y, div_rn(1.0f, mat.exponent + 1.0f));
+            float sin_a = sqrt_rn(1.0f - m_powf(s.y, div_rn(2.0f, mat.exponent + 1.0f)));
+            float cos_a = m_powf(s.y, div_rn(1.0f, mat.exponent + 1.0f));
             float phi = 2.0f * kPi * s.x;
-            V3 local = mk3(sin_a * dm::cosf_det(phi), sin_a * dm::sinf_det(phi), cos_a);
+            V3 local = mk3(sin_a * m_cosf(phi), sin_a * m_sinf(phi), cos_a);
             Frame fr = make_frame(reflect_z(wi));
             d = to_world(fr, local);
             if (d.z <= 0.0f) return false;
@@ -429,7 +429,7 @@ RL_DEV float env_direct_pdf(const DeviceScene& sc, V3 d) {
     if (sc.env_w == 0u) return sc.env_pdf;
     V2 uv = env_to_spherical(d);
     float p = env_bin_pdf(sc, f32_as_usize(uv.x * (float)sc.env_w), f32_as_usize(uv.y * (float)sc.env_h));
-    float st = dm::sinf_det(kPi * uv.y);
+    float st = m_sinf(kPi * uv.y);
     float v = st == 0.0f ? 0.0f : div_rn(p, (2.0f * powi_f(kPi, 2)) * st);
     return v * sc.env_sel_pdf;
 }
@@ -444,8 +444,8 @@ RL_DEV void env_sample_direction(const DeviceScene& sc, V2 u, V3* d, Col* value,
     const float* t = sc.env_texels + 3ull * (py * sc.env_w + px);
     float p = env_bin_pdf(sc, px, py);
     float sp, cp, st, ct;
-    dm::sincosf_det(div_rn(2.0f * kPi, (float)sc.env_w) * x, &sp, &cp);
-    dm::sincosf_det(div_rn(kPi, (float)sc.env_h) * y, &st, &ct);
+    m_sincosf(div_rn(2.0f * kPi, (float)sc.env_w) * x, &sp, &cp);
+    m_sincosf(div_rn(kPi, (float)sc.env_h) * y, &st, &ct);
     *d = mk3(st * cp, st * sp, ct);
     if (st == 0.0f) { *value = czero(); *pdf = 0.0f; }
     else { *value = mkc(t[0], t[1], t[2]); *pdf = div_rn(p, (2.0f * powi_f(kPi, 2)) * st); }
@@ -663,7 +663,7 @@ RL_DEV float light_direct_pdf(const DeviceScene& sc, const MeshRecord& mr, int p
 // ------------------------------------------------------------------------------------------
 // HomogenousVolume (src/volume.rs:95-141) and PhaseFunction (12-68)
 struct MediumSample { float t; Col w; bool exited; };
-RL_DEV Col cexp(Col c) { return mkc(dm::expf_det(c.r), dm::expf_det(c.g), dm::expf_det(c.b)); }
+RL_DEV Col cexp(Col c) { return mkc(m_expf(c.r), m_expf(c.g), m_expf(c.b)); }
 RL_DEV MediumSample medium_sample(const MediumRecord& m, float max_t, float u) {
     Col sigma_t = mkc(m.sigma_t[0], m.sigma_t[1], m.sigma_t[2]);
     Col sigma_s = mkc(m.sigma_s[0], m.sigma_s[1], m.sigma_s[2]);
@@ -671,7 +671,7 @@ RL_DEV MediumSample medium_sample(const MediumRecord& m, float max_t, float u) {
     int component = u3 != u3 ? 0 : (u3 <= 0.0f ? 0 : (u3 >= 255.0f ? 255 : (int)u3));   // `as u8`
     u = u * 3.0f - (float)component;
     float sigma_t_c = cget(sigma_t, component);
-    float t = div_rn(-dm::logf_det(1.0f - u), sigma_t_c);
+    float t = div_rn(-m_logf(1.0f - u), sigma_t_c);
     float t_min = rmin(t, max_t);
     bool exited = t >= max_t;
     Col tau = t_min * sigma_t;
@@ -703,7 +703,7 @@ RL_DEV void phase_sample(const MediumRecord& m, V3 d_in, V2 u, V3* d, Col* weigh
     else { float sq = div_rn(1.0f - g * g, 1.0f - g + 2.0f * g * u.x); cos_t = div_rn(1.0f + g * g - sq * sq, 2.0f * g); }
     float sin_t = sqrt_rn(rmax(1.0f - cos_t * cos_t, 0.0f));
     float sp, cp;
-    dm::sincosf_det(2.0f * kPi * u.y, &sp, &cp);
+    m_sincosf(2.0f * kPi * u.y, &sp, &cp);
     V3 rev = d_in * -1.0f;
     *d = to_world(make_frame(rev), mk3(sin_t * cp, sin_t * sp, cos_t));
     *weight = cone();

@@ -20,6 +20,22 @@ namespace rl {
 
 struct Hit { float t, u, v; int prim; int steps = 0, tris = 0; };   // steps / tris: dev-only traversal statistics (dead code unless read)
 
+// Layout of a scene staged in LDS.  A 64-byte record stride puts the same field of every node on two LDS banks (bank = dword
+// address mod 32) and the 16-byte quarters of every triangle on four bank groups, so lanes that read different records collide
+// (SQ_LDS_BANK_CONFLICT was 25 % of the LDS cycles of k_path_fused on the Cornell box): nodes are staged 17 dwords apart, triangles
+// 20 dwords (ds_read_b128 needs 16-byte alignment), which spreads distinct records over distinct banks.  Child references of
+// inner nodes are rewritten to byte offsets (index x stride x 4) while staging, so a node's address is one add per plane pair.
+#ifndef RL_LDS_NODE_STRIDE
+#define RL_LDS_NODE_STRIDE 17
+#endif
+#ifndef RL_LDS_TRI_STRIDE4
+#define RL_LDS_TRI_STRIDE4 5
+#endif
+static constexpr int kLdsNodeStride = RL_LDS_NODE_STRIDE;      // dwords
+static constexpr int kLdsTriStride4 = RL_LDS_TRI_STRIDE4;      // float4s
+RL_DEV __host__ unsigned lds_nodes_float4s(unsigned n_nodes) { return (n_nodes * (unsigned)kLdsNodeStride + 3u) / 4u; }
+RL_DEV __host__ unsigned lds_scene_float4s(unsigned n_nodes, unsigned n_prims) { return lds_nodes_float4s(n_nodes) + n_prims * (unsigned)kLdsTriStride4; }
+
 // AABB::intersect (src/structure.rs:849-869) with 1/d hoisted out of the loop, restated without its per-axis
 // early exit and compare/select chains — same value, same verdict, a third fewer VALU instructions:
 //  * `t_min = if a0 > t_min {a0} else {t_min}` never makes t_min a NaN (a NaN a0 = 0 * inf loses the compare), so it
@@ -95,7 +111,12 @@ RL_DEV bool tri_test(const float4 q0, const float4 q1, const float4 q2, const fl
     V3 w0 = cross(pv, e2);
     if (dot(u0, n) < 0.0f || dot(w0, n) < 0.0f) return false;
     const float uu = dot(u0, u0), ww = dot(w0, w0);
-#ifdef RL_TRI_REFERENCE_FORM
+#if defined(RL_FAST_MATH)
+    const float s = __builtin_amdgcn_sqrtf(uu) + __builtin_amdgcn_sqrtf(ww);
+    if (s <= det) { hit.t = t; hit.prim = prim; return true; }     // tolerance build: the 1-ulp estimate decides everywhere
+    return false;
+    const bool in_range = true;
+#elif defined(RL_TRI_REFERENCE_FORM)
     const bool in_range = false; const float s = 0.0f;
 #else
     const float s = __builtin_amdgcn_sqrtf(uu) + __builtin_amdgcn_sqrtf(ww);
@@ -124,7 +145,7 @@ struct SceneRecs {
 // `stack` points at this lane's column of the LDS stack, entries are `stride` ints apart;
 // two ints per level: child code and the bits of its entry distance.
 //
-// Control flow is "while-while": every lane first descends inner nodes until it holds a leaf (or is
+// Control flow is "while-while": every lane first descends inner nodes (or takes stack entries) until it holds a leaf (or is
 // done), then the wave tests leaves together.  Visit order and pruning are those of the reference's
 // recursion; only the interleaving between lanes changes (wave64 lane utilisation 32 % -> see profiles/).
 // Per-lane traversal stack: the first `lds_levels` entries live in LDS (layout [level][lane] of 8-byte pairs,
@@ -137,6 +158,8 @@ struct NodeFetchGlobal;
 template <bool LDS_ONLY>
 struct TravStackT {
     using NodeFetch = typename std::conditional<LDS_ONLY, NodeFetchLds, NodeFetchGlobal>::type;   // LDS-only stacks go with LDS-staged scenes
+    static constexpr int kTriStride4 = LDS_ONLY ? kLdsTriStride4 : 4;                              // float4s between triangle records
+    static constexpr int kNodeRefScale = LDS_ONLY ? 4 * kLdsNodeStride : 1;                        // inner-node reference = index x this (LDS: byte offset)
     static constexpr int lds_stride = 256;       // every traversal kernel runs 256-lane workgroups
     int2* lds; int lds_levels;   // lds already offset to this lane; one (code, distance bits) pair per level
     int* glob; size_t glob_stride;               // glob already offset to this lane
@@ -150,17 +173,6 @@ struct TravStackT {
     }
 };
 using TravStack = TravStackT<false>;
-
-template <class Stack>
-RL_DEV int stack_pop(const Stack& st, int& sp, float t_best) {
-    while (sp > 0) {
-        sp--;
-        int code; float dist;
-        st.get(sp, &code, &dist);
-        if (dist < t_best) return code;    // `if d2 < its.t` evaluated after the near subtree (accel.rs:279-284)
-    }
-    return RL_CHILD_NONE;
-}
 
 // One inner node: both child boxes against the ray, verdicts already folded with the current closest hit.
 // `AABB::intersect` clips the far plane with the ray's tfar and the caller then asks `d < its.t` (accel.rs:262-284); its.t never
@@ -178,14 +190,16 @@ struct NodeFetchLds {
         nx = b + (sx ? 3 : 0); fx = b + (sx ? 0 : 3);
         ny = b + (sy ? 4 : 1); fy = b + (sy ? 1 : 4);
         nz = b + (sz ? 5 : 2); fz = b + (sz ? 2 : 5);
-        ids = reinterpret_cast<const int*>(b) + 12;
+        ids = reinterpret_cast<const int*>(b) + 12;     // two dword reads (an odd record stride is only 4-byte aligned)
     }
     RL_DEV NodePlanes operator()(int cur) const {
-        const int k = cur * 16;
+        // `cur` is the node's byte offset (child references are pre-multiplied while staging): one add per plane pair
         NodePlanes p;
-        p.lnx = nx[k]; p.rnx = nx[k + 6]; p.lny = ny[k]; p.rny = ny[k + 6]; p.lnz = nz[k]; p.rnz = nz[k + 6];
-        p.lfx = fx[k]; p.rfx = fx[k + 6]; p.lfy = fy[k]; p.rfy = fy[k + 6]; p.lfz = fz[k]; p.rfz = fz[k + 6];
-        p.id1 = ids[k]; p.id2 = ids[k + 1];
+#define RL_AT(ptr, off) (*reinterpret_cast<const float*>(reinterpret_cast<const char*>(ptr) + cur + 4 * (off)))
+        p.lnx = RL_AT(nx, 0); p.rnx = RL_AT(nx, 6); p.lny = RL_AT(ny, 0); p.rny = RL_AT(ny, 6); p.lnz = RL_AT(nz, 0); p.rnz = RL_AT(nz, 6);
+        p.lfx = RL_AT(fx, 0); p.rfx = RL_AT(fx, 6); p.lfy = RL_AT(fy, 0); p.rfy = RL_AT(fy, 6); p.lfz = RL_AT(fz, 0); p.rfz = RL_AT(fz, 6);
+        p.id1 = __float_as_int(RL_AT(ids, 0)); p.id2 = __float_as_int(RL_AT(ids, 1));
+#undef RL_AT
         return p;
     }
 };
@@ -208,56 +222,75 @@ RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3
                      Hit& hit, const Stack& st) {
     V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
     float dummy;
-    int cur = root;
+    int cur = root >= 0 ? root * Stack::kNodeRefScale : root;
     if (!slab(root_lo, root_hi, o, inv_d, tnear, tfar, &dummy)) cur = RL_CHILD_NONE;   // accel.rs:293-295 / 338-340
     int sp = 0;
     bool found = false;
     typename Stack::NodeFetch fetch(recs, inv_d);
+    // Same visits, same order, one loop level less: the far child is stored unconditionally (the slot only counts when both children
+    // were hit) and a lane that needs the next stack entry takes ONE per trip of the node loop — a stale entry (its subtree lies behind
+    // the current hit) simply keeps the lane in the popping state — instead of spinning in a nested loop the rest of the wave waits for.
+    constexpr int kPop = -1;            // = ~0: a leaf code with zero triangles, which the builder never emits
     while (cur != RL_CHILD_NONE) {
-        // ---- phase 1: inner nodes
-        while (cur >= 0) {
-            hit.steps++;
-            const NodePlanes p = fetch(cur);
-            const float d1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((p.lnx - o.x) * inv_d.x, (p.lny - o.y) * inv_d.y), (p.lnz - o.z) * inv_d.z), tnear);
-            const float f1 = __builtin_fminf(__builtin_fminf(__builtin_fminf((p.lfx - o.x) * inv_d.x, (p.lfy - o.y) * inv_d.y), (p.lfz - o.z) * inv_d.z), hit.t);
-            const float d2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((p.rnx - o.x) * inv_d.x, (p.rny - o.y) * inv_d.y), (p.rnz - o.z) * inv_d.z), tnear);
-            const float f2 = __builtin_fminf(__builtin_fminf(__builtin_fminf((p.rfx - o.x) * inv_d.x, (p.rfy - o.y) * inv_d.y), (p.rfz - o.z) * inv_d.z), hit.t);
-            const bool v1 = !(f1 <= d1), v2 = !(f2 <= d2);                 // box hit and entry distance < its.t
-            // the reference orders by distance with a missed box at +inf and keeps the left child first on ties
-            const bool right_first = v2 && (!v1 || d1 > d2);
-            if (v1 || v2) {
-                if (v1 && v2) { st.push(sp, right_first ? p.id1 : p.id2, right_first ? d1 : d2); sp++; }   // re-checked against its.t at pop time
-                cur = right_first ? p.id2 : p.id1;
-            } else cur = stack_pop(st, sp, hit.t);
+        while (cur >= 0 || cur == kPop) {
+            if (cur >= 0) {
+                hit.steps++;
+                const NodePlanes p = fetch(cur);
+                const float d1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((p.lnx - o.x) * inv_d.x, (p.lny - o.y) * inv_d.y), (p.lnz - o.z) * inv_d.z), tnear);
+                const float f1 = __builtin_fminf(__builtin_fminf(__builtin_fminf((p.lfx - o.x) * inv_d.x, (p.lfy - o.y) * inv_d.y), (p.lfz - o.z) * inv_d.z), hit.t);
+                const float d2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((p.rnx - o.x) * inv_d.x, (p.rny - o.y) * inv_d.y), (p.rnz - o.z) * inv_d.z), tnear);
+                const float f2 = __builtin_fminf(__builtin_fminf(__builtin_fminf((p.rfx - o.x) * inv_d.x, (p.rfy - o.y) * inv_d.y), (p.rfz - o.z) * inv_d.z), hit.t);
+                const bool v1 = !(f1 <= d1), v2 = !(f2 <= d2);                 // box hit and entry distance < its.t
+                // the reference orders by distance with a missed box at +inf and keeps the left child first on ties
+                const bool right_first = v2 & (!v1 | (d1 > d2));
+                st.push(sp, right_first ? p.id1 : p.id2, right_first ? d1 : d2);
+                sp += (v1 && v2) ? 1 : 0;
+                cur = (v1 || v2) ? (right_first ? p.id2 : p.id1) : kPop;
+            }
+            if (cur == kPop) {
+                cur = RL_CHILD_NONE;
+                if (sp > 0) {
+                    sp--;
+                    int code; float dist;
+                    st.get(sp, &code, &dist);
+                    cur = dist < hit.t ? code : kPop;      // `if d2 < its.t` evaluated after the near subtree (accel.rs:279-284)
+                }
+            }
         }
-        // ---- phase 2: a leaf (<= 2 triangles, tested in order: accel.rs:245-254) or nothing left
         if (cur != RL_CHILD_NONE) {
             unsigned int code = (unsigned int)(~cur);
             int first = (int)(code >> 2), count = (int)(code & 3u);
             for (int k = 0; k < count; k++) {
                 hit.tris++;
-                const float4* q = recs.tris + 4 * (first + k);
+                const float4* q = recs.tris + Stack::kTriStride4 * (first + k);
                 if (tri_test(q[0], q[1], q[2], q[3], o, d, hit, first + k)) {
                     found = true;
                     if (ANY_HIT) return true;
                 }
             }
-            cur = stack_pop(st, sp, hit.t);
+            cur = kPop;
         }
     }
     if (!ANY_HIT && found) {   // barycentrics of the closest hit (see tri_test)
-        const float4* q = recs.tris + 4 * hit.prim;
+        const float4* q = recs.tris + Stack::kTriStride4 * hit.prim;
         tri_uv(q[0], q[1], q[2], q[3], o, d, hit.t, &hit.u, &hit.v);
     }
     return found;
 }
 
-// Stage the node / triangle records into LDS (cooperatively, 16 bytes per lane per step).
+// Stage the node / triangle records into LDS (cooperatively) in the padded layout above; inner-child references become dword offsets.
 RL_DEV void stage_scene_lds(const DeviceScene& sc, float4* lds_nodes, float4* lds_tris) {
-    const float4* gn = reinterpret_cast<const float4*>(sc.nodes);
+    const float* gn = reinterpret_cast<const float*>(sc.nodes);
     const float4* gt = reinterpret_cast<const float4*>(sc.tris);
-    for (unsigned int i = threadIdx.x; i < 4u * sc.n_nodes; i += blockDim.x) lds_nodes[i] = gn[i];
-    for (unsigned int i = threadIdx.x; i < 4u * sc.n_prims; i += blockDim.x) lds_tris[i] = gt[i];
+    float* ln = reinterpret_cast<float*>(lds_nodes);
+    for (unsigned int i = threadIdx.x; i < 16u * sc.n_nodes; i += blockDim.x) {
+        const unsigned int node = i >> 4, f = i & 15u;
+        if (f >= 14u) continue;                                  // padding words of the 64-byte record
+        float v = gn[i];
+        if (f >= 12u) { const int id = __float_as_int(v); if (id >= 0) v = __int_as_float(id * 4 * kLdsNodeStride); }   // byte offset
+        ln[node * (unsigned)kLdsNodeStride + f] = v;
+    }
+    for (unsigned int i = threadIdx.x; i < 4u * sc.n_prims; i += blockDim.x) lds_tris[(i >> 2) * (unsigned)kLdsTriStride4 + (i & 3u)] = gt[i];
     __syncthreads();
 }
 

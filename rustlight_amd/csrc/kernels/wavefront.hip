@@ -109,7 +109,7 @@ __device__ unsigned long long g_trav_stats[8];
 template <bool LDS_SCENE, bool SHADOW>
 RL_DEV void trace_kernel_body(const DeviceScene& sc, const Pool& pool, const StackConf& stc) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
-    float4* after_scene = LDS_SCENE ? smem + 4 * (sc.n_nodes + sc.n_prims) : smem;
+    float4* after_scene = LDS_SCENE ? smem + lds_scene_float4s(sc.n_nodes, sc.n_prims) : smem;
     unsigned* list = reinterpret_cast<unsigned*>(after_scene);
     unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
     const TravStackT<LDS_SCENE> stack = make_stack<LDS_SCENE>(stc, list + 272, slot);
@@ -118,8 +118,8 @@ RL_DEV void trace_kernel_body(const DeviceScene& sc, const Pool& pool, const Sta
     if (n_live == 0u) return;          // whole tile idle (finished pixels): skip the scene staging too
     SceneRecs recs;
     if (LDS_SCENE) {
-        stage_scene_lds(sc, smem, smem + 4 * sc.n_nodes);
-        recs.nodes = smem; recs.tris = smem + 4 * sc.n_nodes;
+        stage_scene_lds(sc, smem, smem + lds_nodes_float4s(sc.n_nodes));
+        recs.nodes = smem; recs.tris = smem + lds_nodes_float4s(sc.n_nodes);
     } else {
         recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
         recs.tris = reinterpret_cast<const float4*>(sc.tris);
@@ -366,7 +366,7 @@ extern "C" int rl_context_create(const rl_scene* scene, int device, rl_context**
         ctx->bsdf_type = flat.materials.empty() ? 0 : flat.materials[0].type;
         for (const Material& m : flat.materials) if (m.type != ctx->bsdf_type) ctx->single_bsdf = false;
         // stage the scene in LDS when nodes + triangles are small (<= 48 KiB leaves room for the stacks)
-        ctx->scene_lds_bytes = 64 * ((size_t)ds.n_nodes + ds.n_prims);
+        ctx->scene_lds_bytes = (size_t)16 * lds_scene_float4s(ds.n_nodes, ds.n_prims);     // padded LDS layout (trace.hip.h)
         // LDS-staged scenes also keep their whole traversal stack in LDS (TravStackT<true>)
         ctx->lds_scene = ctx->scene_lds_bytes <= 48 * 1024 && ds.stack_depth <= (uint32_t)kLdsStackLevels;
         {   // worst-case dynamic LDS of any kernel that stages the scene: [scene][compaction list | cold path state][12 stack levels];
@@ -445,7 +445,6 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     if (params->strategy < 0 || params->strategy > 2) return RL_ERR_INVALID_ARGUMENT;
     if (params->stream_mode != RL_STREAM_REFERENCE_ORDER && params->stream_mode != RL_STREAM_PER_SAMPLE) return RL_ERR_INVALID_ARGUMENT;
     if (params->numerics > RL_NUMERICS_FAST) { rl_set_error("numerics must be 0 (exact) or 1 (fast)"); return RL_ERR_INVALID_ARGUMENT; }
-    if (params->numerics == RL_NUMERICS_FAST) { rl_set_error("numerics = fast is not built into this library"); return RL_ERR_UNSUPPORTED; }
     const uint32_t shard_count = params->shard_count ? params->shard_count : 1;
     if (params->shard_index >= shard_count) return RL_ERR_INVALID_ARGUMENT;
     if (params->strategy != RL_STRATEGY_BSDF && ctx->ds.n_emitters == 0) { rl_set_error("light sampling requested but the scene has no emitter"); return RL_ERR_NO_EMITTER; }
@@ -465,11 +464,14 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         n_pixels += bw * bh;
     }
     const bool per_sample = params->stream_mode == RL_STREAM_PER_SAMPLE;
-    // pipeline: 1 = wavefront stage kernels, 2 = persistent fused kernel, 0 = auto (fused for per-sample streams: measured at
+    // pipeline: 1 = wavefront stage kernels, 2 = persistent fused kernel, 0 = auto = fused unless a pool size is forced (reference-order
+    // streams at 1080p x 128 spp: wavefront 8.7 s, fused 2.9 s, fused with the items spread over the waves: see DESIGN.md; per-sample at
     // 1080p x 32 spp, fused vs wavefront: 508 k-triangle / 6-BSDF scene 127 vs 202 ms, 4.9 k triangles 61 vs 153 ms, Cornell box
     // with mixed BSDFs 23 vs 70 ms, diffuse Cornell box 15 vs 35 ms)
     if (params->pipeline > 2) { rl_set_error("pipeline must be 0 (auto), 1 (wavefront) or 2 (fused)"); return RL_ERR_INVALID_ARGUMENT; }
-    const bool fused = params->pipeline == 2 || (params->pipeline == 0 && per_sample && params->pool_slots == 0);
+    const bool fused = params->pipeline == 2 || (params->pipeline == 0 && params->pool_slots == 0);
+    const bool fast_math = params->numerics == RL_NUMERICS_FAST;
+    if (fast_math && !fused) { rl_set_error("numerics = fast exists for the persistent kernel only (pipeline 0 or 2, pool_slots 0)"); return RL_ERR_UNSUPPORTED; }
     // sample-parallel pixels: `split` lanes per pixel, per-sample radiances parked in HBM ([spp][pixel][3] floats) and folded
     // in order.  Auto: scenes that traverse out of L2 / HBM want ~8 M paths in flight per wavefront launch (measured on the
     // 508 k-triangle living-room scene at 1080p: 1 lane/pixel 935 ms, 4 lanes 787 ms, 8 lanes 836 ms); LDS-staged scenes in the
@@ -491,6 +493,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     }
     const unsigned n_items = per_sample ? n_pixels * split : (unsigned)owned.size();
     // a pool never needs more slots than there are work items (and `pool_slots` is caller input: keep the rounding below from wrapping)
+    unsigned item_shift = 0;
     unsigned P = params->pool_slots ? std::min(params->pool_slots, std::max(n_items, 1u)) : std::min<unsigned>(n_items, 16u << 20);
     P = std::max(256u, (unsigned)(((unsigned long long)P + 255ull) / 256ull * 256ull));
     if (fused) {
@@ -504,6 +507,11 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         const unsigned resident = (unsigned)cus * (unsigned)(ctx->lds_scene ? RL_FUSED_WAVES : RL_FUSED_WAVES_STREAMING) * 256u;
         const bool dynamic_items = getenv("RL_FUSED_DYNAMIC") ? atoi(getenv("RL_FUSED_DYNAMIC")) != 0 : (ctx->ds.medium.enabled != 0 || !ctx->lds_scene);
         P = std::max(256u, (std::min(n_items, dynamic_items ? resident : n_items) + 255u) / 256u * 256u);
+        // sparse item sets (reference-order streams): one item per 2^item_shift lanes, all of them resident from the start
+        const unsigned resident4 = (unsigned)cus * 4u * 256u;
+        while (item_shift < 6u && ((size_t)n_items << (item_shift + 1u)) <= resident4) item_shift++;
+        if (getenv("RL_ITEM_SHIFT")) item_shift = std::min(6u, (unsigned)atoi(getenv("RL_ITEM_SHIFT")));
+        if (item_shift) P = std::max(256u, (unsigned)((((size_t)n_items << item_shift) + 255u) / 256u * 256u));
     }
     int rcode;
     if ((rcode = ensure(&ctx->d_owned, &ctx->owned_capacity, owned.size())) != RL_OK) return rcode;
@@ -548,7 +556,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     HIP_OK(hipMemsetAsync(d_out, 0, (size_t)3 * W * H * sizeof(float), st));
     Counters init{};
     init.active = std::min(P, n_items);
-    init.next_item = P;
+    init.next_item = item_shift ? n_items : P;
     HIP_OK(hipMemcpyAsync(ctx->d_counters, &init, sizeof(init), hipMemcpyHostToDevice, st));
     const size_t n_partial_rows = (P + 255) / 256;
     if ((rcode = ensure(&ctx->d_partials, &ctx->partials_capacity, n_partial_rows * STAT_COUNT)) != RL_OK) return rcode;
@@ -564,6 +572,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     rc.inv_spp = 1.0f / (float)params->spp;
     rc.W = W; rc.H = H; rc.nby = (unsigned)nby;
     rc.n_items = n_items;
+    rc.item_shift = item_shift;
     rc.split = split; rc.sample_buf = ctx->d_sample_buf;
     rc.owned_blocks = ctx->d_owned; rc.block_item_base = ctx->d_item_base; rc.n_owned = (unsigned)owned.size();
     rc.block_seeds = ctx->d_block_seeds;
@@ -613,7 +622,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     if (fused) {
         const size_t lds_fused = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + kFusedColdBytes;
         if (timing) hipEventRecord(ctx->events[0], st);
-        (ctx->lds_scene ? launch_fused_lds : launch_fused_stream)(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, ctx->area_lights_only, grid_all, block, lds_fused, st, rc, ds, stc);
+        (ctx->lds_scene ? (fast_math ? launch_fused_lds_fast : launch_fused_lds) : (fast_math ? launch_fused_stream_fast : launch_fused_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, ctx->area_lights_only, grid_all, block, lds_fused, st, rc, ds, stc);
         if (timing) hipEventRecord(ctx->events[1], st);
         HIP_OK(hipGetLastError());          // a refused launch configuration is not sticky: without this the sync below would "succeed"
         HIP_OK(hipStreamSynchronize(st));

@@ -627,7 +627,7 @@ def test_cfg1_reference_order_whole_frame(built):
     ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
     ref_fwd, ost = osc.render(master_seed=0, spp=16, stream_mode=0, eval_order=1)
     ref_rec, _ = osc.render(master_seed=0, spp=16, stream_mode=0, eval_order=0)
-    for pipeline in (api.PIPELINE_AUTO, api.PIPELINE_FUSED):
+    for pipeline in (api.PIPELINE_WAVEFRONT, api.PIPELINE_AUTO):
         img, st = ctx.render(api.IndependentSampler(0).block_seeds(256, 256), api.path_params(spp=16, stream_mode=api.STREAM_REFERENCE_ORDER, pipeline=pipeline))
         _assert_parity(img, st, ref_fwd, ref_rec, ost)
     assert st["camera_samples"] == 256 * 256 * 16
@@ -668,3 +668,30 @@ def test_bench_two_ranks_on_one_gpu(built):
     assert out["n_gpus"] == 2 and out["distributed"]["world_size"] == 2 and len(out["distributed"]["ranks"]) == 2
     assert out["distributed"]["crc_match"] is True and out["config"]["spp_total"] == 8
     assert out["value"] > 0 and out["roofline"]["kernel"] == "k_path_fused"
+
+
+def test_fast_numerics_tolerance_mode(built):
+    """`numerics = fast` (opt-in; FMA contraction, v_rcp / v_rsq / v_sqrt, hardware sin / cos / exp2 / log2 — DESIGN.md §2 "Tolerance
+    mode") is held to BASELINE.json's own bar, not to bit-exactness: RNG sequence bit-exact (same seeds, same draws on every path whose
+    branch decisions do not flip), per-pixel squared L2 vs the oracle < 1e-3.  The exact build stays the default and the only one
+    the other parity tests bless."""
+    cases = [(scenes.cbox(96, 96), dict(spp=16)), (scenes.living_room(96, 64, n_spheres=27, tess=10), dict(spp=8, max_depth=8)),
+             (scenes.cbox_medium(64, 64, 0.5), dict(spp=4))]
+    for sd, kw in cases:
+        ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+        seeds = api.IndependentSampler(3).block_seeds(sd.width, sd.height)
+        ref, ost = osc.render(seeds=seeds, stream_mode=1, eval_order=1, **kw)
+        exact, st = ctx.render(seeds, api.path_params(**kw))
+        fast, stf = ctx.render(seeds, api.path_params(numerics=api.NUMERICS_FAST, **kw))
+        np.testing.assert_array_equal(exact, ref)
+        assert not np.array_equal(fast, ref)                       # it really is another build
+        e = per_pixel_l2(fast, ref)
+        assert e.mean() < 1e-6 and np.quantile(e, 0.999) < L2_TOL, (e.mean(), np.quantile(e, 0.999), e.max())
+        assert stf["camera_samples"] == ost["camera_samples"]
+        # paths whose decisions flipped (a Russian-roulette or cdf comparison within an ulp of its threshold) change the draw count
+        assert abs(stf["rng_draws"] - ost["rng_draws"]) <= 2e-3 * ost["rng_draws"], (stf["rng_draws"], ost["rng_draws"])
+        assert (e > 1e-6).mean() < 0.02
+    with pytest.raises(api.RustlightError, match="persistent kernel"):
+        ctx.render(seeds, api.path_params(spp=1, numerics=api.NUMERICS_FAST, pipeline=api.PIPELINE_WAVEFRONT))
+    with pytest.raises(api.RustlightError, match="numerics"):
+        ctx.render(seeds, api.path_params(spp=1, numerics=7))
