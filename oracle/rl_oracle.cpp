@@ -11,6 +11,10 @@
 // (SURVEY.md App. B.1).  The SmallRng::seed_from_u64 expansion (rand 0.8.5 / rand_core 0.6.4,
 // third-party, not vendored) is restated from its documented algorithm and is switchable
 // between the PCG32-fill default and Xoshiro's SplitMix64 variant.
+// HOW TO PIN IT: oracle/pin/README.md — with a Rust toolchain, `cargo run --release --example=pin_draws` (64 draws of
+// SmallRng::seed_from_u64(0), oracle/pin/pin_draws.rs) and `cargo run --release --example=cli -- -t 1 -r independent:0 -n 4 -o ref.pfm
+// oracle/pin/out/cbox_64.xml path` produce the two artefacts `python oracle/pin/diff_pin.py ref_draws.txt ref.pfm` compares with this
+// oracle's expected outputs (oracle/pin/expected.json holds their hashes; tests/test_pin_kit.py keeps the kit alive).
 //
 // Deliberate, documented deviations from the reference:
 //   * transcendentals go through oracle/detmath.h instead of the platform libm (see there);
