@@ -3,6 +3,13 @@
 // RL_FAST_MATH (NUM = 1: the opt-in tolerance build; the template parameter only keeps the kernel symbols of the two builds apart).
 #pragma once
 
+#ifndef RL_RELOAD_SCENE
+#define RL_RELOAD_SCENE 1    // persistent loop re-reads scene / render constants from the kernarg segment per iteration (see k_path_fused)
+#endif
+#ifndef RL_COOP_FETCH
+#define RL_COOP_FETCH 0     // 1: streaming scenes fetch BVH records wave-cooperatively (trace.hip.h: traverse_coop) — measured slower, kept for the record
+#endif
+
 namespace rl {
 
 // ------------------------------------------------------------------------------------------
@@ -15,7 +22,9 @@ namespace rl {
 __device__ unsigned long long g_stage_timers[16];
 #endif
 template <int MAT, bool MEDIUM, bool LDS_SCENE, int LIGHTS, int NUM>
-__global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAVES_STREAMING) k_path_fused(RenderConst rc, DeviceScene sc, StackConf stc) {
+__global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAVES_STREAMING) k_path_fused(RenderConst rc_arg, DeviceScene sc_arg, StackConf stc) {
+    const RenderConst& rc = rc_arg;
+    const DeviceScene& sc = sc_arg;
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneRecs recs;
     float4* after_scene = smem;
@@ -33,6 +42,9 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
     float* cold_f = reinterpret_cast<float*>(cold_q + 256 * FusedState::kColdQ);
     unsigned* cold_u = reinterpret_cast<unsigned*>(cold_f + 256 * FusedState::kColdF);
     const TravStackT<LDS_SCENE> stack = make_stack<LDS_SCENE>(stc, cold_u + 256 * FusedState::kColdU, tid);
+    // streaming scenes: per-wave staging area of the cooperative record fetch, after the stacks
+    constexpr bool COOP = !LDS_SCENE && RL_COOP_FETCH;
+    float4* stage = reinterpret_cast<float4*>(cold_u + 256 * FusedState::kColdU + 2 * 256 * stc.lds_levels) + (threadIdx.x >> 6) * kCoopStageFloat4s;
     FusedState ps;
     ps.cold_q = cold_q + threadIdx.x; ps.cold_f = cold_f + threadIdx.x; ps.cold_u = cold_u + threadIdx.x;
 #pragma unroll
@@ -60,7 +72,39 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
 #define RL_T0
 #define RL_T1(K, COND)
 #endif
+    if constexpr (COOP) {
+        // every lane of the wave stays in the loop until the whole wave has no work left: idle lanes are the loaders of the cooperative fetch
+        while (__ballot(!(PU(U_FLAGS) & ST_FINISHED)) != 0ull) {
+            RL_T0
+#ifdef RL_STAGE_TIMERS
+            ln[4] += 64;
+            const bool c0 = PU(U_FLAGS) & ST_REGEN;
+#endif
+            if (PU(U_FLAGS) & ST_REGEN) raygen_slot<true>(rc, sc, ps, n_samples, n_draws);
+            RL_T1(0, c0)
+            const bool has_ray = (PU(U_FLAGS) & ST_RAY) != 0u;
+            extend_slot_coop(sc, recs, stack, ps, has_ray, stage);
+            RL_T1(1, has_ray)
+            if (has_ray) shade_slot<MAT, MEDIUM, LIGHTS>(rc, sc, ps, PU(U_FLAGS), n_vertices, n_draws, n_shadow, n_ext);
+            RL_T1(2, has_ray)
+            const bool has_shadow = (PU(U_FLAGS) & ST_SHADOW) != 0u;
+            shadow_slot_coop(sc, recs, stack, ps, has_shadow, stage);
+            RL_T1(3, has_shadow)
+        }
+    } else
     while (!(PU(U_FLAGS) & ST_FINISHED)) {
+#if RL_RELOAD_SCENE
+        // The scene record (25 pointers, camera matrices, ...) and the render constants do not fit the scalar registers next to the saved
+        // exec masks of the stage functions: kept live across the loop they are spilled to VGPR lanes (v_writelane / v_readlane were ~600 of
+        // the kernel's ~4500 vector instructions, 126 spilled SGPRs).  Re-deriving their address from the kernarg segment once per iteration
+        // lets the compiler s_load what each stage needs instead (0-22 spilled SGPRs, 2-6 spilled VGPRs instead of 21; cbox 55.8 -> 51.9 ms,
+        // cbox + medium 136.0 -> 118.9 ms at 32 spp, same bits).  The render constants are re-read too where that paid (the medium kernels).
+        const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        constexpr size_t sc_off = (sizeof(RenderConst) + alignof(DeviceScene) - 1) / alignof(DeviceScene) * alignof(DeviceScene);
+        const DeviceScene& sc = *(const DeviceScene*)(ka + sc_off);
+        const RenderConst& rc = (MEDIUM || RL_RELOAD_SCENE > 1) ? *(const RenderConst*)ka : rc_arg;
+#endif
         RL_T0
 #ifdef RL_STAGE_TIMERS
         ln[4] += 64;

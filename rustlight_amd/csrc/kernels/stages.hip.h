@@ -153,6 +153,39 @@ RL_DEV void shadow_slot(const DeviceScene& sc, const SceneRecs& recs, const Stac
     if (shadow_visible(sc, recs, stack, load3(ps, F_OX), load3(ps, F_SX))) storec(ps, F_LR, loadc(ps, F_LR) + loadc(ps, F_CR));
 }
 
+// Wave-cooperative forms (trace.hip.h: traverse_coop): called by EVERY lane of the wave in step; `has_ray` / `has_shadow` say whether this
+// lane carries one, the others only help fetching.  Same state reads and writes as the per-lane forms for the lanes that do.
+template <class PS, class Stack>
+RL_DEV void extend_slot_coop(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, PS& ps, bool has_ray, float4* stage) {
+    const unsigned flags = PU(U_FLAGS);
+    const bool primary = ((flags >> ST_PREV_SHIFT) & 3u) == PREV_SENSOR;
+    V3 o = primary ? mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]) : load3(ps, F_OX);
+    V3 d = load3(ps, F_DX);
+    Hit hit; hit.t = kF32Max; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
+    traverse_coop<false>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
+                         o, d, kEps, kF32Max, hit, stack, has_ray, stage);
+    if (has_ray) {
+        PF(F_T) = hit.t; PF(F_U) = hit.u; PF(F_V) = hit.v;
+        PU(U_PRIM) = (unsigned)hit.prim;
+    }
+}
+template <class PS, class Stack>
+RL_DEV void shadow_slot_coop(const DeviceScene& sc, const SceneRecs& recs, const Stack& stack, PS& ps, bool has_shadow, float4* stage) {
+    // Acceleration::visible(p0, p1) (accel.rs:316-343), as shadow_visible
+    const V3 p0 = load3(ps, F_OX), p1 = load3(ps, F_SX);
+    V3 d = p1 - p0;
+    const float len = length(d);
+    d = d / len;
+    const float tfar = len * (1.0f - 0.00001f);
+    Hit hit; hit.t = tfar; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
+    const V3 lo = mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), hi = mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]);
+    const V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
+    float te;
+    const bool root_hit = has_shadow && slab(lo, hi, p0, inv_d, kEps, tfar, &te);   // root box missed => "occluded" (accel.rs:338-340)
+    const bool occluded = traverse_coop<true>(recs, sc.root, lo, hi, p0, d, kEps, tfar, hit, stack, root_hit, stage);
+    if (root_hit && !occluded) storec(ps, F_LR, loadc(ps, F_LR) + loadc(ps, F_CR));
+}
+
 // shade_slot<MAT, MEDIUM> — one path vertex of one slot.  MAT >= 0: the hit material is known to have that
 // BSDF type (per-BSDF code path, uniform over the calling lanes); MAT = -1: generic (run-time switch).
 template <int MAT, bool MEDIUM, int LIGHTS = LIGHTS_ANY, class PS>

@@ -278,6 +278,122 @@ RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3
     return found;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Wave-cooperative traversal for scenes that stream their BVH from L2 / HBM (the persistent kernel on the 508 k-triangle scene).
+//
+// EXPERIMENT, OFF BY DEFAULT (RL_COOP_FETCH = 0; bit-identical images, but 144 ms vs 110 ms at 1080p x 32 spp: DESIGN.md §4).
+// The counters suggested that the per-lane form is bound by the CU's vector-memory address path: TA busy 81-91 % of the kernel, TD 95 %,
+// at 12 % lane utilisation (profiles/r02_ta_living_room.json) — a wave64 `global_load_dwordx4` occupies the texture-address unit whether
+// 64 lanes or 6 are live, and a node costs four of them.  It is not: TA "busy" includes waiting for data, the kernel is bound by the
+// LATENCY of each trip's dependent fetch, and the two LDS round trips this form adds in front of and behind the load cost more than the
+// three saved load instructions give back.  Here the live lanes' 64-byte records are fetched by the WHOLE wave: the wanting lanes are ranked (ballot + mbcnt), their record indices travel to the rank slots with one ds_permute,
+// lane L then loads quarter L % 4 of the record of rank L / 4 — a quad reads 64 contiguous bytes, one request — into a per-wave LDS
+// staging area (32 records = 2 KB), and every wanting lane reads its own record back from LDS, the planes through the same
+// sign-swizzled addresses the LDS-staged scenes use.  One or two coalesced load instructions per trip instead of four scattered
+// ones; lanes ranked 32 or higher simply take their turn on the next trip (the wave is well filled then).
+// Every lane of the wave must call this in step (wave-uniform control flow): the loops below are driven by ballots and a lane
+// without a ray (or whose ray is done) stays as a loader.  Visits, order and arithmetic per ray are those of `traverse`.
+static constexpr int kCoopRecords = 32;                         // records staged per wave and trip
+static constexpr int kCoopStageFloat4s = 4 * kCoopRecords;      // per wave
+RL_DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+RL_DEV const float* coop_fetch64(const float4* base, int idx, bool want, float4* stage) {
+    const unsigned long long mask = __ballot(want);
+    const unsigned lane = lane_id();
+    const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));   // wanting lanes below this one
+    const unsigned n = (unsigned)__popcll(mask);
+    // record indices by rank: wanting lanes send theirs to slots 0 .. n-1, the others fill n .. 63 (a full permutation)
+    const unsigned slot = want ? below : n + (lane - below);
+    const int by_rank = __builtin_amdgcn_ds_permute((int)(slot << 2), idx);
+    const unsigned k0 = lane >> 2, q = lane & 3u;
+    const int id0 = __builtin_amdgcn_ds_bpermute((int)(k0 << 2), by_rank);
+    int id1 = 0;
+    if (n > 16u) id1 = __builtin_amdgcn_ds_bpermute((int)((k0 + 16u) << 2), by_rank);     // wave-uniform branch
+    const bool l0 = k0 < n, l1 = k0 + 16u < n;
+    float4 v0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), v1 = v0;
+    if (l0) v0 = base[4 * (size_t)id0 + q];          // both loads are in flight before either is stored
+    if (l1) v1 = base[4 * (size_t)id1 + q];
+    if (l0) stage[lane] = v0;
+    if (l1) stage[64u + lane] = v1;
+    // the records are read back by other lanes of this wave: LDS operations of one wave execute in order, the compiler only has to keep them so
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return (want && below < (unsigned)kCoopRecords) ? reinterpret_cast<const float*>(stage + 4u * below) : nullptr;
+}
+
+template <bool ANY_HIT, class Stack>
+RL_DEV bool traverse_coop(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3 o, V3 d, float tnear, float tfar,
+                          Hit& hit, const Stack& st, bool valid, float4* stage) {
+    const V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
+    float dummy;
+    int cur = RL_CHILD_NONE;
+    if (valid && slab(root_lo, root_hi, o, inv_d, tnear, tfar, &dummy)) cur = root;   // accel.rs:293-295 / 338-340
+    int sp = 0, leaf_k = 0;
+    bool found = false;
+    constexpr int kPop = -1;
+    const bool sx = inv_d.x < 0.0f, sy = inv_d.y < 0.0f, sz = inv_d.z < 0.0f;
+    // dword offsets of the near / far planes of the left child inside a node record (the right child's are 6 further)
+    const int onx = sx ? 3 : 0, ofx = sx ? 0 : 3, ony = sy ? 4 : 1, ofy = sy ? 1 : 4, onz = sz ? 5 : 2, ofz = sz ? 2 : 5;
+    while (__ballot(cur != RL_CHILD_NONE) != 0ull) {
+        // ---- inner nodes and stack entries
+        while (__ballot(cur >= 0 || cur == kPop) != 0ull) {
+            const float* rec = coop_fetch64(recs.nodes, cur, cur >= 0, stage);
+            if (rec) {
+                hit.steps++;
+                const float lnx = rec[onx], rnx = rec[onx + 6], lny = rec[ony], rny = rec[ony + 6], lnz = rec[onz], rnz = rec[onz + 6];
+                const float lfx = rec[ofx], rfx = rec[ofx + 6], lfy = rec[ofy], rfy = rec[ofy + 6], lfz = rec[ofz], rfz = rec[ofz + 6];
+                const int id1 = __float_as_int(rec[12]), id2 = __float_as_int(rec[13]);
+                const float d1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((lnx - o.x) * inv_d.x, (lny - o.y) * inv_d.y), (lnz - o.z) * inv_d.z), tnear);
+                const float f1 = __builtin_fminf(__builtin_fminf(__builtin_fminf((lfx - o.x) * inv_d.x, (lfy - o.y) * inv_d.y), (lfz - o.z) * inv_d.z), hit.t);
+                const float d2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((rnx - o.x) * inv_d.x, (rny - o.y) * inv_d.y), (rnz - o.z) * inv_d.z), tnear);
+                const float f2 = __builtin_fminf(__builtin_fminf(__builtin_fminf((rfx - o.x) * inv_d.x, (rfy - o.y) * inv_d.y), (rfz - o.z) * inv_d.z), hit.t);
+                const bool v1 = !(f1 <= d1), v2 = !(f2 <= d2);
+                const bool right_first = v2 & (!v1 | (d1 > d2));
+                st.push(sp, right_first ? id1 : id2, right_first ? d1 : d2);
+                sp += (v1 && v2) ? 1 : 0;
+                cur = (v1 || v2) ? (right_first ? id2 : id1) : kPop;
+            }
+            if (cur == kPop) {
+                cur = RL_CHILD_NONE;
+                if (sp > 0) {
+                    sp--;
+                    int code; float dist;
+                    st.get(sp, &code, &dist);
+                    cur = dist < hit.t ? code : kPop;
+                }
+            }
+        }
+        // ---- leaves (<= 2 triangles, tested in order: accel.rs:245-254); every lane that still has a ray holds one now
+        while (__ballot(cur != RL_CHILD_NONE && cur != kPop) != 0ull) {
+            const bool is_leaf = cur != RL_CHILD_NONE && cur != kPop;
+            const unsigned int code = (unsigned int)(~cur);
+            const int first = (int)(code >> 2), count = (int)(code & 3u);
+            const float* rec = coop_fetch64(recs.tris, first + leaf_k, is_leaf, stage);
+            if (rec) {
+                hit.tris++;
+                const float4* q = reinterpret_cast<const float4*>(rec);
+                const bool accepted = tri_test(q[0], q[1], q[2], q[3], o, d, hit, first + leaf_k);
+                found = found || accepted;
+                leaf_k++;
+                if (ANY_HIT && accepted) { cur = RL_CHILD_NONE; leaf_k = 0; }
+                else if (leaf_k == count) { cur = kPop; leaf_k = 0; }
+            }
+        }
+    }
+    if (!ANY_HIT) {   // barycentrics of the closest hit (see tri_test)
+        bool need = found;
+        while (__ballot(need) != 0ull) {
+            const float* rec = coop_fetch64(recs.tris, hit.prim, need, stage);
+            if (rec) {
+                const float4* q = reinterpret_cast<const float4*>(rec);
+                tri_uv(q[0], q[1], q[2], q[3], o, d, hit.t, &hit.u, &hit.v);
+                need = false;
+            }
+        }
+    }
+    return found;
+}
+
 // Stage the node / triangle records into LDS (cooperatively) in the padded layout above; inner-child references become dword offsets.
 RL_DEV void stage_scene_lds(const DeviceScene& sc, float4* lds_nodes, float4* lds_tris) {
     const float* gn = reinterpret_cast<const float*>(sc.nodes);

@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "common.hip.h"
+#include "fused.hip.h"     // RL_COOP_FETCH (LDS budget of the persistent kernel); the kernel template is not instantiated here
 #include "../host/scene.h"
 #include "wavefront.h"
 
@@ -410,7 +411,10 @@ static int ensure(T** p, size_t* cap, size_t n) {
 // Scenes that stream their BVH keep only kLdsStackLevelsStreaming levels in LDS: their pools are sparse (most waves of a
 // workgroup exit after the compaction), so what limits the live waves per CU is how many workgroups' stacks fit in LDS —
 // 508 k-triangle scene, 32 spp: 12 / 8 / 6 / 4 / 2 / 0 levels in LDS = 258 / 233 / 228 / 229 / 240 / 251 ms.
-static constexpr int kLdsStackLevelsStreaming = 6;
+#ifndef RL_LDS_LEVELS_STREAMING
+#define RL_LDS_LEVELS_STREAMING 6
+#endif
+static constexpr int kLdsStackLevelsStreaming = RL_LDS_LEVELS_STREAMING;
 static int lds_levels_of(const rl_context* ctx) { return std::min<int>((int)ctx->ds.stack_depth, ctx->lds_scene ? kLdsStackLevels : kLdsStackLevelsStreaming); }
 static size_t traversal_lds_bytes(const rl_context* ctx, bool lds_scene, unsigned block, bool with_list) {
     size_t stack = (size_t)2 * lds_levels_of(ctx) * block * sizeof(int);
@@ -620,7 +624,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     };
     double ms_fused = 0.0;
     if (fused) {
-        const size_t lds_fused = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + kFusedColdBytes;
+        const size_t lds_fused = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + kFusedColdBytes + ((ctx->lds_scene || !RL_COOP_FETCH) ? 0 : (size_t)4 * kCoopStageFloat4s * sizeof(float4));
         if (timing) hipEventRecord(ctx->events[0], st);
         (ctx->lds_scene ? (fast_math ? launch_fused_lds_fast : launch_fused_lds) : (fast_math ? launch_fused_stream_fast : launch_fused_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, ctx->area_lights_only, grid_all, block, lds_fused, st, rc, ds, stc);
         if (timing) hipEventRecord(ctx->events[1], st);
