@@ -97,40 +97,43 @@ RL_DEV void tri_uv(const float4 q0, const float4 q1, const float4 q2, const floa
     *u = div_rn(length(cross(pv, e2)), q3.x);
 }
 RL_DEV bool tri_test(const float4 q0, const float4 q1, const float4 q2, const float4 q3, V3 o, V3 d, Hit& hit, int prim) {
-    V3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z);
-    V3 n = mk3(q0.w, q1.w, q2.w);
-    float det = q3.x;
-    float denom = dot(d, n);
-    if (denom == 0.0f) return false;
-    float t = div_rn(-dot(o - v0, n), denom);
-    if (t < 0.0f) return false;
-    if (!(t < hit.t && t > 0.00001f)) return false;
-    V3 p = o + t * d;
-    V3 pv = p - v0;
-    V3 u0 = cross(e1, pv);
-    V3 w0 = cross(pv, e2);
-    if (dot(u0, n) < 0.0f || dot(w0, n) < 0.0f) return false;
-    const float uu = dot(u0, u0), ww = dot(w0, w0);
+    const V3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z);
+    const V3 n = mk3(q0.w, q1.w, q2.w);
+    const float det = q3.x;
+    const float denom = dot(d, n);
+    const float t = div_rn(-dot(o - v0, n), denom);
+    // The reference rejects on `denom == 0`, then on `t < 0`, and after the barycentrics on `!(t < its.t && t > 1e-5)`.  All of them are pure
+    // comparisons, and the last one implies the first two (denom == 0 makes t +-inf or NaN, which fails it; t > 1e-5 excludes t < 0), so one
+    // compare pair decides — evaluated without short-circuit: a wave runs every level of an early-out ladder anyway as long as one of its 64
+    // lanes gets through, and each level costs half a dozen scalar mask instructions (the ladder was ~35 of the ~130 instructions of a test).
+    const bool window = (t < hit.t) & (t > 0.00001f);
+    bool accept = false;
+    if (window) {
+        const V3 pv = (o + t * d) - v0;
+        const V3 u0 = cross(e1, pv);
+        const V3 w0 = cross(pv, e2);
+        const bool facing = !(dot(u0, n) < 0.0f) & !(dot(w0, n) < 0.0f);
+        const float uu = dot(u0, u0), ww = dot(w0, w0);
 #if defined(RL_FAST_MATH)
-    const float s = __builtin_amdgcn_sqrtf(uu) + __builtin_amdgcn_sqrtf(ww);
-    if (s <= det) { hit.t = t; hit.prim = prim; return true; }     // tolerance build: the 1-ulp estimate decides everywhere
-    return false;
-    const bool in_range = true;
-#elif defined(RL_TRI_REFERENCE_FORM)
-    const bool in_range = false; const float s = 0.0f;
+        accept = facing & (__builtin_amdgcn_sqrtf(uu) + __builtin_amdgcn_sqrtf(ww) <= det);     // tolerance build: the 1-ulp estimate decides everywhere
 #else
-    const float s = __builtin_amdgcn_sqrtf(uu) + __builtin_amdgcn_sqrtf(ww);
-    const bool in_range = __builtin_fminf(__builtin_fminf(uu, ww), det) >= 0x1p-100f;   // false for NaNs too
+#if defined(RL_TRI_REFERENCE_FORM)
+        const bool in_range = false; const float s = 0.0f;
+#else
+        const float s = __builtin_amdgcn_sqrtf(uu) + __builtin_amdgcn_sqrtf(ww);
+        const bool in_range = __builtin_fminf(__builtin_fminf(uu, ww), det) >= 0x1p-100f;   // false for NaNs too
 #endif
-    bool accept;
-    if (in_range && s <= det * 0.99999f) accept = true;
-    else if (in_range && s >= det * 1.00001f) accept = false;
-    else {
-        float v = div_rn(sqrt_rn(uu), det);
-        float u = div_rn(sqrt_rn(ww), det);
-        accept = !(u < 0.0f || v < 0.0f || u > 1.0f || v > 1.0f) && (u + v <= 1.0f);
+        const bool sure_in = in_range & (s <= det * 0.99999f), sure_out = in_range & (s >= det * 1.00001f);
+        accept = facing & sure_in;
+        if (facing & !sure_in & !sure_out) {      // inside the band (or denormal-range / non-finite inputs): the reference's own arithmetic
+            const float v = div_rn(sqrt_rn(uu), det);
+            const float u = div_rn(sqrt_rn(ww), det);
+            accept = !(u < 0.0f || v < 0.0f || u > 1.0f || v > 1.0f) && (u + v <= 1.0f);
+        }
+#endif
     }
-    if (accept) { hit.t = t; hit.prim = prim; }
+    hit.t = accept ? t : hit.t;
+    hit.prim = accept ? prim : hit.prim;
     return accept;
 }
 

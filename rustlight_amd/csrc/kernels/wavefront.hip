@@ -487,10 +487,13 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         // per pixel (rank r of N at spp = 128 N: 1020 tiles at N = 8) leaves most of those slots empty once the tiles that
         // look past the scene have drained, so it is cut into >= ~16 k workgroups (measured, rank 0 of 8 at 1024 spp:
         // 1 lane / pixel 122 ms, 8 lanes 69 ms, 16 lanes 69 ms; a full 8160-tile frame is best left at 1 lane: 64 vs 67 ms).
+        // Scenes that stream their BVH: all 64 lanes of a wave work on samples of ONE pixel (split = 64), so the camera rays of a wave are
+        // nearly identical and fetch the same nodes (508 k triangles, 32 spp: 1 / 4 / 16 / 32 lanes per pixel = 108.9 / 104.0 / 100.8 / 97.4 ms).
         const unsigned fused_groups = (n_pixels + 255u) / 256u;
         const unsigned fused_auto = fused_groups >= 6000u ? 1u : std::max(1u, 16384u / std::max(1u, fused_groups));
         const unsigned want = params->sample_split ? params->sample_split
-                            : (fused ? fused_auto : (ctx->lds_scene ? 1u : std::max(1u, (8u << 20) / std::max(1u, n_pixels))));
+                            : (fused ? (ctx->lds_scene ? fused_auto : std::max(fused_auto, 64u))
+                                     : (ctx->lds_scene ? 1u : std::max(1u, (8u << 20) / std::max(1u, n_pixels))));
         split = std::max(1u, std::min(want, params->spp));
         if ((size_t)n_pixels * params->spp * 3 * sizeof(float) > kSampleBufBudget) split = 1;
         while (split > 1 && (size_t)n_pixels * split > (size_t)0x7fffff00u) split--;
