@@ -18,7 +18,7 @@ CXX_SOURCES = ["host/scene.cpp", "host/bvh.cpp", "host/io.cpp", "host/pbrt.cpp",
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-value", "-Wno-unused-function"]
 # no SLP vectorizer for the kernels: it turns 3-vector math into packed v_pk_{add,mul}_f32, which issue at half rate on gfx950
 # and cost register-pair moves (measured: k_path_fused 65.9 -> 62.5 ms, same bits)
-HIP_EXTRA = ["-fno-slp-vectorize"]
+HIP_EXTRA = ["-fno-slp-vectorize", "-Wno-bitwise-instead-of-logical"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXX = os.environ.get("CXX", "g++")
 
