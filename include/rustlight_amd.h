@@ -225,7 +225,7 @@ typedef struct rl_path_params {
     uint32_t numerics;
 } rl_path_params;
 
-void rl_path_params_default(rl_path_params* params);   /* CLI defaults: examples/cli.rs:53-61,167-168 */
+void rl_path_params_default(rl_path_params* params);   /* CLI defaults: examples/cli.rs:53-61,167-168; stream_mode = RL_STREAM_REFERENCE_ORDER */
 
 /* Counters returned by a render (device atomics). */
 typedef struct rl_render_stats {

@@ -405,10 +405,12 @@ class IntegratorPathTracing:
     """struct IntegratorPathTracing (src/integrators/explicit/path.rs:14-20) + Integrator::compute."""
 
     def __init__(self, min_depth=0, max_depth=None, rr_depth=0, strategy=STRATEGY_ALL, single_scattering=False,
-                 stream_mode=STREAM_PER_SAMPLE, device=0):
+                 stream_mode=STREAM_REFERENCE_ORDER, device=0, numerics=NUMERICS_EXACT):
+        """stream_mode: the plugin's default is rustlight's own per-block stream order (seed-for-seed the reference's image);
+        STREAM_PER_SAMPLE is the opt-in throughput decomposition."""
         self.min_depth, self.max_depth, self.rr_depth = min_depth, max_depth, rr_depth
         self.strategy, self.single_scattering = strategy, single_scattering
-        self.stream_mode, self.device = stream_mode, device
+        self.stream_mode, self.device, self.numerics = stream_mode, device, numerics
         self.last_stats = None
         self._ctx = None
 
@@ -419,7 +421,7 @@ class IntegratorPathTracing:
         w, h = scene.size
         seeds = sampler.block_seeds(w, h)
         p = path_params(nb_samples, self.min_depth, self.max_depth, self.rr_depth, self.strategy, self.single_scattering,
-                        self.stream_mode, sampler.variant)
+                        self.stream_mode, sampler.variant, numerics=self.numerics)
         img, self.last_stats = self._ctx.render(seeds, p)
         return img
 

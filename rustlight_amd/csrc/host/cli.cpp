@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
     std::string cmd, ao_distance = "1.0", average, equal_time;
     bool ao_normal_correction = false;
     size_t nb_bsdf = 1, nb_light = 1;
-    rl_stream_mode mode = RL_STREAM_PER_SAMPLE;
+    rl_stream_mode mode = RL_STREAM_REFERENCE_ORDER;   // like rustlight; `--stream-mode per-sample` trades the seed-for-seed image for throughput
     uint32_t numerics = RL_NUMERICS_EXACT;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];

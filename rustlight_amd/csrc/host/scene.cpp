@@ -440,7 +440,7 @@ void rl_path_params_default(rl_path_params* p) {
     p->has_rr_depth = 1; p->rr_depth = 0;     // "0"
     p->strategy = RL_STRATEGY_ALL;            // "all"
     p->single_scattering = 0;
-    p->stream_mode = RL_STREAM_PER_SAMPLE;
+    p->stream_mode = RL_STREAM_REFERENCE_ORDER;   // the drop-in default: the image `-r independent:SEED` renders in rustlight; per-sample streams are opt-in
     p->seed_variant = 0;
     p->shard_index = 0; p->shard_count = 1;
     p->pool_slots = 0;
