@@ -109,7 +109,12 @@ def main():
     ctx = api.Context(scene, device_index)          # BVH build + upload: untimed, like the reference (mod.rs:280)
     fb = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device=dev)
     host_fb = torch.zeros((args.height, args.width, 3), dtype=torch.float32).pin_memory() if rank == 0 else None
-    stream = torch.cuda.current_stream().cuda_stream
+    # ONE explicit stream for everything a step enqueues (render, reduce, download): torch's default stream has handle 0, which the C-ABI
+    # reads as "use the context's own stream" — the next step's framebuffer memset would then race the previous step's reduce / download
+    work_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(work_stream)
+    stream = work_stream.cuda_stream
+    assert stream != 0
 
     # weak scaling: the image is fixed and spp grows with the GPU count (128 spp at N=1 ... 1024 spp at N=8 =
     # BASELINE configs[3]), so every GPU always traces W*H*128 camera samples per step.
