@@ -27,6 +27,23 @@ def test_library_exports_every_declared_symbol(built):
 def test_kernels_are_compiled_for_gfx950(built):
     data = open(api.LIB_PATH, "rb").read()
     assert b"gfx950" in data and b"k_extend" in data and b"k_shade" in data and b"k_shadow" in data and b"k_raygen" in data
+    assert b"k_path_fused" in data and b"k_pixel_mc" in data
+
+
+def test_library_links_rccl_for_the_framebuffer_reduce(built):
+    """rl_multi_render_path reduces the per-GPU framebuffers with ncclReduce over xGMI inside the product library."""
+    import subprocess
+    out = subprocess.run(["readelf", "-d", api.LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl.so" in out, out
+    syms = subprocess.run(["nm", "-D", "--undefined-only", api.LIB_PATH], capture_output=True, text=True).stdout
+    assert "ncclReduce" in syms and "ncclCommInitAll" in syms and "ncclGroupStart" in syms
+
+
+def test_path_params_defaults_are_the_reference_cli_defaults(built):
+    p = api.abi.PathParams()
+    api.lib().rl_path_params_default(ctypes.byref(p))
+    assert (p.spp, p.has_min_depth, p.min_depth, p.has_max_depth, p.has_rr_depth, p.rr_depth, p.strategy) == (1, 1, 0, 0, 1, 0, api.STRATEGY_ALL)
+    assert p.stream_mode == api.STREAM_REFERENCE_ORDER and p.numerics == api.NUMERICS_EXACT     # seed-for-seed rustlight's streams, exact arithmetic
 
 
 def test_no_gpu_means_loud_failure_not_fallback(built, cbox64):
@@ -36,6 +53,8 @@ def test_no_gpu_means_loud_failure_not_fallback(built, cbox64):
         pytest.skip("GPU present")
     with pytest.raises(api.NoDeviceError):
         api.Context(api.Scene(cbox64))
+    with pytest.raises(api.NoDeviceError):                     # the multi-GPU entry (RCCL reduce in the library) has no fallback either
+        api.MultiContext(api.Scene(cbox64), 2)
     # the CLI (C++ mirror of examples/cli.rs) parses, loads and builds the scene, then refuses to render without a device
     import subprocess
     cli = os.path.join(os.path.dirname(api.LIB_PATH), "rustlight-amd")
