@@ -169,8 +169,8 @@ def main():
             seeds = api.IndependentSampler(args.steps - 1).block_seeds(args.width, args.height)
             single, _ = ctx.render(seeds, params(0, 1))
             crc_single = zlib.crc32(single.tobytes())
-            if crc_single != crc:
-                raise SystemExit(f"{world}-GPU image CRC {crc:08x} != 1-GPU image CRC {crc_single:08x}")
+            if crc_single != crc:       # reported in the JSON (crc_match: false) rather than raised: the other ranks are waiting in a barrier
+                print(f"ERROR: {world}-GPU image CRC {crc:08x} != 1-GPU image CRC {crc_single:08x}", file=sys.stderr)
         # ---- roofline.  Algorithmic bytes per unit:
         #   k_raygen 108 B/camera sample, k_extend 44 B/ray, k_shade 280 B/vertex, k_shadow 72 B/shadow ray,
         #   k_path_fused (all four stages in one persistent launch): the whole-pipeline figure
