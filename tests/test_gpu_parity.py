@@ -429,6 +429,8 @@ def test_randomized_parity(built):
     from tests.parity_fuzz import run
     n, bad = run(budget=25.0, seed=3)
     assert bad == 0 and n >= 100, (n, bad)
+    n, bad = run(budget=12.0, seed=4, fast=True)            # the same generator, eligible cases also through the tolerance build (statistical bar)
+    assert bad == 0 and n >= 20, (n, bad)
 
 
 def test_non_finite_and_degenerate_geometry_parity(built):
