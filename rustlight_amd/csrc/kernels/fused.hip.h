@@ -7,7 +7,7 @@
 #define RL_RELOAD_SCENE 1    // persistent loop re-reads scene / render constants from the kernarg segment per iteration (see k_path_fused)
 #endif
 #ifndef RL_COOP_FETCH
-#define RL_COOP_FETCH 0     // 1: streaming scenes fetch BVH records wave-cooperatively (trace.hip.h: traverse_coop) — measured slower, kept for the record
+#define RL_COOP_FETCH 0     // 1 / 2: streaming scenes fetch BVH records wave-cooperatively (trace.hip.h: traverse_coop; 1 = LDS staging, 2 = registers + ds_bpermute) — both measured slower, kept for the record
 #endif
 
 namespace rl {

@@ -211,7 +211,8 @@ struct NodeFetchGlobal {
     RL_DEV NodeFetchGlobal(const SceneRecs& recs, V3 inv_d) : nodes(recs.nodes), sx(inv_d.x < 0.0f), sy(inv_d.y < 0.0f), sz(inv_d.z < 0.0f) {}
     RL_DEV NodePlanes operator()(int cur) const {
         const float4* q = nodes + 4 * cur;
-        const float4 a = q[0], b = q[1], c = q[2], e = q[3];
+        const float4 a = q[0], b = q[1], c = q[2];
+        const float4 e = q[3];      // (the compiler narrows this to the two child references, and the triangle quarters to what tri_test reads)
         NodePlanes p;
         p.lnx = sx ? a.w : a.x; p.lfx = sx ? a.x : a.w; p.lny = sy ? b.x : a.y; p.lfy = sy ? a.y : b.x; p.lnz = sz ? b.y : a.z; p.lfz = sz ? a.z : b.y;
         p.rnx = sx ? c.y : b.z; p.rfx = sx ? b.z : c.y; p.rny = sy ? c.z : b.w; p.rfy = sy ? b.w : c.z; p.rnz = sz ? c.w : c.x; p.rfz = sz ? c.x : c.w;
@@ -284,7 +285,8 @@ RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3
 // ------------------------------------------------------------------------------------------------------------------------------
 // Wave-cooperative traversal for scenes that stream their BVH from L2 / HBM (the persistent kernel on the 508 k-triangle scene).
 //
-// EXPERIMENT, OFF BY DEFAULT (RL_COOP_FETCH = 0; bit-identical images, but 144 ms vs 110 ms at 1080p x 32 spp: DESIGN.md §4).
+// EXPERIMENT, OFF BY DEFAULT (RL_COOP_FETCH = 0; bit-identical images, but 144 ms (LDS staging) / 145 ms (registers + ds_bpermute) vs 97-110 ms at
+// 1080p x 32 spp: DESIGN.md §4).
 // The counters suggested that the per-lane form is bound by the CU's vector-memory address path: TA busy 81-91 % of the kernel, TD 95 %,
 // at 12 % lane utilisation (profiles/r02_ta_living_room.json) — a wave64 `global_load_dwordx4` occupies the texture-address unit whether
 // 64 lanes or 6 are live, and a node costs four of them.  It is not: TA "busy" includes waiting for data, the kernel is bound by the
@@ -324,6 +326,39 @@ RL_DEV const float* coop_fetch64(const float4* base, int idx, bool want, float4*
     return (want && below < (unsigned)kCoopRecords) ? reinterpret_cast<const float*>(stage + 4u * below) : nullptr;
 }
 
+// The same fetch without LDS memory (RL_COOP_FETCH = 2): the loaded quarters stay in the loader lanes' registers and every owner pulls its NDW
+// dwords with ds_bpermute (the LDS crossbar, no storage), so the kernel's LDS budget — and with it 6 waves/SIMD — is untouched.
+template <int NDW>
+RL_DEV bool coop_fetch_regs(const float4* base, int idx, bool want, float (&out)[NDW]) {
+    const unsigned long long mask = __ballot(want);
+    const unsigned lane = lane_id();
+    const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    const unsigned n = (unsigned)__popcll(mask);
+    const unsigned slot = want ? below : n + (lane - below);
+    const int by_rank = __builtin_amdgcn_ds_permute((int)(slot << 2), idx);
+    const unsigned k0 = lane >> 2, q = lane & 3u;
+    const int id0 = __builtin_amdgcn_ds_bpermute((int)(k0 << 2), by_rank);
+    int id1 = 0;
+    if (n > 16u) id1 = __builtin_amdgcn_ds_bpermute((int)((k0 + 16u) << 2), by_rank);
+    float4 v0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), v1 = v0;
+    if (k0 < n) v0 = base[4 * (size_t)id0 + q];
+    if (k0 + 16u < n) v1 = base[4 * (size_t)id1 + q];
+    const unsigned src = (below & 15u) << 4;                     // byte address of lane 4 * (rank % 16) in the bpermute address space
+#pragma unroll
+    for (int f = 0; f < NDW; f++) {
+        const int addr = (int)(src + (unsigned)((f >> 2) << 2));
+        const float a0 = (f & 3) == 0 ? v0.x : (f & 3) == 1 ? v0.y : (f & 3) == 2 ? v0.z : v0.w;
+        float x = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(a0)));
+        if (n > 16u) {                                           // wave-uniform
+            const float a1 = (f & 3) == 0 ? v1.x : (f & 3) == 1 ? v1.y : (f & 3) == 2 ? v1.z : v1.w;
+            const float y = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(a1)));
+            x = below >= 16u ? y : x;
+        }
+        out[f] = x;
+    }
+    return want && below < 32u;
+}
+
 template <bool ANY_HIT, class Stack>
 RL_DEV bool traverse_coop(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3 o, V3 d, float tnear, float tfar,
                           Hit& hit, const Stack& st, bool valid, float4* stage) {
@@ -340,12 +375,22 @@ RL_DEV bool traverse_coop(const SceneRecs& recs, int root, V3 root_lo, V3 root_h
     while (__ballot(cur != RL_CHILD_NONE) != 0ull) {
         // ---- inner nodes and stack entries
         while (__ballot(cur >= 0 || cur == kPop) != 0ull) {
+#if RL_COOP_FETCH == 2
+            float rec[14];
+            const bool got = coop_fetch_regs<14>(recs.nodes, cur, cur >= 0, rec);
+            if (got) {
+                hit.steps++;
+                const float lnx = sx ? rec[3] : rec[0], lfx = sx ? rec[0] : rec[3], lny = sy ? rec[4] : rec[1], lfy = sy ? rec[1] : rec[4], lnz = sz ? rec[5] : rec[2], lfz = sz ? rec[2] : rec[5];
+                const float rnx = sx ? rec[9] : rec[6], rfx = sx ? rec[6] : rec[9], rny = sy ? rec[10] : rec[7], rfy = sy ? rec[7] : rec[10], rnz = sz ? rec[11] : rec[8], rfz = sz ? rec[8] : rec[11];
+                const int id1 = __float_as_int(rec[12]), id2 = __float_as_int(rec[13]);
+#else
             const float* rec = coop_fetch64(recs.nodes, cur, cur >= 0, stage);
             if (rec) {
                 hit.steps++;
                 const float lnx = rec[onx], rnx = rec[onx + 6], lny = rec[ony], rny = rec[ony + 6], lnz = rec[onz], rnz = rec[onz + 6];
                 const float lfx = rec[ofx], rfx = rec[ofx + 6], lfy = rec[ofy], rfy = rec[ofy + 6], lfz = rec[ofz], rfz = rec[ofz + 6];
                 const int id1 = __float_as_int(rec[12]), id2 = __float_as_int(rec[13]);
+#endif
                 const float d1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((lnx - o.x) * inv_d.x, (lny - o.y) * inv_d.y), (lnz - o.z) * inv_d.z), tnear);
                 const float f1 = __builtin_fminf(__builtin_fminf(__builtin_fminf((lfx - o.x) * inv_d.x, (lfy - o.y) * inv_d.y), (lfz - o.z) * inv_d.z), hit.t);
                 const float d2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((rnx - o.x) * inv_d.x, (rny - o.y) * inv_d.y), (rnz - o.z) * inv_d.z), tnear);
@@ -371,10 +416,18 @@ RL_DEV bool traverse_coop(const SceneRecs& recs, int root, V3 root_lo, V3 root_h
             const bool is_leaf = cur != RL_CHILD_NONE && cur != kPop;
             const unsigned int code = (unsigned int)(~cur);
             const int first = (int)(code >> 2), count = (int)(code & 3u);
+#if RL_COOP_FETCH == 2
+            float rec[13];
+            const bool got = coop_fetch_regs<13>(recs.tris, first + leaf_k, is_leaf, rec);
+            if (got) {
+                hit.tris++;
+                const float4 q[4] = {make_float4(rec[0], rec[1], rec[2], rec[3]), make_float4(rec[4], rec[5], rec[6], rec[7]), make_float4(rec[8], rec[9], rec[10], rec[11]), make_float4(rec[12], 0.0f, 0.0f, 0.0f)};
+#else
             const float* rec = coop_fetch64(recs.tris, first + leaf_k, is_leaf, stage);
             if (rec) {
                 hit.tris++;
                 const float4* q = reinterpret_cast<const float4*>(rec);
+#endif
                 const bool accepted = tri_test(q[0], q[1], q[2], q[3], o, d, hit, first + leaf_k);
                 found = found || accepted;
                 leaf_k++;
@@ -386,9 +439,16 @@ RL_DEV bool traverse_coop(const SceneRecs& recs, int root, V3 root_lo, V3 root_h
     if (!ANY_HIT) {   // barycentrics of the closest hit (see tri_test)
         bool need = found;
         while (__ballot(need) != 0ull) {
+#if RL_COOP_FETCH == 2
+            float rec[13];
+            const bool got = coop_fetch_regs<13>(recs.tris, hit.prim, need, rec);
+            if (got) {
+                const float4 q[4] = {make_float4(rec[0], rec[1], rec[2], rec[3]), make_float4(rec[4], rec[5], rec[6], rec[7]), make_float4(rec[8], rec[9], rec[10], rec[11]), make_float4(rec[12], 0.0f, 0.0f, 0.0f)};
+#else
             const float* rec = coop_fetch64(recs.tris, hit.prim, need, stage);
             if (rec) {
                 const float4* q = reinterpret_cast<const float4*>(rec);
+#endif
                 tri_uv(q[0], q[1], q[2], q[3], o, d, hit.t, &hit.u, &hit.v);
                 need = false;
             }

@@ -627,7 +627,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     };
     double ms_fused = 0.0;
     if (fused) {
-        const size_t lds_fused = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + kFusedColdBytes + ((ctx->lds_scene || !RL_COOP_FETCH) ? 0 : (size_t)4 * kCoopStageFloat4s * sizeof(float4));
+        const size_t lds_fused = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + kFusedColdBytes + ((ctx->lds_scene || RL_COOP_FETCH != 1) ? 0 : (size_t)4 * kCoopStageFloat4s * sizeof(float4));
         if (timing) hipEventRecord(ctx->events[0], st);
         (ctx->lds_scene ? (fast_math ? launch_fused_lds_fast : launch_fused_lds) : (fast_math ? launch_fused_stream_fast : launch_fused_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, ctx->area_lights_only, grid_all, block, lds_fused, st, rc, ds, stc);
         if (timing) hipEventRecord(ctx->events[1], st);
