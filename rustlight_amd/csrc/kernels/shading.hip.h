@@ -663,7 +663,15 @@ RL_DEV float light_direct_pdf(const DeviceScene& sc, const MeshRecord& mr, int p
 // ------------------------------------------------------------------------------------------
 // HomogenousVolume (src/volume.rs:95-141) and PhaseFunction (12-68)
 struct MediumSample { float t; Col w; bool exited; };
-RL_DEV Col cexp(Col c) { return mkc(m_expf(c.r), m_expf(c.g), m_expf(c.b)); }
+// exp per channel.  The reference CLI only ever creates grey media (`-m sigma_s[:sigma_a[:g]]` fills all three channels with one value,
+// examples/cli.rs:381-385), so the three arguments are usually equal and one evaluation of the (f64, ~40-instruction) recipe serves all of them —
+// same inputs, same bits.  The test is per lane but all lanes of a grey medium agree, so the branch never diverges.
+RL_DEV Col cexp(Col c) {
+#ifndef RL_NO_GREY_EXP
+    if ((c.r == c.g) & (c.g == c.b)) { const float e = m_expf(c.r); return mkc(e, e, e); }
+#endif
+    return mkc(m_expf(c.r), m_expf(c.g), m_expf(c.b));
+}
 RL_DEV MediumSample medium_sample(const MediumRecord& m, float max_t, float u) {
     Col sigma_t = mkc(m.sigma_t[0], m.sigma_t[1], m.sigma_t[2]);
     Col sigma_s = mkc(m.sigma_s[0], m.sigma_s[1], m.sigma_s[2]);
