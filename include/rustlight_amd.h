@@ -272,6 +272,34 @@ int rl_render_path(rl_context* ctx, const rl_path_params* params, const uint64_t
                    size_t n_blocks, float* out_rgb, int out_is_device, void* stream,
                    rl_render_stats* stats);
 
+/* ---- the whole scene as ONE plain-old-data description ("SceneDesc POD: counts + pointers") ------------------
+ * What a Rust host fills from `&Scene` (src/scene.rs:16-30) in one go instead of the builder calls above; the arrays are only read during
+ * the call.  Equivalent to: rl_scene_create, rl_scene_set_camera, rl_scene_add_bitmap (in order: their ids are 0, 1, ...), rl_scene_add_mesh
+ * (in order), rl_scene_set_medium, rl_scene_add_point_light / _directional_light (in order), rl_scene_set_environment[_map],
+ * rl_scene_enable_ats, rl_scene_build_emitters — with the same checks and error codes. */
+typedef struct rl_mesh_desc {          /* struct Mesh (src/geometry.rs:107-119) */
+    const float* vertices; size_t n_vertices;      /* xyz */
+    const uint32_t* indices; size_t n_triangles;   /* 3 per triangle */
+    const float* normals;                          /* xyz per vertex or NULL */
+    const float* uv;                               /* uv per vertex or NULL */
+    rl_bsdf_desc bsdf;
+    int32_t has_emission; float emission_rgb[3];   /* EmissionType::Color */
+} rl_mesh_desc;
+typedef struct rl_bitmap_desc { uint32_t width, height; const float* rgb; } rl_bitmap_desc;
+typedef struct rl_light_desc { int32_t kind;       /* 0 = PointEmitter { position = a }, 1 = DirectionalLight { direction = a } */
+                               float a[3]; float intensity[3]; } rl_light_desc;
+typedef struct rl_scene_desc {
+    uint32_t width, height; float fov_degrees; int32_t fov_axis; float to_world[16]; int32_t flip;   /* Camera::new */
+    const rl_mesh_desc* meshes; size_t n_meshes;
+    const rl_bitmap_desc* bitmaps; size_t n_bitmaps;
+    const rl_light_desc* lights; size_t n_lights;
+    int32_t has_environment; float environment_rgb[3];            /* EnvironmentLightColor::Constant */
+    uint32_t env_map_width, env_map_height; const float* env_map_rgb;   /* EnvironmentLightColor::Texture (0 x 0 / NULL: none) */
+    int32_t has_medium; float sigma_a[3], sigma_s[3]; int32_t phase_type; float g;   /* HomogenousVolume */
+    int32_t build_ats;                                             /* Scene::build_emitters(build_ats) */
+} rl_scene_desc;
+int rl_scene_create_from_desc(const rl_scene_desc* desc, rl_scene** out);
+
 /* ---- several GPUs of one node behind one call ------------------------------------------------------
  * The reference merges its per-block bitmaps with `accumulate_bitmap` (src/integrators/mod.rs:445-448); here every GPU renders the
  * blocks b % N == g into its own zeroed framebuffer in HBM and ONE ncclReduce(sum, root = first device) over xGMI merges them —

@@ -21,6 +21,29 @@ class BsdfDesc(C.Structure):
                 ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("glass_eta", C.c_float)]
 
 
+class MeshDesc(C.Structure):
+    _fields_ = [("vertices", C.POINTER(C.c_float)), ("n_vertices", C.c_size_t), ("indices", C.POINTER(C.c_uint32)), ("n_triangles", C.c_size_t),
+                ("normals", C.POINTER(C.c_float)), ("uv", C.POINTER(C.c_float)), ("bsdf", BsdfDesc), ("has_emission", C.c_int32),
+                ("emission_rgb", C.c_float * 3)]
+
+
+class BitmapDesc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgb", C.POINTER(C.c_float))]
+
+
+class LightDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("a", C.c_float * 3), ("intensity", C.c_float * 3)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("fov_degrees", C.c_float), ("fov_axis", C.c_int32), ("to_world", C.c_float * 16),
+                ("flip", C.c_int32), ("meshes", C.POINTER(MeshDesc)), ("n_meshes", C.c_size_t), ("bitmaps", C.POINTER(BitmapDesc)),
+                ("n_bitmaps", C.c_size_t), ("lights", C.POINTER(LightDesc)), ("n_lights", C.c_size_t), ("has_environment", C.c_int32),
+                ("environment_rgb", C.c_float * 3), ("env_map_width", C.c_uint32), ("env_map_height", C.c_uint32),
+                ("env_map_rgb", C.POINTER(C.c_float)), ("has_medium", C.c_int32), ("sigma_a", C.c_float * 3), ("sigma_s", C.c_float * 3),
+                ("phase_type", C.c_int32), ("g", C.c_float), ("build_ats", C.c_int32)]
+
+
 class Sampler(C.Structure):
     _fields_ = [("s", C.c_uint64 * 4)]
 

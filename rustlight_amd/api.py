@@ -28,7 +28,7 @@ NUMERICS_EXACT, NUMERICS_FAST = 0, 1
 
 # every symbol include/rustlight_amd.h declares (tests check the .so exports all of them)
 PUBLIC_SYMBOLS = [
-    "rl_scene_create", "rl_scene_destroy", "rl_scene_set_camera", "rl_scene_scale_image", "rl_scene_add_mesh",
+    "rl_scene_create", "rl_scene_create_from_desc", "rl_scene_destroy", "rl_scene_set_camera", "rl_scene_scale_image", "rl_scene_add_mesh",
     "rl_scene_add_bitmap", "rl_scene_set_medium", "rl_scene_add_point_light", "rl_scene_add_directional_light",
     "rl_scene_set_environment", "rl_scene_set_environment_map", "rl_scene_build_emitters", "rl_scene_enable_ats", "rl_scene_load_pbrt", "rl_scene_load_mitsuba", "rl_scene_load",
     "rl_scene_image_size", "rl_scene_counts", "rl_sampler_seed", "rl_sampler_next_u64", "rl_sampler_next_f32",
@@ -60,6 +60,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, f32p, u32p, u64p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
     L.rl_scene_create.argtypes = [C.POINTER(vp)]
+    L.rl_scene_create_from_desc.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(vp)]
     L.rl_scene_destroy.argtypes = [vp]
     L.rl_scene_destroy.restype = None
     L.rl_scene_set_camera.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_float, C.c_int, f32p, C.c_int]
@@ -183,6 +184,58 @@ class Scene:
         if sd is not None and getattr(sd, "use_ats", False):
             _check(L.rl_scene_enable_ats(self.h, 1))
         _check(L.rl_scene_build_emitters(self.h))
+
+    @classmethod
+    def from_desc(cls, sd: S.SceneData) -> "Scene":
+        """The same scene through the one-call POD entry (rl_scene_create_from_desc, SURVEY §8(b) "SceneDesc")."""
+        keep = []                                  # numpy arrays must outlive the call
+        def fp(a):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.float32); keep.append(a)
+            return abi.fptr(a)
+        d = abi.SceneDesc()
+        d.width, d.height, d.fov_degrees, d.fov_axis, d.flip = sd.width, sd.height, sd.fov, sd.fov_axis, int(sd.flip)
+        d.to_world = (C.c_float * 16)(*np.asarray(sd.to_world, np.float32).ravel())
+        meshes = (abi.MeshDesc * max(1, len(sd.meshes)))()
+        for k, m in enumerate(sd.meshes):
+            v, i, n, uv, e = abi.mesh_arrays(m)
+            keep.extend([v, i])
+            meshes[k].vertices, meshes[k].n_vertices = abi.fptr(v), v.shape[0]
+            meshes[k].indices, meshes[k].n_triangles = abi.u32ptr(i), i.shape[0]
+            meshes[k].normals, meshes[k].uv = fp(n), fp(uv)
+            meshes[k].bsdf = abi.bsdf_desc(m.bsdf)
+            if e is not None:
+                meshes[k].has_emission = 1
+                meshes[k].emission_rgb = (C.c_float * 3)(*e)
+        d.meshes, d.n_meshes = meshes, len(sd.meshes)
+        bitmaps = (abi.BitmapDesc * max(1, len(sd.bitmaps)))()
+        for k, (w, h, rgb) in enumerate(sd.bitmaps):
+            bitmaps[k].width, bitmaps[k].height, bitmaps[k].rgb = w, h, fp(rgb)
+        d.bitmaps, d.n_bitmaps = bitmaps, len(sd.bitmaps)
+        lights = (abi.LightDesc * max(1, len(sd.lights)))()
+        for k, lt in enumerate(sd.lights):
+            lights[k].kind = 0 if lt["type"] == "point" else 1
+            lights[k].a = (C.c_float * 3)(*lt["a"])
+            lights[k].intensity = (C.c_float * 3)(*lt["intensity"])
+        d.lights, d.n_lights = lights, len(sd.lights)
+        if sd.environment is not None:
+            d.has_environment = 1
+            d.environment_rgb = (C.c_float * 3)(*sd.environment)
+        if sd.environment_map is not None:
+            em = np.ascontiguousarray(sd.environment_map, np.float32); keep.append(em)
+            d.env_map_width, d.env_map_height, d.env_map_rgb = em.shape[1], em.shape[0], abi.fptr(em)
+        if sd.medium is not None:
+            d.has_medium = 1
+            d.sigma_a = (C.c_float * 3)(*sd.medium.sigma_a)
+            d.sigma_s = (C.c_float * 3)(*sd.medium.sigma_s)
+            d.phase_type, d.g = sd.medium.phase, sd.medium.g
+        d.build_ats = int(bool(getattr(sd, "use_ats", False)))
+        h = C.c_void_p()
+        _check(lib().rl_scene_create_from_desc(C.byref(d), C.byref(h)))
+        obj = cls.__new__(cls)
+        obj.sd, obj.h = sd, h
+        return obj
 
     @classmethod
     def load_pbrt(cls, path: str, use_shading_normals: bool = True) -> "Scene":

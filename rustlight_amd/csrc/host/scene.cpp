@@ -432,6 +432,36 @@ int rl_generate_block_seeds(rl_sampler* master, uint32_t width, uint32_t height,
     return RL_OK;
 }
 
+// the scene as one POD — the builder calls above in their canonical order
+int rl_scene_create_from_desc(const rl_scene_desc* d, rl_scene** out) {
+    if (!d || !out) return RL_ERR_INVALID_ARGUMENT;
+    if ((d->n_meshes && !d->meshes) || (d->n_bitmaps && !d->bitmaps) || (d->n_lights && !d->lights)) return RL_ERR_INVALID_ARGUMENT;
+    rl_scene* s = nullptr;
+    int rc = rl_scene_create(&s);
+    if (rc != RL_OK) return rc;
+    auto fail = [&](int code) { rl_scene_destroy(s); return code < 0 ? code : RL_ERR_INVALID_ARGUMENT; };
+    if ((rc = rl_scene_set_camera(s, d->width, d->height, d->fov_degrees, d->fov_axis, d->to_world, d->flip)) != RL_OK) return fail(rc);
+    for (size_t i = 0; i < d->n_bitmaps; i++)
+        if ((rc = rl_scene_add_bitmap(s, d->bitmaps[i].width, d->bitmaps[i].height, d->bitmaps[i].rgb)) < 0) return fail(rc);
+    for (size_t i = 0; i < d->n_meshes; i++) {
+        const rl_mesh_desc& m = d->meshes[i];
+        if ((rc = rl_scene_add_mesh(s, m.vertices, m.n_vertices, m.indices, m.n_triangles, m.normals, m.uv, &m.bsdf, m.has_emission ? m.emission_rgb : nullptr)) < 0) return fail(rc);
+    }
+    if (d->has_medium && (rc = rl_scene_set_medium(s, d->sigma_a, d->sigma_s, d->phase_type, d->g)) != RL_OK) return fail(rc);
+    for (size_t i = 0; i < d->n_lights; i++) {
+        const rl_light_desc& l = d->lights[i];
+        if (l.kind != 0 && l.kind != 1) { rl_set_error("unknown light kind"); return fail(RL_ERR_INVALID_ARGUMENT); }
+        if ((rc = (l.kind == 0 ? rl_scene_add_point_light : rl_scene_add_directional_light)(s, l.a, l.intensity)) != RL_OK) return fail(rc);
+    }
+    if (d->has_environment && (rc = rl_scene_set_environment(s, d->environment_rgb)) != RL_OK) return fail(rc);
+    if (d->env_map_rgb && d->env_map_width && d->env_map_height &&
+        (rc = rl_scene_set_environment_map(s, d->env_map_width, d->env_map_height, d->env_map_rgb)) != RL_OK) return fail(rc);
+    if ((rc = rl_scene_enable_ats(s, d->build_ats ? 1 : 0)) != RL_OK) return fail(rc);
+    if ((rc = rl_scene_build_emitters(s)) != RL_OK) return fail(rc);
+    *out = s;
+    return RL_OK;
+}
+
 void rl_path_params_default(rl_path_params* p) {
     std::memset(p, 0, sizeof(*p));
     p->spp = 1;                               // Cli.nbsamples default (cli.rs:113-114)

@@ -220,3 +220,32 @@ def test_emitters_with_non_finite_area_or_flux_are_refused(built):
     [m for m in sd.meshes if m.emission][0].emission = (float("inf"), 1.0, 1.0)
     with pytest.raises(api.RustlightError, match="total flux is not finite"):
         api.Scene(sd)
+
+
+def test_scene_from_one_pod_description_equals_the_builder_calls(built):
+    """rl_scene_create_from_desc ("SceneDesc POD: counts + pointers") builds the scene the builder calls build: same BVH, camera,
+    emitter table, light tree; and refuses what they refuse."""
+    S = scenes
+    tex = S.cbox(32, 24)
+    tex.bitmaps = [(3, 2, np.arange(18, dtype=np.float32).reshape(2, 3, 3) / 18.0)]
+    tex.meshes[0].uv = np.zeros((len(tex.meshes[0].vertices), 2), np.float32)
+    tex.meshes[0].bsdf = S.Bsdf(type=S.DIFFUSE, diffuse={"type": S.TEX_BITMAP, "bitmap_id": 0, "color0": (1, 1, 1)})
+    cases = [S.cbox(40, 24), S.cbox_other_lights(24, 24), S.sky_scene(24, 20, keep_area_light=True), S.many_lights(24, 20, 3, glowing_spheres=1),
+             S.cbox_medium(24, 24, 0.5, 0.1, g=0.3), S.living_room(24, 16, n_spheres=8, tess=6), tex]
+    for sd in cases:
+        a, b = api.Scene(sd), api.Scene.from_desc(sd)
+        assert a.size == b.size and a.counts() == b.counts()
+        for x, y in zip(a.debug_bvh(), b.debug_bvh()):
+            np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(a.debug_emitters_cdf(), b.debug_emitters_cdf())
+        for x, y in zip(a.debug_ats(), b.debug_ats()):
+            np.testing.assert_array_equal(x, y)
+        for px, py in ((0.5, 0.5), (13.25, 7.75)):
+            for x, y in zip(a.camera_ray(px, py), b.camera_ray(px, py)):
+                np.testing.assert_array_equal(x, y)
+    bad = S.cbox(16, 16)
+    bad.meshes[1].bsdf = S.Bsdf(type=S.DIFFUSE, diffuse={"type": S.TEX_BITMAP, "bitmap_id": 3, "color0": (1, 1, 1)})
+    with pytest.raises(api.RustlightError, match="bitmap"):
+        api.Scene.from_desc(bad)
+    with pytest.raises(api.RustlightError, match="bitmap"):
+        api.Scene(bad)
