@@ -706,3 +706,13 @@ def test_fast_numerics_tolerance_mode(built):
         ctx.render(seeds, api.path_params(spp=1, numerics=api.NUMERICS_FAST, pipeline=api.PIPELINE_WAVEFRONT))
     with pytest.raises(api.RustlightError, match="numerics"):
         ctx.render(seeds, api.path_params(spp=1, numerics=7))
+
+
+def test_scene_from_pod_description_renders_the_same_image(built):
+    """The one-call POD entry (rl_scene_create_from_desc) and the builder calls describe the same scene to the kernels."""
+    for sd in (scenes.cbox(48, 32), scenes.living_room(48, 32, n_spheres=8, tess=6), scenes.cbox_medium(32, 32, 0.5)):
+        seeds = api.IndependentSampler(6).block_seeds(sd.width, sd.height)
+        a, sa = api.Context(api.Scene(sd), 0).render(seeds, api.path_params(spp=3, max_depth=6))
+        b, sb = api.Context(api.Scene.from_desc(sd), 0).render(seeds, api.path_params(spp=3, max_depth=6))
+        np.testing.assert_array_equal(a, b)
+        assert sa["vertices"] == sb["vertices"] and sa["rng_draws"] == sb["rng_draws"]
