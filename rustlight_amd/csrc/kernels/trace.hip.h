@@ -148,9 +148,8 @@ struct SceneRecs {
 // `stack` points at this lane's column of the LDS stack, entries are `stride` ints apart;
 // two ints per level: child code and the bits of its entry distance.
 //
-// Control flow is "while-while": every lane first descends inner nodes (or takes stack entries) until it holds a leaf (or is
-// done), then the wave tests leaves together.  Visit order and pruning are those of the reference's
-// recursion; only the interleaving between lanes changes (wave64 lane utilisation 32 % -> see profiles/).
+// Control flow: per-lane visit order and pruning are those of the reference's recursion; only the interleaving between lanes
+// changes — "while-while" phases on LDS-staged scenes, wave-voted node / leaf trips on streaming scenes (see traverse).
 // Per-lane traversal stack: the first `lds_levels` entries live in LDS (layout [level][lane] of 8-byte pairs,
 // conflict-free, one ds_read_b64 / ds_write_b64 per pop / push), deeper levels spill to a global overflow buffer
 // with the same coalesced layout.  LDS_ONLY (BVH depth <= the LDS levels, always the case for LDS-staged scenes)
@@ -161,6 +160,7 @@ struct NodeFetchGlobal;
 template <bool LDS_ONLY>
 struct TravStackT {
     using NodeFetch = typename std::conditional<LDS_ONLY, NodeFetchLds, NodeFetchGlobal>::type;   // LDS-only stacks go with LDS-staged scenes
+    static constexpr bool kLdsOnly = LDS_ONLY;
     static constexpr int kTriStride4 = LDS_ONLY ? kLdsTriStride4 : 4;                              // float4s between triangle records
     static constexpr int kNodeRefScale = LDS_ONLY ? 4 * kLdsNodeStride : 1;                        // inner-node reference = index x this (LDS: byte offset)
     static constexpr int lds_stride = 256;       // every traversal kernel runs 256-lane workgroups
@@ -221,6 +221,10 @@ struct NodeFetchGlobal {
     }
 };
 
+#ifndef RL_VOTE_NUM
+#define RL_VOTE_NUM 3      // streaming scenes: a node trip while (lanes with node / stack work) * DEN >= NUM * (lanes holding leaves)
+#define RL_VOTE_DEN 2
+#endif
 template <bool ANY_HIT, class Stack>
 RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3 o, V3 d, float tnear, float tfar,
                      Hit& hit, const Stack& st) {
@@ -231,48 +235,72 @@ RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3
     int sp = 0;
     bool found = false;
     typename Stack::NodeFetch fetch(recs, inv_d);
-    // Same visits, same order, one loop level less: the far child is stored unconditionally (the slot only counts when both children
-    // were hit) and a lane that needs the next stack entry takes ONE per trip of the node loop — a stale entry (its subtree lies behind
-    // the current hit) simply keeps the lane in the popping state — instead of spinning in a nested loop the rest of the wave waits for.
+    // Same visits, same order as the reference's recursion, one loop level less than a literal transcription: the far child is stored
+    // unconditionally (the slot only counts when both children were hit) and a lane that needs the next stack entry takes ONE per trip of the
+    // node loop — a stale entry (its subtree lies behind the current hit) simply keeps the lane in the popping state — instead of spinning in a
+    // nested loop the rest of the wave waits for.
     constexpr int kPop = -1;            // = ~0: a leaf code with zero triangles, which the builder never emits
-    while (cur != RL_CHILD_NONE) {
-        while (cur >= 0 || cur == kPop) {
-            if (cur >= 0) {
-                hit.steps++;
-                const NodePlanes p = fetch(cur);
-                const float d1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((p.lnx - o.x) * inv_d.x, (p.lny - o.y) * inv_d.y), (p.lnz - o.z) * inv_d.z), tnear);
-                const float f1 = __builtin_fminf(__builtin_fminf(__builtin_fminf((p.lfx - o.x) * inv_d.x, (p.lfy - o.y) * inv_d.y), (p.lfz - o.z) * inv_d.z), hit.t);
-                const float d2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((p.rnx - o.x) * inv_d.x, (p.rny - o.y) * inv_d.y), (p.rnz - o.z) * inv_d.z), tnear);
-                const float f2 = __builtin_fminf(__builtin_fminf(__builtin_fminf((p.rfx - o.x) * inv_d.x, (p.rfy - o.y) * inv_d.y), (p.rfz - o.z) * inv_d.z), hit.t);
-                const bool v1 = !(f1 <= d1), v2 = !(f2 <= d2);                 // box hit and entry distance < its.t
-                // the reference orders by distance with a missed box at +inf and keeps the left child first on ties
-                const bool right_first = v2 & (!v1 | (d1 > d2));
-                st.push(sp, right_first ? p.id1 : p.id2, right_first ? d1 : d2);
-                sp += (v1 && v2) ? 1 : 0;
-                cur = (v1 || v2) ? (right_first ? p.id2 : p.id1) : kPop;
-            }
-            if (cur == kPop) {
-                cur = RL_CHILD_NONE;
-                if (sp > 0) {
-                    sp--;
-                    int code; float dist;
-                    st.get(sp, &code, &dist);
-                    cur = dist < hit.t ? code : kPop;      // `if d2 < its.t` evaluated after the near subtree (accel.rs:279-284)
-                }
+    // one trip over inner nodes / stack entries for a lane in that state
+    auto node_trip = [&]() {
+        if (cur >= 0) {
+            hit.steps++;
+            const NodePlanes p = fetch(cur);
+            const float d1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((p.lnx - o.x) * inv_d.x, (p.lny - o.y) * inv_d.y), (p.lnz - o.z) * inv_d.z), tnear);
+            const float f1 = __builtin_fminf(__builtin_fminf(__builtin_fminf((p.lfx - o.x) * inv_d.x, (p.lfy - o.y) * inv_d.y), (p.lfz - o.z) * inv_d.z), hit.t);
+            const float d2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((p.rnx - o.x) * inv_d.x, (p.rny - o.y) * inv_d.y), (p.rnz - o.z) * inv_d.z), tnear);
+            const float f2 = __builtin_fminf(__builtin_fminf(__builtin_fminf((p.rfx - o.x) * inv_d.x, (p.rfy - o.y) * inv_d.y), (p.rfz - o.z) * inv_d.z), hit.t);
+            const bool v1 = !(f1 <= d1), v2 = !(f2 <= d2);                 // box hit and entry distance < its.t
+            // the reference orders by distance with a missed box at +inf and keeps the left child first on ties
+            const bool right_first = v2 & (!v1 | (d1 > d2));
+            st.push(sp, right_first ? p.id1 : p.id2, right_first ? d1 : d2);
+            sp += (v1 && v2) ? 1 : 0;
+            cur = (v1 || v2) ? (right_first ? p.id2 : p.id1) : kPop;
+        }
+        if (cur == kPop) {
+            cur = RL_CHILD_NONE;
+            if (sp > 0) {
+                sp--;
+                int code; float dist;
+                st.get(sp, &code, &dist);
+                cur = dist < hit.t ? code : kPop;      // `if d2 < its.t` evaluated after the near subtree (accel.rs:279-284)
             }
         }
-        if (cur != RL_CHILD_NONE) {
-            unsigned int code = (unsigned int)(~cur);
-            int first = (int)(code >> 2), count = (int)(code & 3u);
-            for (int k = 0; k < count; k++) {
-                hit.tris++;
-                const float4* q = recs.tris + Stack::kTriStride4 * (first + k);
-                if (tri_test(q[0], q[1], q[2], q[3], o, d, hit, first + k)) {
-                    found = true;
-                    if (ANY_HIT) return true;
-                }
+    };
+    // a leaf (<= 2 triangles, tested in order: accel.rs:245-254); returns true when an any-hit query is decided
+    auto leaf_visit = [&]() -> bool {
+        const unsigned int code = (unsigned int)(~cur);
+        const int first = (int)(code >> 2), count = (int)(code & 3u);
+        for (int k = 0; k < count; k++) {
+            hit.tris++;
+            const float4* q = recs.tris + Stack::kTriStride4 * (first + k);
+            if (tri_test(q[0], q[1], q[2], q[3], o, d, hit, first + k)) {
+                found = true;
+                if (ANY_HIT) return true;
             }
-            cur = kPop;
+        }
+        cur = kPop;
+        return false;
+    };
+    if (Stack::kLdsOnly) {
+        // scenes staged in LDS (instruction-issue bound): "while-while" — every lane first descends inner nodes (or takes stack entries) until it
+        // holds a leaf (or is done), then the wave tests leaves together
+        while (cur != RL_CHILD_NONE) {
+            while (cur >= 0 || cur == kPop) node_trip();
+            if (cur != RL_CHILD_NONE && leaf_visit()) return true;
+        }
+    } else {
+        // scenes that stream their BVH (bound by vector-memory instructions: a trip costs the same address-path cycles for 3 live lanes as for
+        // 60): which kind of trip runs next is VOTED by the wave — a node trip while the lanes holding inner nodes / stack work are at least 1.5 x
+        // the lanes holding leaves, a leaf trip otherwise; the minority waits instead of dragging the wave through a sparsely filled trip
+        // (508 k triangles, 32 spp: node : leaf >= 0 (while-while) / 1/4 / 1/2 / 1 / 3/2 / 2 / 4 / 8 / leaf-first = 97.0 / 91.7 / 87.1 / 83.6 / 81.8 /
+        // 82.5 / 84.8 / 89.3 / 98.7 ms, both kinds in every trip: 98.1 ms; on LDS-staged scenes the ballots cost more than they save: 62 vs 50 ms)
+        for (;;) {
+            const bool in_node = cur >= 0 || cur == kPop;
+            const bool in_leaf = !in_node && cur != RL_CHILD_NONE;
+            const int n_node = __popcll(__ballot(in_node)), n_leaf = __popcll(__ballot(in_leaf));
+            if (n_node + n_leaf == 0) break;
+            if (n_node > 0 && n_node * RL_VOTE_DEN >= RL_VOTE_NUM * n_leaf) { if (in_node) node_trip(); }
+            else if (in_leaf && leaf_visit()) return true;
         }
     }
     if (!ANY_HIT && found) {   // barycentrics of the closest hit (see tri_test)
