@@ -42,6 +42,8 @@ def parse_args(argv=None):
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=128, help="samples per pixel PER GPU (weak scaling: the render uses spp x N)")
     ap.add_argument("--scene", default="cbox", choices=["cbox", "cbox_medium", "living_room"])
+    ap.add_argument("--tris", type=int, default=0, help="living_room only: tessellate the spheres finer until the scene has at least this many triangles "
+                    "(SURVEY 8(d): >= 4 M puts nodes + triangles past the 256 MB Infinity Cache)")
     ap.add_argument("--pool", type=int, default=0)
     ap.add_argument("--pipeline", default="auto", choices=["auto", "wavefront", "fused"])
     ap.add_argument("--stream-mode", default="per_sample", choices=["per_sample", "reference"],
@@ -104,7 +106,9 @@ def main():
         sd = scenes.cbox_medium(args.width, args.height, 0.5)
         workload = f"cbox + homogeneous medium sigma_s=0.5 {args.width}x{args.height}x{args.spp}spp (BASELINE configs[4])"
     else:
-        sd = scenes.living_room(args.width, args.height)
+        tess = 32
+        while 256 * 2 * tess * (tess - 1) + 14 < args.tris: tess += 1
+        sd = scenes.living_room(args.width, args.height, tess=tess)
         workload = (f"living-room-class synthetic stand-in ({sd.n_triangles} tris, 6 BSDF types; the real pbrt-v3 living-room is not available) "
                     f"{args.width}x{args.height}x{args.spp}spp (BASELINE configs[2])")
     scene = api.Scene(sd)
@@ -200,7 +204,7 @@ def main():
         traffic, pmc_entry = None, None
         try:
             live = json.load(open(os.path.join(ROOT, "profiles", "pmc_live.json")))
-            key = f"{args.scene}:{args.width}x{args.height}x{args.spp}:{args.stream_mode}:{args.numerics}"
+            key = f"{args.scene}{':tris' + str(args.tris) if args.tris else ''}:{args.width}x{args.height}x{args.spp}:{args.stream_mode}:{args.numerics}"
             e = live.get(key)
             if e and e.get("kernel") == dominant and world == 1:
                 pmc_entry = dict(e, current=(e.get("kernel_src_hash") == src_hash))
@@ -222,7 +226,7 @@ def main():
             from oracle import orc
             orc.use_timing_build()        # -O3 / libm / FMA build of the same restatement; never the checker
             cw, ch, cspp = args.width, args.height, max(1, args.spp // 4)   # bounded sample of the same workload: same scene and resolution, 1/4 of the spp (~10 s of CPU work over three passes)
-            osc = orc.Scene(scenes.cbox(cw, ch) if args.scene == "cbox" else (scenes.cbox_medium(cw, ch, 0.5) if args.scene == "cbox_medium" else scenes.living_room(cw, ch)))
+            osc = orc.Scene(scenes.cbox(cw, ch) if args.scene == "cbox" else (scenes.cbox_medium(cw, ch, 0.5) if args.scene == "cbox_medium" else sd))
             # cores this process may really use: the GPU boxes report 256 hardware threads but run under a cgroup CPU quota
             # (cpu.max = 16 CPUs); more runnable threads than quota only adds throttling
             ncpu = len(os.sched_getaffinity(0))

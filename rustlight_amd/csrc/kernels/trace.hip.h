@@ -293,7 +293,9 @@ RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3
         // 60): which kind of trip runs next is VOTED by the wave — a node trip while the lanes holding inner nodes / stack work are at least 1.5 x
         // the lanes holding leaves, a leaf trip otherwise; the minority waits instead of dragging the wave through a sparsely filled trip
         // (508 k triangles, 32 spp: node : leaf >= 0 (while-while) / 1/4 / 1/2 / 1 / 3/2 / 2 / 4 / 8 / leaf-first = 97.0 / 91.7 / 87.1 / 83.6 / 81.8 /
-        // 82.5 / 84.8 / 89.3 / 98.7 ms, both kinds in every trip: 98.1 ms; on LDS-staged scenes the ballots cost more than they save: 62 vs 50 ms)
+        // 82.5 / 84.8 / 89.3 / 98.7 ms, both kinds in every trip: 98.1 ms; a different ratio for shadow rays — 1/2, 1, 2, 3 with 3/2 for extension rays:
+        // 84.3 / 82.7 / 81.7 / 82.2 vs 81.8 ms.  On LDS-staged scenes the ballots cost more than they save: 62 vs 50 ms; so does the lighter form that
+        // only leaves the nested node loop early, when the lanes still in it are fewer than 1/8 ... 1 x the lanes waiting: 56.1 ... 60.1 vs 49.5 ms)
         for (;;) {
             const bool in_node = cur >= 0 || cur == kPop;
             const bool in_leaf = !in_node && cur != RL_CHILD_NONE;

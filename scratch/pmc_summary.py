@@ -39,7 +39,7 @@ def main():
     cyc_valu = cal.get("cycles_per_wave64_valu_instruction", None)
     n_simd = 256 * 4
     clk_ghz = min(2.4, c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / (ms * 1e-3) / 1e9) if c.get("GRBM_GUI_ACTIVE") and ms else None     # GRBM_GUI_ACTIVE is summed over the 8 XCDs
-    out = {"key": f"{a.scene}:{a.width}x{a.height}x{a.spp}:{a.stream_mode}:{a.numerics}", "kernel": kern, "kernel_ms_under_profiler": ms, "launches_seen": len(dur),
+    out = {"key": f"{a.scene}{':tris' + str(a.tris) if a.tris else ''}:{a.width}x{a.height}x{a.spp}:{a.stream_mode}:{a.numerics}", "kernel": kern, "kernel_ms_under_profiler": ms, "launches_seen": len(dur),
            "kernel_src_hash": provenance.kernel_source_hash(), "commit": os.environ.get("RL_COMMIT"), "bench_args": bargs, "counters": c,
            "effective_clock_GHz": clk_ghz}
     if ms and cyc_valu and "SQ_INSTS_VALU" in c:
