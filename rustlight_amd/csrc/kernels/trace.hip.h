@@ -183,9 +183,13 @@ using TravStack = TravStackT<false>;
 // compare (min is exact and its.t is never a NaN).  NodeFetchLds reads the six near and six far planes through per-ray
 // pre-swizzled LDS addresses (the sign of 1/d picks lo or hi once per ray instead of once per plane per node: 12 selects -> 6
 // address adds, and the paired left/right planes come from one ds_read2_b32); NodeFetchGlobal keeps the four 16-byte loads.
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef const f4v __attribute__((address_space(4))) F4c;      // constant address space: uniform addresses load through the scalar cache
 struct NodePlanes { float lnx, lny, lnz, lfx, lfy, lfz, rnx, rny, rnz, rfx, rfy, rfz; int id1, id2; };
 
 struct NodeFetchLds {
+    static constexpr bool kHasUniform = false;
+    RL_DEV NodePlanes uniform(int) const { return NodePlanes(); }
     const float *nx, *ny, *nz, *fx, *fy, *fz; const int* ids;
     RL_DEV NodeFetchLds(const SceneRecs& recs, V3 inv_d) {
         const float* b = reinterpret_cast<const float*>(recs.nodes);
@@ -219,8 +223,24 @@ struct NodeFetchGlobal {
         p.id1 = __float_as_int(e.x); p.id2 = __float_as_int(e.y);
         return p;
     }
+    // every calling lane wants the SAME node (`cur` is wave-uniform): the record comes through the scalar data cache (one s_load_dwordx16) instead
+    // of four vector loads — it stays off the CU's vector address path, which is what bounds the streaming kernel, and arrives ~3x sooner
+    // (profiles/r02_vmem_calibration.jsonl: 21 vs 68 cycles of the CU per record, 0.2 vs 0.7 us per dependent fetch under load)
+    static constexpr bool kHasUniform = true;
+    RL_DEV NodePlanes uniform(int cur) const {
+        const F4c* q = (const F4c*)(nodes) + 4 * cur;
+        const f4v a = q[0], b = q[1], c = q[2], e = q[3];
+        NodePlanes p;
+        p.lnx = sx ? a.w : a.x; p.lfx = sx ? a.x : a.w; p.lny = sy ? b.x : a.y; p.lfy = sy ? a.y : b.x; p.lnz = sz ? b.y : a.z; p.lfz = sz ? a.z : b.y;
+        p.rnx = sx ? c.y : b.z; p.rfx = sx ? b.z : c.y; p.rny = sy ? c.z : b.w; p.rfy = sy ? b.w : c.z; p.rnz = sz ? c.w : c.x; p.rfz = sz ? c.x : c.w;
+        p.id1 = __float_as_int(e.x); p.id2 = __float_as_int(e.y);
+        return p;
+    }
 };
 
+#ifndef RL_UNIFORM_TRIPS
+#define RL_UNIFORM_TRIPS 1     // streaming scenes: trips on which all lanes hold the same node / leaf fetch it through the scalar cache
+#endif
 #ifndef RL_VOTE_NUM
 #define RL_VOTE_NUM 3      // streaming scenes: a node trip while (lanes with node / stack work) * DEN >= NUM * (lanes holding leaves)
 #define RL_VOTE_DEN 2
@@ -244,7 +264,10 @@ RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3
     auto node_trip = [&]() {
         if (cur >= 0) {
             hit.steps++;
-            const NodePlanes p = fetch(cur);
+            NodePlanes p;
+            const int cur0 = __builtin_amdgcn_readfirstlane(cur);
+            if (Stack::NodeFetch::kHasUniform && RL_UNIFORM_TRIPS && __ballot(cur != cur0) == 0ull) p = fetch.uniform(cur0);
+            else p = fetch(cur);
             const float d1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((p.lnx - o.x) * inv_d.x, (p.lny - o.y) * inv_d.y), (p.lnz - o.z) * inv_d.z), tnear);
             const float f1 = __builtin_fminf(__builtin_fminf(__builtin_fminf((p.lfx - o.x) * inv_d.x, (p.lfy - o.y) * inv_d.y), (p.lfz - o.z) * inv_d.z), hit.t);
             const float d2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((p.rnx - o.x) * inv_d.x, (p.rny - o.y) * inv_d.y), (p.rnz - o.z) * inv_d.z), tnear);
@@ -270,6 +293,27 @@ RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3
     auto leaf_visit = [&]() -> bool {
         const unsigned int code = (unsigned int)(~cur);
         const int first = (int)(code >> 2), count = (int)(code & 3u);
+        if (Stack::NodeFetch::kHasUniform && RL_UNIFORM_TRIPS) {
+            // every calling lane holds the SAME leaf: its triangle records come through the scalar cache as well
+            const int cur0 = __builtin_amdgcn_readfirstlane(cur);
+            if (__ballot(cur != cur0) == 0ull) {
+                const unsigned int code0 = (unsigned int)(~cur0);
+                const int first0 = (int)(code0 >> 2), count0 = (int)(code0 & 3u);
+                const F4c* base = (const F4c*)(recs.tris);
+                for (int k = 0; k < count0; k++) {
+                    hit.tris++;
+                    const F4c* q = base + 4 * (first0 + k);
+                    const f4v a = q[0], b = q[1], c = q[2], e = q[3];
+                    if (tri_test(make_float4(a.x, a.y, a.z, a.w), make_float4(b.x, b.y, b.z, b.w), make_float4(c.x, c.y, c.z, c.w), make_float4(e.x, e.y, e.z, e.w),
+                                 o, d, hit, first0 + k)) {
+                        found = true;
+                        if (ANY_HIT) return true;
+                    }
+                }
+                cur = kPop;
+                return false;
+            }
+        }
         for (int k = 0; k < count; k++) {
             hit.tris++;
             const float4* q = recs.tris + Stack::kTriStride4 * (first + k);

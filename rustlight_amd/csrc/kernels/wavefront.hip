@@ -377,6 +377,7 @@ extern "C" int rl_context_create(const rl_scene* scene, int device, rl_context**
             const size_t worst = ctx->scene_lds_bytes + std::max<size_t>(272 * sizeof(unsigned), kFusedColdBytes) + (size_t)2 * kLdsStackLevels * 256 * sizeof(int);
             if (worst > (size_t)lds_limit) ctx->lds_scene = false;
         }
+        if (getenv("RL_FORCE_STREAMING")) ctx->lds_scene = false;     // dev / test knob: small scenes through the kernels that stream the BVH (tests/parity_fuzz.py)
         if (hipMalloc((void**)&ctx->d_counters, sizeof(Counters)) != hipSuccess) { rl_set_error("hipMalloc counters"); rc = RL_ERR_HIP; break; }
         if (hipHostMalloc((void**)&ctx->h_counters, sizeof(Counters)) != hipSuccess) { rl_set_error("hipHostMalloc counters"); rc = RL_ERR_HIP; break; }
     } while (0);

@@ -69,7 +69,14 @@ def run(budget=20.0, seed=0, verbose=True, fast=False):
             kw = rand_params(sd)
             seed = int(rng.integers(0, 1000))
             pipe = int(rng.choice([0, 1, 2])); split = int(rng.choice([0, 0, 1, 2, 3])); pool = int(rng.choice([0, 0, 512, 4096])) if pipe != 2 else 0
-            ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+            # a third of the cases run the kernels that stream the BVH from L2 / HBM (wave-voted trips, scalar-cache fetches, stack overflow to global
+            # memory) instead of the LDS-staged ones small scenes would get
+            streaming = rng.random() < 0.33
+            if streaming: os.environ["RL_FORCE_STREAMING"] = "1"
+            try:
+                ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+            finally:
+                os.environ.pop("RL_FORCE_STREAMING", None)
             which = rng.random()
             if which < 0.25:          # the `ao` / `direct` integrators (no medium there: src/integrators/{ao,direct}.rs ignore it)
                 seeds = api.IndependentSampler(seed, kw["seed_variant"]).block_seeds(sd.width, sd.height)
@@ -88,7 +95,7 @@ def run(budget=20.0, seed=0, verbose=True, fast=False):
                 n += 1
                 if not (np.array_equal(img, ref) and all(st[k] == ost[k] for k in keys)):
                     bad += 1
-                    print("MISMATCH (ao/direct)", n, dict(size=(sd.width, sd.height), tris=sd.n_triangles, seed=seed, **mk), "max abs diff", float(np.nanmax(np.abs(img - ref))), flush=True)
+                    print("MISMATCH (ao/direct)", n, dict(size=(sd.width, sd.height), tris=sd.n_triangles, streaming=streaming, seed=seed, **mk), "max abs diff", float(np.nanmax(np.abs(img - ref))), flush=True)
                 continue
             img, st = ctx.render(api.IndependentSampler(seed, kw["seed_variant"]).block_seeds(sd.width, sd.height), api.path_params(pipeline=pipe, sample_split=split, pool_slots=pool, **kw))
             ref, ost = osc.render(master_seed=seed, eval_order=1, **kw)
@@ -100,6 +107,8 @@ def run(budget=20.0, seed=0, verbose=True, fast=False):
                 # blackened guarded colour products moved the vertex count by 10 % — so that is held to 1 %; the image mean of these tiny,
                 # often high-variance renders (min_depth, BSDF-only strategy: a single flipped light hit moves it by percents; 16 of 2608 cases
                 # moved it by more than 2 % in a 6-minute run, none by more than 40 %, all with vertex counts within 0.6 %) only to a coarse bound
+                # (a handful of flipped paths can also be hundreds of vertices long — glass, min_depth — and move the census of a tiny render by several percent
+                # while the image stays put: 2 of 4230 cases, per-pixel L2 1e-16; those pass on the image)
                 kf = dict(kw, spp=max(32, 8 * kw["spp"]))
                 seeds = api.IndependentSampler(seed, kw["seed_variant"]).block_seeds(sd.width, sd.height)
                 ex, sx = ctx.render(seeds, api.path_params(pipeline=pipe, sample_split=split, **kf))
@@ -107,14 +116,14 @@ def run(budget=20.0, seed=0, verbose=True, fast=False):
                 n_fast += 1
                 mx, mf = float(np.mean(ex, dtype=np.float64)), float(np.mean(fa, dtype=np.float64))
                 e = np.sum((ex.astype(np.float64) - fa) ** 2, -1)
-                fine = (np.isfinite(fa).all() or not np.isfinite(ex).all()) and (sx["camera_samples"] < 20000 or abs(mf - mx) <= 0.5 * abs(mx) + 1e-3) and abs(sf["vertices"] - sx["vertices"]) <= 0.01 * sx["vertices"] + 48
+                fine = (np.isfinite(fa).all() or not np.isfinite(ex).all()) and (sx["camera_samples"] < 20000 or abs(mf - mx) <= 0.5 * abs(mx) + 1e-3) and (abs(sf["vertices"] - sx["vertices"]) <= 0.01 * sx["vertices"] + 48 or float(e.mean()) <= 1e-9)
                 if not fine:
                     bad += 1
                     print("FAST-MODE DRIFT", n, dict(size=(sd.width, sd.height), meshes=len(sd.meshes), tris=sd.n_triangles, pipe=pipe, split=split, seed=seed, **kf),
                           "means", mx, mf, "vertices", sx["vertices"], sf["vertices"], "L2 mean", float(e.mean()), flush=True)
             if not ok:
                 bad += 1
-                print("MISMATCH", n, dict(size=(sd.width, sd.height), meshes=len(sd.meshes), tris=sd.n_triangles, pipe=pipe, split=split, pool=pool, seed=seed, **kw),
+                print("MISMATCH", n, dict(size=(sd.width, sd.height), meshes=len(sd.meshes), tris=sd.n_triangles, streaming=streaming, pipe=pipe, split=split, pool=pool, seed=seed, **kw),
                       "max abs diff", float(np.nanmax(np.abs(img - ref))), {k: (st[k], ost[k]) for k in ("vertices", "rng_draws", "shadow_rays")}, flush=True)
         except Exception as e:
             bad += 1
