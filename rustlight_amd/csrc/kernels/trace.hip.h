@@ -239,7 +239,14 @@ struct NodeFetchGlobal {
 };
 
 #ifndef RL_UNIFORM_TRIPS
-#define RL_UNIFORM_TRIPS 1     // streaming scenes: trips on which all lanes hold the same node / leaf fetch it through the scalar cache
+// streaming scenes: trips on which all lanes hold the same node / leaf fetch it through the scalar cache.  Exact build only: 81.9 -> 79.6 ms on the 508 k-triangle
+// scene at 32 spp (nodes alone 81.0, leaves alone 79.7); in the tolerance build the same code LOSES (75.1 -> 93.5 ms, all of it from the leaf form, with or without
+// requesting both records of a leaf up front) — not understood, so that build keeps the vector fetches
+#if defined(RL_FAST_MATH)
+#define RL_UNIFORM_TRIPS 0
+#else
+#define RL_UNIFORM_TRIPS 1
+#endif
 #endif
 #ifndef RL_VOTE_NUM
 #define RL_VOTE_NUM 3      // streaming scenes: a node trip while (lanes with node / stack work) * DEN >= NUM * (lanes holding leaves)
