@@ -1,0 +1,55 @@
+"""Host-side logic of bench.py that can be checked without a GPU: the CLI contract (defaults, knobs), the self-launch under
+torch.distributed.run, and the provenance gate on stored counter summaries."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_defaults_are_the_baseline_workload_on_one_gpu():
+    a = bench.parse_args([])
+    assert (a.gpus, a.scene, a.width, a.height, a.spp) == (1, "cbox", 1920, 1080, 128)
+    assert a.steps >= 1 and a.warmup >= 1 and a.steps * 0.06 < 60          # a default run is seconds, not minutes
+    assert a.stream_mode == "per_sample" and a.numerics == "exact" and a.pipeline == "auto" and a.tris == 0
+
+
+def test_knobs_parse():
+    a = bench.parse_args(["--gpus", "8", "--steps", "5", "--warmup", "2", "--scene", "living_room", "--tris", "4000000", "--stream-mode", "reference", "--numerics", "fast"])
+    assert (a.gpus, a.steps, a.warmup, a.scene, a.tris, a.stream_mode, a.numerics) == (8, 5, 2, "living_room", 4000000, "reference", "fast")
+    with pytest.raises(SystemExit):
+        bench.parse_args(["--scene", "nope"])
+
+
+def test_self_launch_uses_the_local_rendezvous(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-executes itself as N ranks on 127.0.0.1 with the same arguments."""
+    seen = {}
+    monkeypatch.setattr(os, "execvp", lambda prog, argv: seen.update(prog=prog, argv=list(argv)))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    bench._respawn_under_launcher(bench.parse_args(["--gpus", "4", "--steps", "2"]))
+    argv = seen["argv"]
+    assert argv[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in argv and "--nproc-per-node=4" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(argv[argv.index("--master-port") + 1]) < 65536
+    k = argv.index(os.path.join(ROOT, "bench.py"))
+    assert argv[k + 1:] == ["--gpus", "4", "--steps", "2"]
+    assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"            # dmabuf IPC: RCCL across processes needs it on this pool
+
+
+def test_stored_counter_keys_follow_the_workload():
+    """profiles/pmc_live.json is keyed the way bench.py looks entries up (scene[:trisN]:WxHxSPP:stream:numerics)."""
+    live = json.load(open(os.path.join(ROOT, "profiles", "pmc_live.json")))
+    for key, e in live.items():
+        scene, *rest = key.split(":")
+        assert scene in ("cbox", "cbox_medium", "living_room")
+        if rest[0].startswith("tris"): rest = rest[1:]
+        dims, stream, numerics = rest
+        w, h, spp = (int(x) for x in dims.split("x"))
+        assert (w, h, spp) == (1920, 1080, 128) and stream in ("per_sample", "reference") and numerics in ("exact", "fast")
+        assert e["key"] == key and len(e["kernel_src_hash"]) == 16 and e["commit"]
