@@ -239,14 +239,9 @@ struct NodeFetchGlobal {
 };
 
 #ifndef RL_UNIFORM_TRIPS
-// streaming scenes: trips on which all lanes hold the same node / leaf fetch it through the scalar cache.  Exact build only: 81.9 -> 79.6 ms on the 508 k-triangle
-// scene at 32 spp (nodes alone 81.0, leaves alone 79.7); in the tolerance build the same code LOSES (75.1 -> 93.5 ms, all of it from the leaf form, with or without
-// requesting both records of a leaf up front) — not understood, so that build keeps the vector fetches
-#if defined(RL_FAST_MATH)
-#define RL_UNIFORM_TRIPS 0
-#else
+// streaming scenes: trips on which all lanes hold the same node / leaf fetch it through the scalar cache: 81.2 -> 78.7 ms on the 508 k-triangle scene at 32 spp,
+// 75.5 -> 74.4 ms in the tolerance build
 #define RL_UNIFORM_TRIPS 1
-#endif
 #endif
 #ifndef RL_VOTE_NUM
 #define RL_VOTE_NUM 3      // streaming scenes: a node trip while (lanes with node / stack work) * DEN >= NUM * (lanes holding leaves)
@@ -300,31 +295,22 @@ RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3
     auto leaf_visit = [&]() -> bool {
         const unsigned int code = (unsigned int)(~cur);
         const int first = (int)(code >> 2), count = (int)(code & 3u);
-        if (Stack::NodeFetch::kHasUniform && RL_UNIFORM_TRIPS) {
-            // every calling lane holds the SAME leaf: its triangle records come through the scalar cache as well
-            const int cur0 = __builtin_amdgcn_readfirstlane(cur);
-            if (__ballot(cur != cur0) == 0ull) {
-                const unsigned int code0 = (unsigned int)(~cur0);
-                const int first0 = (int)(code0 >> 2), count0 = (int)(code0 & 3u);
-                const F4c* base = (const F4c*)(recs.tris);
-                for (int k = 0; k < count0; k++) {
-                    hit.tris++;
-                    const F4c* q = base + 4 * (first0 + k);
-                    const f4v a = q[0], b = q[1], c = q[2], e = q[3];
-                    if (tri_test(make_float4(a.x, a.y, a.z, a.w), make_float4(b.x, b.y, b.z, b.w), make_float4(c.x, c.y, c.z, c.w), make_float4(e.x, e.y, e.z, e.w),
-                                 o, d, hit, first0 + k)) {
-                        found = true;
-                        if (ANY_HIT) return true;
-                    }
-                }
-                cur = kPop;
-                return false;
-            }
-        }
+        // every calling lane holds the SAME leaf (wave-uniform code): its triangle records come through the scalar cache as well; one test site
+        // for both forms (a second inlined copy of tri_test upset the register allocation of the whole loop: 75 -> 93 ms in the tolerance build)
+        bool uni = false;
+        if (Stack::NodeFetch::kHasUniform && RL_UNIFORM_TRIPS) uni = __ballot(cur != __builtin_amdgcn_readfirstlane(cur)) == 0ull;
         for (int k = 0; k < count; k++) {
             hit.tris++;
-            const float4* q = recs.tris + Stack::kTriStride4 * (first + k);
-            if (tri_test(q[0], q[1], q[2], q[3], o, d, hit, first + k)) {
+            float4 q0, q1, q2, q3;
+            if (uni) {
+                const F4c* q = (const F4c*)(recs.tris) + 4 * (__builtin_amdgcn_readfirstlane(first) + k);
+                const f4v a = q[0], b = q[1], c = q[2], e = q[3];
+                q0 = make_float4(a.x, a.y, a.z, a.w); q1 = make_float4(b.x, b.y, b.z, b.w); q2 = make_float4(c.x, c.y, c.z, c.w); q3 = make_float4(e.x, e.y, e.z, e.w);
+            } else {
+                const float4* q = recs.tris + Stack::kTriStride4 * (first + k);
+                q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+            }
+            if (tri_test(q0, q1, q2, q3, o, d, hit, first + k)) {
                 found = true;
                 if (ANY_HIT) return true;
             }
