@@ -354,11 +354,12 @@ RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3
 //
 // EXPERIMENT, OFF BY DEFAULT (RL_COOP_FETCH = 0; bit-identical images, but 144 ms (LDS staging) / 145 ms (registers + ds_bpermute) vs 97-110 ms at
 // 1080p x 32 spp: DESIGN.md §4).
-// The counters suggested that the per-lane form is bound by the CU's vector-memory address path: TA busy 81-91 % of the kernel, TD 95 %,
-// at 12 % lane utilisation (profiles/r02_ta_living_room.json) — a wave64 `global_load_dwordx4` occupies the texture-address unit whether
-// 64 lanes or 6 are live, and a node costs four of them.  It is not: TA "busy" includes waiting for data, the kernel is bound by the
-// LATENCY of each trip's dependent fetch, and the two LDS round trips this form adds in front of and behind the load cost more than the
-// three saved load instructions give back.  Here the live lanes' 64-byte records are fetched by the WHOLE wave: the wanting lanes are ranked (ballot + mbcnt), their record indices travel to the rank slots with one ds_permute,
+// The per-lane form is bound by the instruction throughput of the CU's vector-memory address path (TA busy 81-91 % of the kernel,
+// profiles/r02_ta_living_room.json; calibrated in profiles/r02_vmem_calibration.jsonl: a wave64 `global_load_dwordx4` holds that path for >= 17
+// cycles however few lanes are live, + 0.45 / 2.3 cycles per live lane from L2 / the Infinity Cache), and a node costs four such loads.  This form
+// replaces them by one or two full ones and still loses: finding, ranking and redistributing the records costs two LDS round trips (or 14-17
+// ds_bpermute) per trip and ballot-driven loops every lane stays in, more than the saved load instructions give back.
+// Here the live lanes' 64-byte records are fetched by the WHOLE wave: the wanting lanes are ranked (ballot + mbcnt), their record indices travel to the rank slots with one ds_permute,
 // lane L then loads quarter L % 4 of the record of rank L / 4 — a quad reads 64 contiguous bytes, one request — into a per-wave LDS
 // staging area (32 records = 2 KB), and every wanting lane reads its own record back from LDS, the planes through the same
 // sign-swizzled addresses the LDS-staged scenes use.  One or two coalesced load instructions per trip instead of four scattered

@@ -225,6 +225,28 @@ def test_mixed_materials_parity(built, pipeline):
     _assert_parity(*_render_pair(sd, spp=5, max_depth=6, pipeline=pipeline, sample_split=2))
 
 
+@pytest.mark.parametrize("pipeline", [api.PIPELINE_WAVEFRONT, api.PIPELINE_FUSED])
+def test_small_scenes_through_the_streaming_kernels(built, monkeypatch, pipeline):
+    """The kernels that stream the BVH from L2 / HBM (wave-voted node / leaf trips, uniform trips through the scalar cache, traversal stack
+    overflowing from LDS to global memory) on scenes the oracle finishes in seconds: RL_FORCE_STREAMING keeps small scenes out of LDS."""
+    monkeypatch.setenv("RL_FORCE_STREAMING", "1")
+    for sd, kw in ((scenes.cbox(64, 48), dict(spp=6)),
+                   (scenes.living_room(56, 40, n_spheres=27, tess=12), dict(spp=4, max_depth=8)),        # BVH deeper than the 6 LDS stack levels
+                   (scenes.cbox_medium(40, 32, 0.5), dict(spp=3))):
+        ctx = api.Context(api.Scene(sd), 0)
+        assert not ctx.debug_sizes()["lds_scene"]
+        _assert_parity(*_render_pair(sd, ctx=ctx, pipeline=pipeline, **kw))
+        _assert_parity(*_render_pair(sd, ctx=ctx, pipeline=pipeline, stream_mode=api.STREAM_REFERENCE_ORDER, **kw))
+    sd = scenes.living_room(48, 32, n_spheres=20, tess=8)
+    ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+    seeds = api.IndependentSampler(4).block_seeds(sd.width, sd.height)
+    img, st = ctx.render_direct(seeds, spp=3); ref, ost = osc.render_direct(seeds=seeds, spp=3)
+    np.testing.assert_array_equal(img, ref)
+    assert all(st[k] == ost[k] for k in ("camera_samples", "extension_rays", "shadow_rays", "rng_draws"))
+    img, st = ctx.render_ao(seeds, spp=3, max_distance=1.0); ref, ost = osc.render_ao(seeds=seeds, spp=3, max_distance=1.0)
+    np.testing.assert_array_equal(img, ref)
+
+
 def test_phong_beckmann_textures_parity(built):
     sd = scenes.cbox(48, 48)
     S = scenes

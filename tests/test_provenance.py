@@ -15,6 +15,15 @@ def test_kernel_source_hash_is_stable_and_sensitive(tmp_path):
     assert any(p.endswith("wavefront.hip") for p in provenance.kernel_source_files())
 
 
+def test_hash_ignores_comments_and_layout_but_not_code():
+    code = 'int f(int x) {\n    return x * 2;   // double it\n}\nconst char* s = "// kept";\n'
+    same = '/* header */\nint f(int x) {\n\n  return x * 2; // twice\n}\n\nconst char* s = "// kept";'
+    other = code.replace("x * 2", "x * 3")
+    assert provenance.strip_comments(code) == provenance.strip_comments(same)
+    assert provenance.strip_comments(code) != provenance.strip_comments(other)
+    assert '"// kept"' in provenance.strip_comments(code)
+
+
 def test_stored_pmc_entries_match_the_kernel_sources():
     p = os.path.join(ROOT, "profiles", "pmc_live.json")
     if not os.path.exists(p):
