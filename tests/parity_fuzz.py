@@ -1,6 +1,6 @@
 """Randomized differential test, HIP path vs CPU oracle (bit-exact image + counters), over random scene / light / material /
 integrator-option / pipeline combinations.  `run(seconds, seed)` is used by tests/test_gpu_parity.py (short) and can be run by hand
-for longer: python tests/parity_fuzz.py [seconds] [seed] [fast]   (round 1: ~75 000 cases over eight runs on 1 x MI355X, 0 failures; round 2: 26 k + 17 k + 17 k + 34 k + 69 k cases, the last three with a third of the
+for longer: python tests/parity_fuzz.py [seconds] [seed] [fast]   (round 1: ~75 000 cases over eight runs on 1 x MI355X, 0 failures; round 2: 26 k + 17 k + 17 k + 34 k + 69 k + 87 k cases, the last four with a third of the
 cases forced through the kernels that stream the BVH, 0 mismatches).
 `fast`: eligible cases are also rendered with the opt-in tolerance build (`numerics = fast`) and held to a statistical bar (vertex
 count within 2 % of the exact build at the same seeds — the path census is what a systematic error moves —, image mean within a coarse bound)."""
