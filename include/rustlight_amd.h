@@ -238,7 +238,7 @@ typedef struct rl_render_stats {
     uint64_t kernel_launches;
     double render_ms;             /* wall time of the call (the reference's own timed region, mod.rs:324-334) */
     /* per-kernel accumulated device time from HIP events on the render stream (ms) */
-    double ms_raygen, ms_extend, ms_shade, ms_shadow, ms_compact, ms_other;   /* ms_other = the fused kernel */
+    double ms_raygen, ms_extend, ms_shade, ms_shadow, ms_prepass, ms_other;   /* ms_other = the fused kernel; ms_prepass = k_stream_chain, the draw-count pass of reference-order streams */
     uint64_t n_extend_launches;
     uint64_t reserved[4];
 } rl_render_stats;

@@ -68,7 +68,7 @@ class RenderStats(C.Structure):
                 ("shadow_rays", C.c_uint64), ("rng_draws", C.c_uint64), ("iterations", C.c_uint64),
                 ("kernel_launches", C.c_uint64), ("render_ms", C.c_double), ("ms_raygen", C.c_double),
                 ("ms_extend", C.c_double), ("ms_shade", C.c_double), ("ms_shadow", C.c_double),
-                ("ms_compact", C.c_double), ("ms_other", C.c_double), ("n_extend_launches", C.c_uint64),
+                ("ms_prepass", C.c_double), ("ms_other", C.c_double), ("n_extend_launches", C.c_uint64),
                 ("reserved", C.c_uint64 * 4)]
 
     def as_dict(self):

@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
         const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ka));
         constexpr size_t sc_off = (sizeof(RenderConst) + alignof(DeviceScene) - 1) / alignof(DeviceScene) * alignof(DeviceScene);
+        static_assert(sc_off == offsetof(PathKernargs, sc) && offsetof(PathKernargs, rc) == 0, "kernarg layout of k_path_fused(RenderConst, DeviceScene, StackConf)");
         const DeviceScene& sc = *(const DeviceScene*)(ka + sc_off);
         const RenderConst& rc = (MEDIUM || RL_RELOAD_SCENE > 1) ? *(const RenderConst*)ka : rc_arg;
 #endif

@@ -95,7 +95,21 @@ struct RenderConst {
     float* out;                         // W*H*3 framebuffer
     Counters* counters;
     unsigned long long* partials;       // [max grid blocks][STAT_COUNT] statistics rows
+    // reference-order streams in two passes (chain.hip.h): the block sampler's state at the start of every camera sample,
+    // [sample][chunk pixel][4] u64 — written by k_stream_chain, read by the per-sample kernel (stream_mode = kStreamGivenStates)
+    unsigned long long* sample_states;
+    unsigned n_state_pixels;            // pixels of this chunk (second index of sample_states)
+    unsigned cursor_begin, cursor_end;  // k_stream_chain: the block cursors [begin, end) this chunk covers
+    unsigned long long* chain_states;   // [owned block][4]: where a block's stream stands between two chunks
 };
+// internal third value of RenderConst::stream_mode (never accepted from a caller): per-pixel work items as in RL_STREAM_PER_SAMPLE, but every
+// camera sample starts from the sampler state k_stream_chain recorded for it — the image and the counters of RL_STREAM_REFERENCE_ORDER
+enum : int { kStreamGivenStates = 2 };
+
+// k_path_fused / k_stream_chain take (RenderConst, DeviceScene, StackConf) by value and re-read the first two from the kernarg segment inside
+// their loops: the segment lays the arguments out like this struct (each at its natural alignment, in order); the kernels static_assert their
+// hand-computed offset against it, so a reordered or added argument fails to compile instead of reading garbage.
+struct PathKernargs { RenderConst rc; DeviceScene sc; StackConf stc; };
 
 // Path-state accessors.  The stage functions below are written once against `ps.f/u/q(field)`:
 //  * PoolState: the wavefront kernels — state lives in the HBM pool, one coalesced word per lane;

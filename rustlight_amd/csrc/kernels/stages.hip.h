@@ -24,6 +24,63 @@ RL_DEV V3 camera_direction(const DeviceScene& sc, float u, float v) {
                ((tw[2] * dl.x + tw[6] * dl.y) + tw[10] * dl.z) + tw[14] * 0.0f);
 }
 
+// Reference-order streams in two passes: sampler state at the start of camera sample `s` of chunk pixel `p` ([sample][pixel][4] u64)
+RL_DEV Rng load_sample_state(const RenderConst& rc, unsigned s, unsigned p) {
+    const ulonglong2* q = reinterpret_cast<const ulonglong2*>(rc.sample_states + 4 * ((size_t)s * rc.n_state_pixels + p));
+    const ulonglong2 a = q[0], b = q[1];
+    Rng r; r.s0 = a.x; r.s1 = a.y; r.s2 = b.x; r.s3 = b.y;
+    return r;
+}
+RL_DEV void store_sample_state(const RenderConst& rc, unsigned s, unsigned p, const Rng& r) {
+    ulonglong2* q = reinterpret_cast<ulonglong2*>(rc.sample_states + 4 * ((size_t)s * rc.n_state_pixels + p));
+    q[0] = make_ulonglong2(r.s0, r.s1); q[1] = make_ulonglong2(r.s2, r.s3);
+}
+
+// raygen_chain_slot — first pass of reference-order streams (k_stream_chain): the slot owns one 16x16 block and walks (iy, ix, sample) in
+// compute_mc's order (integrators/mod.rs:420-435) on the block's own sampler, like raygen_slot does in RL_STREAM_REFERENCE_ORDER — but all it
+// keeps of a camera sample is where in the stream it STARTS (sample_states); no radiance, no fold.  How many draws a sample takes is decided by
+// shade_slot<.., DRAWS_ONLY = true> from the same geometry, BSDF samples and Russian-roulette tests as the full evaluation.
+template <class PS>
+RL_DEV void raygen_chain_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps) {
+    const unsigned flags = PU(U_FLAGS);
+    const unsigned item = PU(U_ITEM);
+    unsigned s = PU(U_SAMPLE), cursor = PU(U_CURSOR);
+    unsigned bx, by, bw, bh;
+    const unsigned b = rc.owned_blocks[item];
+    block_geometry(rc, b, &bx, &by, &bw, &bh);
+    const unsigned c_end = min(rc.cursor_end, bw * bh);
+    Rng rng;
+    if (flags & ST_FRESH) {
+        cursor = rc.cursor_begin; s = 0;
+        if (cursor >= c_end) { PU(U_FLAGS) = ST_FINISHED; return; }
+        if (rc.cursor_begin == 0u) rng = rng_seed(rc.block_seeds[b], rc.seed_variant);      // the block's own sampler (mod.rs:371)
+        else { const unsigned long long* q = rc.chain_states + 4 * (size_t)item; rng.s0 = q[0]; rng.s1 = q[1]; rng.s2 = q[2]; rng.s3 = q[3]; }
+    } else {
+        rng = load_rng(ps, Q_R0);
+        s++;
+        if (s == rc.spp) { s = 0; cursor++; }
+        if (cursor == c_end) {
+            unsigned long long* q = rc.chain_states + 4 * (size_t)item;                     // the next chunk resumes here
+            q[0] = rng.s0; q[1] = rng.s1; q[2] = rng.s2; q[3] = rng.s3;
+            PU(U_FLAGS) = ST_FINISHED;
+            return;
+        }
+    }
+    store_sample_state(rc, s, rc.block_item_base[item] + (cursor - rc.cursor_begin), rng);
+    const unsigned px = bx + cursor % bw, py = by + cursor / bw;
+    const float u = (float)px + rng_next_f32(rng);          // Path::from_sensor: uv = (ix + next(), iy + next())
+    const float v = (float)py + rng_next_f32(rng);
+    PU(U_SAMPLE) = s;
+    PU(U_CURSOR) = cursor;
+    const bool expand = (!rc.has_max || 1u < rc.max_depth);
+    if (!expand) { store_rng(ps, Q_R0, rng); PU(U_FLAGS) = ST_REGEN; return; }
+    store3(ps, F_DX, camera_direction(sc, u, v));
+    if (sc.medium.enabled) PF(F_XI) = rng_next_f32(rng);
+    store_rng(ps, Q_R0, rng);
+    PU(U_DEPTH) = 1u;
+    PU(U_FLAGS) = ST_RAY | (PREV_SENSOR << ST_PREV_SHIFT) | ST_PDF_SA;
+}
+
 // raygen_slot — sample completion, work-item hand-out, sampler forking, Path::from_sensor (2 draws) and
 // Camera::generate for one slot that asked for regeneration.  DYNAMIC: work items come from the global
 // dispenser (wavefront pool); otherwise the slot owns exactly one item (persistent fused kernel).
@@ -37,7 +94,9 @@ RL_DEV void raygen_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, un
     bool need_item = fresh;
     unsigned bx = 0, by = 0, bw = 1, bh = 1;
     if (rc.stream_mode == RL_STREAM_REFERENCE_ORDER && item < rc.n_items) block_geometry(rc, rc.owned_blocks[item], &bx, &by, &bw, &bh);
-    const unsigned split = rc.stream_mode == RL_STREAM_PER_SAMPLE ? rc.split : 1u;
+    const bool per_pixel = rc.stream_mode != RL_STREAM_REFERENCE_ORDER;    // per-pixel work items: RL_STREAM_PER_SAMPLE, or the second pass of reference-order streams
+    const bool given = rc.stream_mode == kStreamGivenStates;
+    const unsigned split = per_pixel ? rc.split : 1u;
     const unsigned pitem = split > 1u ? item / split : item;         // pixel item of this lane
     if (!fresh && split > 1u) {
         // sample-parallel pixels: this lane owns samples s, s + split, ...; each sample's radiance is parked in
@@ -52,12 +111,12 @@ RL_DEV void raygen_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, un
         acc = acc + loadc(ps, F_LR);
         s++;
         if (s == rc.spp) {
-            unsigned pix = rc.stream_mode == RL_STREAM_PER_SAMPLE ? rc.item_pixel[item] : (by + cursor / bw) * rc.W + (bx + cursor % bw);
+            unsigned pix = per_pixel ? rc.item_pixel[item] : (by + cursor / bw) * rc.W + (bx + cursor % bw);
             Col px = scale_unguarded(acc, rc.inv_spp);            // im_block.scale(1 / spp) (mod.rs:436)
             rc.out[3 * (size_t)pix] = px.r; rc.out[3 * (size_t)pix + 1] = px.g; rc.out[3 * (size_t)pix + 2] = px.b;
             acc = czero();
             s = 0;
-            if (rc.stream_mode == RL_STREAM_PER_SAMPLE) need_item = true;
+            if (per_pixel) need_item = true;
             else { cursor++; if (cursor == bw * bh) need_item = true; }
         }
     }
@@ -70,7 +129,11 @@ RL_DEV void raygen_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, un
             return;
         }
         cursor = 0;
-        if (rc.stream_mode == RL_STREAM_PER_SAMPLE) {
+        if (given) {
+            const unsigned pi = split > 1u ? item / split : item;
+            if (split > 1u) s = item % split;
+            rng = load_sample_state(rc, s, pi);                             // the block sampler as compute_mc would hold it here (k_stream_chain)
+        } else if (per_pixel) {
             const unsigned pi = split > 1u ? item / split : item;
             Rng item_rng = rng_seed(rc.item_seed[pi], rc.seed_variant);     // pixel sampler = block_sampler.clone_box()
             if (split > 1u) { s = item % split; for (unsigned k = 0; k < s; k++) rng_next_u64(item_rng); }   // forks of the samples before ours
@@ -82,7 +145,9 @@ RL_DEV void raygen_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, un
             rng = rng_seed(rc.block_seeds[b], rc.seed_variant);            // the block's own sampler (mod.rs:371)
         }
         PU(U_ITEM) = item;
-    } else if (rc.stream_mode == RL_STREAM_PER_SAMPLE) {
+    } else if (given) {
+        rng = load_sample_state(rc, s, pitem);
+    } else if (per_pixel) {
         Rng item_rng = load_rng(ps, Q_I0);
         for (unsigned k = 1; k < split; k++) rng_next_u64(item_rng);        // the forks taken by the other lanes of this pixel
         rng = rng_seed(rng_next_u64(item_rng), rc.seed_variant);
@@ -91,7 +156,7 @@ RL_DEV void raygen_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, un
         rng = load_rng(ps, Q_R0);
     }
     unsigned px, py;
-    if (rc.stream_mode == RL_STREAM_PER_SAMPLE) { unsigned pix = rc.item_pixel[split > 1u ? item / split : item]; px = pix % rc.W; py = pix / rc.W; }
+    if (per_pixel) { unsigned pix = rc.item_pixel[split > 1u ? item / split : item]; px = pix % rc.W; py = pix / rc.W; }
     else { px = bx + cursor % bw; py = by + cursor / bw; }
     // Path::from_sensor: uv = (ix + next(), iy + next())
     float u = (float)px + rng_next_f32(rng);
@@ -188,7 +253,10 @@ RL_DEV void shadow_slot_coop(const DeviceScene& sc, const SceneRecs& recs, const
 
 // shade_slot<MAT, MEDIUM> — one path vertex of one slot.  MAT >= 0: the hit material is known to have that
 // BSDF type (per-BSDF code path, uniform over the calling lanes); MAT = -1: generic (run-time switch).
-template <int MAT, bool MEDIUM, int LIGHTS = LIGHTS_ANY, class PS>
+// DRAWS_ONLY (k_stream_chain, the first pass of reference-order streams): only what decides how the path goes on and how many
+// random numbers it takes — medium distance, surface point, BSDF / phase sample, Russian roulette — is evaluated, through the very
+// same statements as the full form; emission, MIS, light sampling (its four draws are skipped over) and the radiance fields are left out.
+template <int MAT, bool MEDIUM, int LIGHTS = LIGHTS_ANY, bool DRAWS_ONLY = false, class PS>
 RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, unsigned flags,
                        unsigned& n_vertices, unsigned& n_draws, unsigned& n_shadow, unsigned& n_ext) {
     n_ext += 1;      // every shaded slot carried exactly one extension ray through k_extend
@@ -199,11 +267,11 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
     const V3 ro = primary ? mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]) : load3(ps, F_OX);
     const V3 rd = load3(ps, F_DX);
     const float t_hit = PF(F_T);
-    Col w_edge = primary ? cone() : loadc(ps, F_WR);
-    const float rr = primary ? 1.0f : PF(F_RR);
-    const float pdf_edge = primary ? 1.0f : PF(F_PDF);
-    Col beta = primary ? cone() : loadc(ps, F_BR);
-    Col L = primary ? czero() : loadc(ps, F_LR);
+    Col w_edge = (primary || DRAWS_ONLY) ? cone() : loadc(ps, F_WR);
+    const float rr = (primary || DRAWS_ONLY) ? 1.0f : PF(F_RR);
+    const float pdf_edge = (primary || DRAWS_ONLY) ? 1.0f : PF(F_PDF);
+    Col beta = (primary || DRAWS_ONLY) ? cone() : loadc(ps, F_BR);
+    Col L = (primary || DRAWS_ONLY) ? czero() : loadc(ps, F_LR);
     bool zeroed = (flags & ST_ZEROED) != 0u;
     const bool hit = prim >= 0;
     bool is_volume = false;
@@ -220,6 +288,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
     if (!MEDIUM && !hit) {
         // edge without a next vertex: Edge::contribution = weight * rr * scene.enviroment_luminance(d) (edge.rs:201-210)
         ended = true;
+        if constexpr (!DRAWS_ONLY) {
         // A zero term is still added as beta * 0: with a NaN / infinite throughput (hostile textures) the reference's recursion turns the
         // whole sample into NaN through `weight * evaluate(next)`, and the forward form keeps that by not skipping the product.
         Col contrib = (w_edge * rr) * (LIGHTS != LIGHTS_AREA_ONLY && sc.env_emitter >= 0 ? env_eval(sc, rd) : czero());      // enviroment_luminance is black without an environment
@@ -242,6 +311,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
             L = L + beta * term;
         }
         storec(ps, F_LR, L);
+        }
     }
     if (!ended) {
         const Col W = w_edge * rr;                // edge.weight * edge.rr_weight (Color * f32, guarded)
@@ -254,6 +324,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
             mat = &sc.materials[mr.material];
         }
         // ---- contribution carried by the arriving edge (Edge::contribution -> Vertex::contribution)
+        if constexpr (!DRAWS_ONLY) {
         Col emit = czero();
         if (!is_volume && (mr.flags & MESH_IS_LIGHT) && dot(sp.n_s, -rd) >= 0.0f) emit = mkc(mr.emission[0], mr.emission[1], mr.emission[2]);
         Col contrib = W * emit;
@@ -280,6 +351,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
         }
         beta = beta * W;
         if (rc.single_scattering && !is_volume) zeroed = true;                  // evaluate(): surface vertex => subtree is 0
+        }
 
         // ---- expand the new vertex (generate(), strategies/mod.rs:35-80)
         const unsigned gen = depth + 1u;
@@ -330,6 +402,9 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
             const bool use_light = rc.strategy != RL_STRATEGY_BSDF;
             const bool smooth = !is_volume && mat->smooth;
             bool shadow = false;
+            if (DRAWS_ONLY) {
+                if (use_light && !smooth) { rng_next_u64(rng); rng_next_u64(rng); rng_next_u64(rng); rng_next_u64(rng); }   // the light sample's four draws
+            } else
             if (use_light && !smooth) {
                 float a = rng_next_f32(rng);
                 float b = rng_next_f32(rng);
@@ -383,16 +458,20 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
             if (has_edge) {
                 store3(ps, F_DX, sd_world);
                 storec(ps, F_TR, thr);
-                storec(ps, F_WR, sw);
-                PF(F_RR) = rr_new;
-                PF(F_PDF) = spdf;
+                if constexpr (!DRAWS_ONLY) {
+                    storec(ps, F_WR, sw);
+                    PF(F_RR) = rr_new;
+                    PF(F_PDF) = spdf;
+                }
                 PU(U_DEPTH) = gen;
                 const unsigned kind = is_volume ? PREV_VOLUME : (smooth ? PREV_SURFACE_SMOOTH : PREV_SURFACE);
                 new_flags |= ST_RAY | (kind << ST_PREV_SHIFT) | (spdf_kind == PDF_SOLID_ANGLE ? ST_PDF_SA : 0u) | (zeroed ? ST_ZEROED : 0u);
             } else new_flags |= ST_REGEN;
         }
-        storec(ps, F_BR, beta);
-        storec(ps, F_LR, L);
+        if constexpr (!DRAWS_ONLY) {
+            storec(ps, F_BR, beta);
+            storec(ps, F_LR, L);
+        }
     }
     PU(U_FLAGS) = new_flags;
 }

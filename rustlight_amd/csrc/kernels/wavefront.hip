@@ -61,6 +61,16 @@ __global__ void k_seed_pixels(RenderConst rc) {
         }
 }
 
+// reference-order streams in two passes: pixel of every work item of the chunk (block cursors [cursor_begin, cursor_end) of each owned block)
+__global__ void k_chunk_pixels(RenderConst rc) {
+    unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= rc.n_owned) return;
+    unsigned bx, by, bw, bh;
+    block_geometry(rc, rc.owned_blocks[j], &bx, &by, &bw, &bh);
+    const unsigned c_end = min(rc.cursor_end, bw * bh), base = rc.block_item_base[j];
+    for (unsigned c = rc.cursor_begin; c < c_end; c++) rc.item_pixel[base + (c - rc.cursor_begin)] = (by + c / bw) * rc.W + (bx + c % bw);
+}
+
 __global__ void k_init(RenderConst rc, Pool pool) {
     unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= pool.P) return;
@@ -258,6 +268,8 @@ struct rl_context {
     unsigned long long* d_partials = nullptr; size_t partials_capacity = 0;
     int* d_overflow = nullptr; size_t overflow_capacity = 0;
     float* d_sample_buf = nullptr; size_t sample_buf_capacity = 0;   // sample-parallel pixels: [spp][pixel item][3]
+    unsigned long long* d_sample_states = nullptr; size_t sample_states_capacity = 0;   // reference-order streams, two passes: [spp][chunk pixel][4]
+    unsigned long long* d_chain_states = nullptr; size_t chain_states_capacity = 0;     // [owned block][4]
     std::vector<hipEvent_t> events;
     BvhBuild bvh_dump;                // kept for rl_debug_bvh
 };
@@ -391,7 +403,8 @@ extern "C" void rl_context_destroy(rl_context* ctx) {
     hipSetDevice(ctx->device);
     for (void* p : ctx->allocs) hipFree(p);
     void* scratch[] = {ctx->pool.f, ctx->pool.u, ctx->pool.q, ctx->d_owned, ctx->d_item_base, ctx->d_block_seeds, ctx->d_item_seed,
-                       ctx->d_item_pixel, ctx->d_queues, ctx->d_qcounts, ctx->d_out, ctx->d_counters, ctx->d_partials, ctx->d_overflow, ctx->d_sample_buf};
+                       ctx->d_item_pixel, ctx->d_queues, ctx->d_qcounts, ctx->d_out, ctx->d_counters, ctx->d_partials, ctx->d_overflow, ctx->d_sample_buf,
+                       ctx->d_sample_states, ctx->d_chain_states};
     for (void* p : scratch) if (p) hipFree(p);
     if (ctx->h_counters) hipHostFree(ctx->h_counters);
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
@@ -470,64 +483,106 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     }
     const bool per_sample = params->stream_mode == RL_STREAM_PER_SAMPLE;
     // pipeline: 1 = wavefront stage kernels, 2 = persistent fused kernel, 0 = auto = fused unless a pool size is forced (reference-order
-    // streams at 1080p x 128 spp: wavefront 8.7 s, fused 2.9 s, fused with the items spread over the waves: see DESIGN.md; per-sample at
-    // 1080p x 32 spp, fused vs wavefront: 508 k-triangle / 6-BSDF scene 127 vs 202 ms, 4.9 k triangles 61 vs 153 ms, Cornell box
-    // with mixed BSDFs 23 vs 70 ms, diffuse Cornell box 15 vs 35 ms)
+    // streams at 1080p x 128 spp: wavefront 8.7 s, fused 2.9 s, fused with the items spread over the waves 1.7 s, fused in two passes: see
+    // DESIGN.md; per-sample at 1080p x 32 spp, fused vs wavefront: 508 k-triangle / 6-BSDF scene 127 vs 202 ms, 4.9 k triangles 61 vs 153 ms,
+    // Cornell box with mixed BSDFs 23 vs 70 ms, diffuse Cornell box 15 vs 35 ms)
     if (params->pipeline > 2) { rl_set_error("pipeline must be 0 (auto), 1 (wavefront) or 2 (fused)"); return RL_ERR_INVALID_ARGUMENT; }
     const bool fused = params->pipeline == 2 || (params->pipeline == 0 && params->pool_slots == 0);
     const bool fast_math = params->numerics == RL_NUMERICS_FAST;
     if (fast_math && !fused) { rl_set_error("numerics = fast exists for the persistent kernel only (pipeline 0 or 2, pool_slots 0)"); return RL_ERR_UNSUPPORTED; }
-    // sample-parallel pixels: `split` lanes per pixel, per-sample radiances parked in HBM ([spp][pixel][3] floats) and folded
-    // in order.  Auto: scenes that traverse out of L2 / HBM want ~8 M paths in flight per wavefront launch (measured on the
-    // 508 k-triangle living-room scene at 1080p: 1 lane/pixel 935 ms, 4 lanes 787 ms, 8 lanes 836 ms); LDS-staged scenes in the
-    // wavefront pipeline are VALU-bound and only pay for the extra state, so they stay at one lane per pixel.
-    // The parking buffer is capped (kSampleBufBudget), beyond it one lane per pixel.
-    unsigned split = 1;
-    if (per_sample && n_pixels > 0) {
-        // The persistent kernel keeps 4 x 256-lane workgroups per CU resident; a shard with few pixel tiles but many samples
-        // per pixel (rank r of N at spp = 128 N: 1020 tiles at N = 8) leaves most of those slots empty once the tiles that
-        // look past the scene have drained, so it is cut into >= ~16 k workgroups (measured, rank 0 of 8 at 1024 spp:
-        // 1 lane / pixel 122 ms, 8 lanes 69 ms, 16 lanes 69 ms; a full 8160-tile frame is best left at 1 lane: 64 vs 67 ms).
-        // Scenes that stream their BVH: all 64 lanes of a wave work on samples of ONE pixel (split = 64), so the camera rays of a wave are
-        // nearly identical and fetch the same nodes (508 k triangles, 32 spp: 1 / 4 / 16 / 32 lanes per pixel = 108.9 / 104.0 / 100.8 / 97.4 ms).
-        const unsigned fused_groups = (n_pixels + 255u) / 256u;
-        const unsigned fused_auto = fused_groups >= 6000u ? 1u : std::max(1u, 16384u / std::max(1u, fused_groups));
-        const unsigned want = params->sample_split ? params->sample_split
-                            : (fused ? (ctx->lds_scene ? fused_auto : std::max(fused_auto, 64u))
-                                     : (ctx->lds_scene ? 1u : std::max(1u, (8u << 20) / std::max(1u, n_pixels))));
-        split = std::max(1u, std::min(want, params->spp));
-        if ((size_t)n_pixels * params->spp * 3 * sizeof(float) > kSampleBufBudget) split = 1;
-        while (split > 1 && (size_t)n_pixels * split > (size_t)0x7fffff00u) split--;
+    // Reference-order streams through the persistent kernel run in TWO passes (chain.hip.h): k_stream_chain walks every block's stream with the
+    // radiance half of the integrator left out and records the sampler state at the start of each camera sample, then the per-sample form of
+    // k_path_fused evaluates all samples from those states with every lane busy.  Same image, same counters as the single-pass walk
+    // (RL_REF_SINGLE_PASS=1 keeps that form: a test / measurement knob).
+    const bool two_pass = !per_sample && fused && !owned.empty() && !getenv("RL_REF_SINGLE_PASS");
+    int cus = 256;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    // ---- how a set of work items is laid over the lanes.  per_pixel: pixel items (RL_STREAM_PER_SAMPLE, or the second pass of reference-order
+    // streams), else one item per owned block.
+    struct Plan { unsigned split, n_items, P, item_shift; };
+    auto plan_items = [&](bool per_pixel, unsigned n_pix, unsigned n_chains) -> Plan {
+        // sample-parallel pixels: `split` lanes per pixel, per-sample radiances parked in HBM ([spp][pixel][3] floats) and folded
+        // in order.  Auto: scenes that traverse out of L2 / HBM want ~8 M paths in flight per wavefront launch (measured on the
+        // 508 k-triangle living-room scene at 1080p: 1 lane/pixel 935 ms, 4 lanes 787 ms, 8 lanes 836 ms); LDS-staged scenes in the
+        // wavefront pipeline are VALU-bound and only pay for the extra state, so they stay at one lane per pixel.
+        // The parking buffer is capped (kSampleBufBudget), beyond it one lane per pixel.
+        Plan pl{1u, 0u, 0u, 0u};
+        if (per_pixel && n_pix > 0) {
+            // The persistent kernel keeps 4 x 256-lane workgroups per CU resident; a shard with few pixel tiles but many samples
+            // per pixel (rank r of N at spp = 128 N: 1020 tiles at N = 8) leaves most of those slots empty once the tiles that
+            // look past the scene have drained, so it is cut into >= ~16 k workgroups (measured, rank 0 of 8 at 1024 spp:
+            // 1 lane / pixel 122 ms, 8 lanes 69 ms, 16 lanes 69 ms; a full 8160-tile frame is best left at 1 lane: 64 vs 67 ms).
+            // Scenes that stream their BVH: all 64 lanes of a wave work on samples of ONE pixel (split = 64), so the camera rays of a wave are
+            // nearly identical and fetch the same nodes (508 k triangles, 32 spp: 1 / 4 / 16 / 32 lanes per pixel = 108.9 / 104.0 / 100.8 / 97.4 ms).
+            const unsigned fused_groups = (n_pix + 255u) / 256u;
+            const unsigned fused_auto = fused_groups >= 6000u ? 1u : std::max(1u, 16384u / std::max(1u, fused_groups));
+            const unsigned want = params->sample_split ? params->sample_split
+                                : (fused ? (ctx->lds_scene ? fused_auto : std::max(fused_auto, 64u))
+                                         : (ctx->lds_scene ? 1u : std::max(1u, (8u << 20) / std::max(1u, n_pix))));
+            pl.split = std::max(1u, std::min(want, params->spp));
+            if ((size_t)n_pix * params->spp * 3 * sizeof(float) > kSampleBufBudget) pl.split = 1;
+            while (pl.split > 1 && (size_t)n_pix * pl.split > (size_t)0x7fffff00u) pl.split--;
+        }
+        pl.n_items = per_pixel ? n_pix * pl.split : n_chains;
+        // a pool never needs more slots than there are work items (and `pool_slots` is caller input: keep the rounding below from wrapping)
+        unsigned P = params->pool_slots ? std::min(params->pool_slots, std::max(pl.n_items, 1u)) : std::min<unsigned>(pl.n_items, 16u << 20);
+        P = std::max(256u, (unsigned)(((unsigned long long)P + 255ull) / 256ull * 256ull));
+        if (fused) {
+            // One lane per work item by default.  With a participating medium path lengths vary by orders of magnitude, and on scenes
+            // that stream their BVH from L2 / HBM the cost per pixel varies as much, so there the grid is only what the chip keeps
+            // resident (RL_FUSED_WAVES x 256-lane workgroups per CU) and lanes draw further items from the dispenser as they finish —
+            // no workgroup idles behind its slowest pixel (cbox + medium, 32 spp: 185.5 -> 151.6 ms; 508 k triangles: 148.6 -> 126.9 ms;
+            // LDS-staged scenes: plain cbox 63.5 vs 63.6 ms, mixed-BSDF cbox 23.3 vs 25.5 ms, so they keep the static tile order).
+            const unsigned resident = (unsigned)cus * (unsigned)(ctx->lds_scene ? RL_FUSED_WAVES : RL_FUSED_WAVES_STREAMING) * 256u;
+            const bool dynamic_items = getenv("RL_FUSED_DYNAMIC") ? atoi(getenv("RL_FUSED_DYNAMIC")) != 0 : (ctx->ds.medium.enabled != 0 || !ctx->lds_scene);
+            P = std::max(256u, (std::min(pl.n_items, dynamic_items ? resident : pl.n_items) + 255u) / 256u * 256u);
+            // sparse item sets (reference-order streams): one item per 2^item_shift lanes, all of them resident from the start
+            const unsigned resident4 = (unsigned)cus * 4u * 256u;
+            while (pl.item_shift < 6u && ((size_t)pl.n_items << (pl.item_shift + 1u)) <= resident4) pl.item_shift++;
+            if (getenv("RL_ITEM_SHIFT")) pl.item_shift = std::min(6u, (unsigned)atoi(getenv("RL_ITEM_SHIFT")));
+            if (pl.item_shift) P = std::max(256u, (unsigned)((((size_t)pl.n_items << pl.item_shift) + 255u) / 256u * 256u));
+        }
+        pl.P = P;
+        return pl;
+    };
+    // ---- chunks of the two-pass form: block cursors [c0, c1) of every owned block per chunk, sized so that the recorded sampler states
+    // (32 B per camera sample) fit their budget; one chunk unless the render is very large (1080p x 128 spp = 8.5 GB).
+    struct Chunk { unsigned c0, c1, n_pix; std::vector<unsigned> base; };
+    std::vector<Chunk> chunks;
+    if (two_pass) {
+        size_t budget = (size_t)24 << 30;
+        if (getenv("RL_STATE_BUDGET_MB")) budget = std::max<size_t>(1, (size_t)atoll(getenv("RL_STATE_BUDGET_MB"))) << 20;   // test knob: forces several chunks
+        const size_t per_cursor = (size_t)owned.size() * params->spp * 32;       // bytes of states one cursor position of every block takes (upper bound)
+        const unsigned cursors_per_chunk = (unsigned)std::max<size_t>(1, std::min<size_t>(256, budget / std::max<size_t>(1, per_cursor)));
+        for (unsigned c0 = 0; c0 < 256u; c0 += cursors_per_chunk) {
+            Chunk ch; ch.c0 = c0; ch.c1 = std::min(256u, c0 + cursors_per_chunk); ch.n_pix = 0;
+            for (size_t j = 0; j < owned.size(); j++) {
+                const unsigned bidx = owned[j], bx = (unsigned)(bidx / nby) * 16u, by = (unsigned)(bidx % nby) * 16u;
+                const unsigned npx = std::min(16u, W - bx) * std::min(16u, H - by);
+                ch.base.push_back(ch.n_pix);
+                ch.n_pix += std::min(ch.c1, npx) - std::min(ch.c0, npx);
+            }
+            if (ch.n_pix) chunks.push_back(std::move(ch));
+        }
     }
-    const unsigned n_items = per_sample ? n_pixels * split : (unsigned)owned.size();
-    // a pool never needs more slots than there are work items (and `pool_slots` is caller input: keep the rounding below from wrapping)
-    unsigned item_shift = 0;
-    unsigned P = params->pool_slots ? std::min(params->pool_slots, std::max(n_items, 1u)) : std::min<unsigned>(n_items, 16u << 20);
-    P = std::max(256u, (unsigned)(((unsigned long long)P + 255ull) / 256ull * 256ull));
-    if (fused) {
-        // One lane per work item by default.  With a participating medium path lengths vary by orders of magnitude, and on scenes
-        // that stream their BVH from L2 / HBM the cost per pixel varies as much, so there the grid is only what the chip keeps
-        // resident (RL_FUSED_WAVES x 256-lane workgroups per CU) and lanes draw further items from the dispenser as they finish —
-        // no workgroup idles behind its slowest pixel (cbox + medium, 32 spp: 185.5 -> 151.6 ms; 508 k triangles: 148.6 -> 126.9 ms;
-        // LDS-staged scenes: plain cbox 63.5 vs 63.6 ms, mixed-BSDF cbox 23.3 vs 25.5 ms, so they keep the static tile order).
-        int cus = 256;
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        const unsigned resident = (unsigned)cus * (unsigned)(ctx->lds_scene ? RL_FUSED_WAVES : RL_FUSED_WAVES_STREAMING) * 256u;
-        const bool dynamic_items = getenv("RL_FUSED_DYNAMIC") ? atoi(getenv("RL_FUSED_DYNAMIC")) != 0 : (ctx->ds.medium.enabled != 0 || !ctx->lds_scene);
-        P = std::max(256u, (std::min(n_items, dynamic_items ? resident : n_items) + 255u) / 256u * 256u);
-        // sparse item sets (reference-order streams): one item per 2^item_shift lanes, all of them resident from the start
-        const unsigned resident4 = (unsigned)cus * 4u * 256u;
-        while (item_shift < 6u && ((size_t)n_items << (item_shift + 1u)) <= resident4) item_shift++;
-        if (getenv("RL_ITEM_SHIFT")) item_shift = std::min(6u, (unsigned)atoi(getenv("RL_ITEM_SHIFT")));
-        if (item_shift) P = std::max(256u, (unsigned)((((size_t)n_items << item_shift) + 255u) / 256u * 256u));
-    }
+    unsigned max_chunk_pix = 0;
+    for (const Chunk& ch : chunks) max_chunk_pix = std::max(max_chunk_pix, ch.n_pix);
+    const Plan plan = two_pass ? plan_items(true, max_chunk_pix, 0) : plan_items(per_sample, n_pixels, (unsigned)owned.size());   // two-pass: the largest second pass
+    const Plan plan_chain = two_pass ? plan_items(false, 0, (unsigned)owned.size()) : Plan{1u, 0u, 0u, 0u};
+    const unsigned split = plan.split, n_items = plan.n_items, item_shift = plan.item_shift;
+    const unsigned P = std::max(plan.P, plan_chain.P);
+    const unsigned n_item_pixels = two_pass ? max_chunk_pix : n_pixels;
     int rcode;
     if ((rcode = ensure(&ctx->d_owned, &ctx->owned_capacity, owned.size())) != RL_OK) return rcode;
     if ((rcode = ensure(&ctx->d_item_base, &ctx->item_base_capacity, owned.size())) != RL_OK) return rcode;
     if ((rcode = ensure(&ctx->d_block_seeds, &ctx->seeds_capacity, n_blocks)) != RL_OK) return rcode;
-    if (per_sample) {
-        if ((rcode = ensure(&ctx->d_item_seed, &ctx->item_capacity, n_pixels)) != RL_OK) return rcode;
-        if ((rcode = ensure(&ctx->d_item_pixel, &ctx->item_pixel_capacity, n_pixels)) != RL_OK) return rcode;
+    if (per_sample || two_pass) {
+        if (per_sample && (rcode = ensure(&ctx->d_item_seed, &ctx->item_capacity, n_item_pixels)) != RL_OK) return rcode;
+        if ((rcode = ensure(&ctx->d_item_pixel, &ctx->item_pixel_capacity, n_item_pixels)) != RL_OK) return rcode;
+    }
+    if (two_pass) {
+        if ((rcode = ensure(&ctx->d_sample_states, &ctx->sample_states_capacity, (size_t)max_chunk_pix * params->spp * 4)) != RL_OK) return rcode;
+        if ((rcode = ensure(&ctx->d_chain_states, &ctx->chain_states_capacity, owned.size() * 4)) != RL_OK) return rcode;
     }
     if (!fused && ctx->pool_capacity < P) {
         if (ctx->pool.f) hipFree(ctx->pool.f);
@@ -548,7 +603,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         }
         ctx->pool_capacity = P;
     }
-    if (split > 1 && (rcode = ensure(&ctx->d_sample_buf, &ctx->sample_buf_capacity, (size_t)n_pixels * params->spp * 3)) != RL_OK) return rcode;
+    if (split > 1 && (rcode = ensure(&ctx->d_sample_buf, &ctx->sample_buf_capacity, (size_t)n_item_pixels * params->spp * 3)) != RL_OK) return rcode;
     Pool pool = ctx->pool;
     pool.P = P;
     const bool use_sort = !ctx->single_bsdf;
@@ -559,13 +614,13 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     }
 
     HIP_OK(hipMemcpyAsync(ctx->d_owned, owned.data(), owned.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(ctx->d_item_base, item_base.data(), item_base.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    if (!two_pass) HIP_OK(hipMemcpyAsync(ctx->d_item_base, item_base.data(), item_base.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(ctx->d_block_seeds, block_seeds, n_blocks * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     HIP_OK(hipMemsetAsync(d_out, 0, (size_t)3 * W * H * sizeof(float), st));
     Counters init{};
-    init.active = std::min(P, n_items);
-    init.next_item = item_shift ? n_items : P;
-    HIP_OK(hipMemcpyAsync(ctx->d_counters, &init, sizeof(init), hipMemcpyHostToDevice, st));
+    init.active = std::min(plan.P, n_items);
+    init.next_item = item_shift ? n_items : plan.P;
+    if (!two_pass) HIP_OK(hipMemcpyAsync(ctx->d_counters, &init, sizeof(init), hipMemcpyHostToDevice, st));
     const size_t n_partial_rows = (P + 255) / 256;
     if ((rcode = ensure(&ctx->d_partials, &ctx->partials_capacity, n_partial_rows * STAT_COUNT)) != RL_OK) return rcode;
     HIP_OK(hipMemsetAsync(ctx->d_partials, 0, n_partial_rows * STAT_COUNT * sizeof(unsigned long long), st));
@@ -588,20 +643,19 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     rc.out = d_out;
     rc.counters = ctx->d_counters;
     rc.partials = ctx->d_partials;
+    rc.sample_states = ctx->d_sample_states; rc.chain_states = ctx->d_chain_states;
 
     const DeviceScene& ds = ctx->ds;
     const dim3 block(256);
-    const dim3 grid_all((P + 255) / 256);
+    const dim3 grid_all((plan.P + 255) / 256);
     // material-sort kernel: sparse pools (several lanes per pixel) are gathered four 256-slot chunks per workgroup
     const unsigned sort_chunks = split > 1 ? 4u : 1u;
     const dim3 grid_sort((P + 1023) / 1024);
-    int n_cu = 256;
-    hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    const dim3 grid_persistent(std::min<unsigned>((P + 255) / 256, (unsigned)n_cu * 8u));
+    const dim3 grid_persistent(std::min<unsigned>((P + 255) / 256, (unsigned)cus * 8u));
     const bool medium = ds.medium.enabled != 0;
     const size_t lds_trav = traversal_lds_bytes(ctx, ctx->lds_scene, 256, true);
     StackConf stc;
-    if ((rcode = stack_conf(ctx, (size_t)grid_all.x * 256, &stc)) != RL_OK) return rcode;
+    if ((rcode = stack_conf(ctx, (size_t)((P + 255) / 256) * 256, &stc)) != RL_OK) return rcode;
 
     if (per_sample && !owned.empty()) hipLaunchKernelGGL(k_seed_pixels, dim3(((unsigned)owned.size() + 63) / 64), dim3(64), 0, st, rc);
     if (!fused) hipLaunchKernelGGL(k_init, grid_all, block, 0, st, rc, pool);
@@ -626,11 +680,51 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             }
         return RL_OK;
     };
-    double ms_fused = 0.0;
-    if (fused) {
-        const size_t lds_fused = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + kFusedColdBytes + ((ctx->lds_scene || RL_COOP_FETCH != 1) ? 0 : (size_t)4 * kCoopStageFloat4s * sizeof(float4));
+    double ms_fused = 0.0, ms_chain = 0.0;
+    const size_t lds_fused = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + kFusedColdBytes + ((ctx->lds_scene || RL_COOP_FETCH != 1) ? 0 : (size_t)4 * kCoopStageFloat4s * sizeof(float4));
+    auto launch_fused = [&](const RenderConst& rcl, dim3 grid) {
+        (ctx->lds_scene ? (fast_math ? launch_fused_lds_fast : launch_fused_lds) : (fast_math ? launch_fused_stream_fast : launch_fused_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, ctx->area_lights_only, grid, block, lds_fused, st, rcl, ds, stc);
+    };
+    if (two_pass) {
+        const size_t lds_chain = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false);
+        for (const Chunk& ch : chunks) {
+            // ---- pass 1: the chains
+            HIP_OK(hipMemcpyAsync(ctx->d_item_base, ch.base.data(), ch.base.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
+            RenderConst ra = rc;
+            ra.stream_mode = RL_STREAM_REFERENCE_ORDER;
+            ra.n_items = plan_chain.n_items; ra.item_shift = plan_chain.item_shift; ra.split = 1;
+            ra.n_state_pixels = ch.n_pix; ra.cursor_begin = ch.c0; ra.cursor_end = ch.c1;
+            hipLaunchKernelGGL(k_chunk_pixels, dim3(((unsigned)owned.size() + 63) / 64), dim3(64), 0, st, ra);
+            if (timing) hipEventRecord(ctx->events[0], st);
+            (ctx->lds_scene ? (fast_math ? launch_chain_lds_fast : launch_chain_lds) : (fast_math ? launch_chain_stream_fast : launch_chain_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, dim3((plan_chain.P + 255) / 256), block, lds_chain, st, ra, ds, stc);
+            if (timing) hipEventRecord(ctx->events[1], st);
+            // ---- pass 2: every camera sample of the chunk from its recorded state, per-pixel work items
+            const Plan pb = plan_items(true, ch.n_pix, 0);
+            RenderConst rb = ra;
+            rb.stream_mode = kStreamGivenStates;
+            rb.n_items = pb.n_items; rb.item_shift = pb.item_shift; rb.split = pb.split;
+            Counters cinit{};
+            cinit.active = std::min(pb.P, pb.n_items);
+            cinit.next_item = pb.item_shift ? pb.n_items : pb.P;
+            HIP_OK(hipMemcpyAsync(ctx->d_counters, &cinit, sizeof(cinit), hipMemcpyHostToDevice, st));
+            if (timing) hipEventRecord(ctx->events[2], st);
+            launch_fused(rb, dim3((pb.P + 255) / 256));
+            if (timing) hipEventRecord(ctx->events[3], st);
+            if (pb.split > 1) hipLaunchKernelGGL(k_fold_samples, dim3((ch.n_pix + 255) / 256), block, 0, st, rb);
+            HIP_OK(hipGetLastError());
+            HIP_OK(hipStreamSynchronize(st));       // (the chunk's host arrays and the counters block are reused by the next chunk)
+            if (timing) {
+                float t = 0.0f;
+                HIP_OK(hipEventElapsedTime(&t, ctx->events[0], ctx->events[1])); ms_chain += t;
+                HIP_OK(hipEventElapsedTime(&t, ctx->events[2], ctx->events[3])); ms_fused += t;
+            }
+            launches += 3 + (pb.split > 1 ? 1 : 0);
+        }
+        dump_stage_timers(ctx->lds_scene);
+        iterations = chunks.size();
+    } else if (fused) {
         if (timing) hipEventRecord(ctx->events[0], st);
-        (ctx->lds_scene ? (fast_math ? launch_fused_lds_fast : launch_fused_lds) : (fast_math ? launch_fused_stream_fast : launch_fused_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, ctx->area_lights_only, grid_all, block, lds_fused, st, rc, ds, stc);
+        launch_fused(rc, grid_all);
         if (timing) hipEventRecord(ctx->events[1], st);
         HIP_OK(hipGetLastError());          // a refused launch configuration is not sticky: without this the sync below would "succeed"
         HIP_OK(hipStreamSynchronize(st));
@@ -678,7 +772,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     }
 #endif
     // one more raygen pass is never needed: `active` reaches 0 inside k_raygen after the last fold.
-    if (split > 1) { hipLaunchKernelGGL(k_fold_samples, dim3((n_pixels + 255) / 256), block, 0, st, rc); launches += 1; }
+    if (split > 1 && !two_pass) { hipLaunchKernelGGL(k_fold_samples, dim3((n_pixels + 255) / 256), block, 0, st, rc); launches += 1; }
     if (!out_is_device) HIP_OK(hipMemcpyAsync(out_rgb, d_out, (size_t)3 * W * H * sizeof(float), hipMemcpyDeviceToHost, st));
     std::vector<unsigned long long> partials(n_partial_rows * STAT_COUNT);
     HIP_OK(hipMemcpyAsync(partials.data(), ctx->d_partials, partials.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -699,6 +793,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         stats->render_ms = std::chrono::duration<double, std::milli>(t_end - t_start).count();
         stats->ms_raygen = ms[0]; stats->ms_extend = ms[1]; stats->ms_shade = ms[2]; stats->ms_shadow = ms[3];
         stats->ms_other = ms_fused;   // the persistent fused kernel (pipeline 2)
+        stats->ms_prepass = ms_chain;  // k_stream_chain (reference-order streams, first pass)
         stats->n_extend_launches = n_extend;
     }
     return RL_OK;

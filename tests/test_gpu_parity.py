@@ -3,6 +3,8 @@ inputs.  Bar (BASELINE.json): RNG sequence bit-exact; per-pixel squared L2 < 1e-
 Because both sides use IEEE f32 without contraction and the same deterministic transcendentals, the
 comparisons below are in fact bit-exact against the oracle's forward evaluation order, and within
 f32 rounding of the reference's recursive order."""
+import os
+
 import numpy as np
 import pytest
 
@@ -657,6 +659,83 @@ def test_cfg1_reference_order_whole_frame(built):
         img, st = ctx.render(api.IndependentSampler(0).block_seeds(256, 256), api.path_params(spp=16, stream_mode=api.STREAM_REFERENCE_ORDER, pipeline=pipeline))
         _assert_parity(img, st, ref_fwd, ref_rec, ost)
     assert st["camera_samples"] == 256 * 256 * 16
+
+
+def test_reference_order_two_pass_equals_single_pass(built, monkeypatch):
+    """RL_STREAM_REFERENCE_ORDER through the persistent kernel runs in two passes (k_stream_chain records the sampler state at the start of
+    every camera sample with the radiance half of the integrator left out; the per-sample kernel evaluates them): the image and every counter
+    must be those of the single-pass walk (RL_REF_SINGLE_PASS, the form rounds 1-2 shipped) and of the oracle, bit for bit — on every scene
+    feature that changes how many draws a sample takes (smooth BSDFs skip the light sample, media add distance / phase draws, strategies,
+    depth limits, Russian roulette off), with the states cut into several chunks (RL_STATE_BUDGET_MB) and through the streaming kernels."""
+    ref_mode = api.STREAM_REFERENCE_ORDER
+    cases = [(scenes.cbox(70, 41), dict(spp=5)),
+             (scenes.cbox(48, 48), dict(spp=3, strategy=api.STRATEGY_BSDF, max_depth=6)),
+             (scenes.cbox(48, 48), dict(spp=3, strategy=api.STRATEGY_EMITTER)),
+             (scenes.cbox(48, 48), dict(spp=2, rr_depth=None, max_depth=9)),
+             (scenes.cbox(48, 48), dict(spp=3, rr_depth=3, min_depth=1, max_depth=7)),
+             (scenes.cbox(32, 32), dict(spp=2, max_depth=1)),
+             (scenes.cbox_medium(40, 40, 0.8, 0.2, g=0.6), dict(spp=3)),
+             (scenes.cbox_medium(32, 32, 0.5), dict(spp=2, single_scattering=True)),
+             (scenes.living_room(64, 48, n_spheres=27, tess=10), dict(spp=4, max_depth=10)),          # glass / mirror / phong / substrate
+             (scenes.cbox_other_lights(48, 48), dict(spp=3)),
+             (scenes.sky_scene(48, 48), dict(spp=3, min_depth=1)),
+             (scenes.many_lights(48, 48, n=5, use_ats=True), dict(spp=2, max_depth=4))]
+    for sd, kw in cases:
+        ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+        monkeypatch.delenv("RL_REF_SINGLE_PASS", raising=False)
+        monkeypatch.delenv("RL_STATE_BUDGET_MB", raising=False)
+        two = _render_pair(sd, ctx, osc, seed=3, stream_mode=ref_mode, **kw)
+        _assert_parity(*two)
+        assert two[1]["ms_prepass"] > 0.0 and two[1]["ms_other"] > 0.0          # both passes ran
+        monkeypatch.setenv("RL_REF_SINGLE_PASS", "1")
+        one = _render_pair(sd, ctx, osc, seed=3, stream_mode=ref_mode, **kw)
+        assert one[1]["ms_prepass"] == 0.0
+        np.testing.assert_array_equal(two[0], one[0])
+        assert all(two[1][k] == one[1][k] for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws"))
+        monkeypatch.delenv("RL_REF_SINGLE_PASS")
+        for split in (0, 3):
+            img, st = ctx.render(api.IndependentSampler(3).block_seeds(sd.width, sd.height), api.path_params(stream_mode=ref_mode, sample_split=split, **kw))
+            np.testing.assert_array_equal(img, two[0])
+    # several chunks: 1 MB of states = a few block cursors per chunk on this frame (130 blocks x 24 spp x 32 B per cursor)
+    sd = scenes.cbox(160, 200)
+    ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+    whole = _render_pair(sd, ctx, osc, seed=1, stream_mode=ref_mode, spp=24)
+    _assert_parity(*whole)
+    monkeypatch.setenv("RL_STATE_BUDGET_MB", "1")
+    img, st = ctx.render(api.IndependentSampler(1).block_seeds(160, 200), api.path_params(stream_mode=ref_mode, spp=24))
+    assert st["iterations"] > 10                                                  # chunks
+    np.testing.assert_array_equal(img, whole[0])
+    assert all(st[k] == whole[1][k] for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws"))
+    monkeypatch.delenv("RL_STATE_BUDGET_MB")
+    # shards: the chains of a shard's blocks only
+    parts = [ctx.render(api.IndependentSampler(1).block_seeds(160, 200), api.path_params(stream_mode=ref_mode, spp=24, shard_index=r, shard_count=3))[0] for r in range(3)]
+    np.testing.assert_array_equal(parts[0] + parts[1] + parts[2], whole[0])
+
+
+def test_full_size_reference_order(built):
+    """BASELINE cfg 2's frame in the drop-in default mode, RL_STREAM_REFERENCE_ORDER (rustlight's own stream assignment,
+    src/integrators/mod.rs:420-435), 1920x1080 x 8 spp through the two-pass form: 8 blocks (the four busiest + fixed ones inside and outside
+    the box) equal the oracle's walk of the same block streams bit for bit, the single-pass walk gives the same frame and counters."""
+    sd = scenes.cbox(1920, 1080)
+    ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+    seeds = api.IndependentSampler(0).block_seeds(1920, 1080)
+    a, st = ctx.render(seeds, api.path_params(spp=8, stream_mode=api.STREAM_REFERENCE_ORDER))
+    assert st["camera_samples"] == 1920 * 1080 * 8 and st["ms_prepass"] > 0.0 and np.isfinite(a).all()
+    nby, nb = 68, 120 * 68
+    verts = 0
+    for b in _busiest_blocks(a, 4) + [60 * 68 + 34, 45 * 68 + 20, 75 * 68 + 50, 2 * 68 + 3]:
+        ref, ost = osc.render(seeds=seeds, spp=8, stream_mode=0, eval_order=1, shard_index=int(b), shard_count=nb)
+        x0, y0 = (b // nby) * 16, (b % nby) * 16
+        np.testing.assert_array_equal(a[y0:y0 + 16, x0:x0 + 16], ref[y0:y0 + 16, x0:x0 + 16], err_msg=f"block {b} at ({x0}, {y0})")
+        verts += ost["vertices"]
+    assert verts > 8000
+    os.environ["RL_REF_SINGLE_PASS"] = "1"
+    try:
+        b1, st1 = ctx.render(seeds, api.path_params(spp=8, stream_mode=api.STREAM_REFERENCE_ORDER))
+    finally:
+        del os.environ["RL_REF_SINGLE_PASS"]
+    np.testing.assert_array_equal(a, b1)
+    assert all(st[k] == st1[k] for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws"))
 
 
 def test_multi_context_rccl_reduce(built, cbox64, ctx_cbox):
