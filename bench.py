@@ -10,18 +10,24 @@ outside, as in the reference (integrators/mod.rs:280 vs 324-334).
 `python bench.py --gpus N` starts its own N ranks (re-executes itself under torch.distributed.run) unless it already runs
 under a launcher (WORLD_SIZE set).  On a box with fewer GPUs than ranks the ranks share devices and the reduce goes
 through gloo — a plumbing mode, flagged in the JSON (`devices_shared`), never a scaling measurement.
+`--scaling weak` (default): the image is fixed and spp = 128 x N, every GPU traces W*H*128 camera samples per step (N = 8 is
+BASELINE configs[3]); `--scaling strong`: 128 spp in total, the tiles split N ways.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_path_fused on this workload): algorithmic bytes
 per launch / mean launch duration from HIP events on the render stream.  `cpu_baseline` times the
 CPU oracle (a C++ restatement of rustlight's path integrator — NOT rustlight itself) on a bounded
-sample of the same workload on the host cores."""
+sample of the same workload on the host cores.  On the default single-GPU run the line also carries `also`: the other BASELINE
+configurations and stream modes timed the same way in the same process (configs[2] stand-in, configs[4], configs[1] in
+rustlight's own reference-order streams, configs[1] on a square frame), and `reference_order_value` at the top level."""
 from __future__ import annotations
 
 import argparse
+import datetime
 import json
 import os
 import socket
 import sys
+import threading
 import time
 import zlib
 
@@ -31,6 +37,8 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
+
+PEAK_HBM_GBPS = 8000.0
 
 
 def parse_args(argv=None):
@@ -47,10 +55,13 @@ def parse_args(argv=None):
     ap.add_argument("--pool", type=int, default=0)
     ap.add_argument("--pipeline", default="auto", choices=["auto", "wavefront", "fused"])
     ap.add_argument("--stream-mode", default="per_sample", choices=["per_sample", "reference"],
-                    help="per_sample: one lane per pixel / sample (throughput decomposition); reference: one lane per 16x16 block, rustlight's own stream assignment")
+                    help="per_sample: one lane per pixel / sample (throughput decomposition); reference: rustlight's own stream assignment (one sampler per 16x16 block)")
     ap.add_argument("--numerics", default="exact", choices=["exact", "fast"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: spp x N (fixed work per GPU); strong: spp in total, tiles split N ways")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed single-GPU re-render that checks the N-GPU image CRC")
+    ap.add_argument("--no-also", action="store_true", help="skip the `also` sub-records (the other BASELINE configs / stream modes) of the default single-GPU run")
+    ap.add_argument("--init-timeout", type=float, default=180.0, help="seconds the process-group init and the first collective may take before the rank prints diagnostics and exits")
     return ap.parse_args(argv)
 
 
@@ -72,6 +83,39 @@ def _respawn_under_launcher(args):
     os.execvp(cmd[0], cmd)
 
 
+def is_default_workload(args) -> bool:
+    """The run the driver makes (`python bench.py --gpus 1 ...`): BASELINE configs[1] untouched — only then the `also` records are added."""
+    return (args.gpus == 1 and args.scene == "cbox" and (args.width, args.height, args.spp) == (1920, 1080, 128) and args.stream_mode == "per_sample"
+            and args.numerics == "exact" and args.pipeline == "auto" and args.pool == 0 and args.tris == 0 and not args.no_also)
+
+
+class _Watchdog:
+    """A collective that never returns (first RCCL contact between ranks: peer access, IPC handles, a wrong device) must not hang the
+    driver's run silently: after `seconds` the rank prints who / where it is and exits non-zero."""
+
+    def __init__(self, what, seconds, info):
+        self.t = threading.Timer(seconds, self._fire)
+        self.what, self.info, self.seconds = what, info, seconds
+        self.t.daemon = True
+
+    def _fire(self):
+        print(f"bench.py: {self.what} did not finish within {self.seconds:.0f} s: {json.dumps(self.info)}", file=sys.stderr, flush=True)
+        os._exit(3)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
+def pipeline_bytes(stats_sum, pixels, steps):
+    """SURVEY.md §8(d) / DESIGN.md §4: algorithmic bytes of the whole pipeline = 248 B / camera sample + 352 B / expanded vertex + 12 B / pixel."""
+    return 248 * stats_sum["camera_samples"] + 352 * stats_sum["vertices"] + 12 * pixels * steps
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -87,82 +131,99 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback path exists)")
     n_dev = torch.cuda.device_count()
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_rank = int(os.environ.get("RANK", "0"))
+    env_local = int(os.environ.get("LOCAL_RANK", "0"))
     # fewer devices than ranks (or RL_BENCH_SHARE_DEVICE=1): ranks share devices, RCCL cannot (one rank per device), so the reduce goes through gloo
     shared = env_world > n_dev or bool(os.environ.get("RL_BENCH_SHARE_DEVICE"))
     backend = os.environ.get("RL_BENCH_BACKEND") or ("gloo" if shared else "nccl")
-    rank, world, local_rank = rd.init_from_env(args.gpus, backend)
+    # the device is chosen BEFORE the process group exists and handed to it (device_id): RCCL then binds its communicator to this GPU at init,
+    # not lazily to whatever device happens to be current at the first collective
+    device_index = env_local % n_dev
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
+    who = {"rank": env_rank, "local_rank": env_local, "world": env_world, "device": device_index, "devices_visible": n_dev, "backend": backend,
+           "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}", "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+           "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES"), "ROCR_VISIBLE_DEVICES": os.environ.get("ROCR_VISIBLE_DEVICES"), "pid": os.getpid()}
+    with _Watchdog("torch.distributed init + first collective", args.init_timeout, who):
+        try:
+            rank, world, local_rank = rd.init_from_env(args.gpus, backend, device=dev if backend == "nccl" else None, timeout_s=args.init_timeout)
+            if world > 1:
+                rd.max_over_ranks(1.0)          # first contact between the ranks (communicator setup over xGMI), outside every timed region
+        except Exception as e:      # noqa: BLE001 — whatever RCCL / the store raises: say where, then fail
+            print(f"bench.py: process-group init failed: {e!r}: {json.dumps(who)}", file=sys.stderr, flush=True)
+            raise
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} is running with WORLD_SIZE={world}: launch it with --nproc-per-node {args.gpus} (or without a launcher)")
     if world > 1:
         assert dist.is_initialized() and dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
-    device_index = local_rank % n_dev
-    torch.cuda.set_device(device_index)
-    dev = torch.device("cuda", device_index)
 
-    if args.scene == "cbox":
-        sd = scenes.cbox(args.width, args.height)
-        workload = f"cbox {args.width}x{args.height}x{args.spp}spp-per-GPU diffuse path (BASELINE configs[1]; configs[3] at 8 GPUs)"
-    elif args.scene == "cbox_medium":
-        sd = scenes.cbox_medium(args.width, args.height, 0.5)
-        workload = f"cbox + homogeneous medium sigma_s=0.5 {args.width}x{args.height}x{args.spp}spp (BASELINE configs[4])"
-    else:
-        tess = 32
-        while 256 * 2 * tess * (tess - 1) + 14 < args.tris: tess += 1
-        sd = scenes.living_room(args.width, args.height, tess=tess)
-        workload = (f"living-room-class synthetic stand-in ({sd.n_triangles} tris, 6 BSDF types; the real pbrt-v3 living-room is not available) "
-                    f"{args.width}x{args.height}x{args.spp}spp (BASELINE configs[2])")
-    scene = api.Scene(sd)
-    ctx = api.Context(scene, device_index)          # BVH build + upload: untimed, like the reference (mod.rs:280)
-    fb = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device=dev)
-    host_fb = torch.zeros((args.height, args.width, 3), dtype=torch.float32).pin_memory() if rank == 0 else None
     # ONE explicit stream for everything a step enqueues (render, reduce, download): torch's default stream has handle 0, which the C-ABI
     # reads as "use the context's own stream" — the next step's framebuffer memset would then race the previous step's reduce / download
     work_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(work_stream)
     stream = work_stream.cuda_stream
     assert stream != 0
-
-    # weak scaling: the image is fixed and spp grows with the GPU count (128 spp at N=1 ... 1024 spp at N=8 =
-    # BASELINE configs[3]), so every GPU always traces W*H*128 camera samples per step.
-    spp_total = args.spp * world
-    stream_mode = api.STREAM_PER_SAMPLE if args.stream_mode == "per_sample" else api.STREAM_REFERENCE_ORDER
     pipeline = {"auto": 0, "wavefront": 1, "fused": 2}[args.pipeline]
-    numerics = {"exact": 0, "fast": 1}[args.numerics]
+    STAT_KEYS = ("camera_samples", "vertices", "extension_rays", "shadow_rays", "iterations", "n_extend_launches", "kernel_launches")
+    MS_KEYS = ("ms_raygen", "ms_extend", "ms_shade", "ms_shadow", "ms_other", "ms_prepass")
 
-    def params(shard_index, shard_count):
-        return api.path_params(spp=spp_total, shard_index=shard_index, shard_count=shard_count, pool_slots=args.pool, pipeline=pipeline,
-                               stream_mode=stream_mode, numerics=numerics)
+    def build_scene(name, width, height, tris=0):
+        if name == "cbox":
+            return scenes.cbox(width, height), f"cbox {width}x{height} diffuse path"
+        if name == "cbox_medium":
+            return scenes.cbox_medium(width, height, 0.5), f"cbox + homogeneous medium sigma_s=0.5 {width}x{height}"
+        tess = 32
+        while 256 * 2 * tess * (tess - 1) + 14 < tris: tess += 1
+        sd = scenes.living_room(width, height, tess=tess)
+        return sd, f"living-room-class synthetic stand-in ({sd.n_triangles} tris, 6 BSDF types; the real pbrt-v3 living-room is not available) {width}x{height}"
 
-    def step(seed):
-        seeds = api.IndependentSampler(seed).block_seeds(args.width, args.height)     # same master stream on every rank
-        _, st = ctx.render(seeds, params(rank, world), out_device_ptr=fb.data_ptr(), stream=stream)
-        if world > 1:
-            rd.reduce_framebuffer(fb)                                                   # one RCCL reduce over xGMI
-        if rank == 0:
-            host_fb.copy_(fb, non_blocking=True)                                        # framebuffer download (inside the timed region, §8(d))
-        return st
+    def time_workload(ctx, width, height, spp_total, stream_mode, numerics, steps, warmup, shard=(0, 1), pool=0, pipe=0):
+        """`steps` timed renders (+ reduce + download) between barriers; returns the record the JSON lines are made of."""
+        fb = torch.zeros((height, width, 3), dtype=torch.float32, device=dev)
+        host_fb = torch.zeros((height, width, 3), dtype=torch.float32).pin_memory() if rank == 0 else None
 
-    for w in range(args.warmup):
-        step(1000 + w)
-    rd.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    stats = []
-    for s in range(args.steps):
-        stats.append(step(s))
-    rd.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    dt = rd.max_over_ranks(dt)
-    host_img = host_fb.numpy() if rank == 0 else None
+        def params(shard_index, shard_count):
+            return api.path_params(spp=spp_total, shard_index=shard_index, shard_count=shard_count, pool_slots=pool, pipeline=pipe,
+                                   stream_mode=api.STREAM_PER_SAMPLE if stream_mode == "per_sample" else api.STREAM_REFERENCE_ORDER,
+                                   numerics={"exact": 0, "fast": 1}[numerics])
 
-    samples_per_step = args.width * args.height * spp_total
-    value = samples_per_step * args.steps / dt / 1e6
-    agg = {k: sum(s[k] for s in stats) for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "iterations", "n_extend_launches", "kernel_launches")}
-    ms = {k: sum(s[k] for s in stats) for k in ("ms_raygen", "ms_extend", "ms_shade", "ms_shadow", "ms_other")}
+        def step(seed):
+            seeds = api.IndependentSampler(seed).block_seeds(width, height)              # same master stream on every rank
+            _, st = ctx.render(seeds, params(*shard), out_device_ptr=fb.data_ptr(), stream=stream)
+            if shard[1] > 1:
+                rd.reduce_framebuffer(fb)                                                 # one RCCL reduce over xGMI
+            if rank == 0:
+                host_fb.copy_(fb, non_blocking=True)                                      # framebuffer download (inside the timed region, §8(d))
+            return st
+
+        for w in range(warmup):
+            step(1000 + w)
+        rd.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        stats = [step(s) for s in range(steps)]
+        rd.barrier()
+        torch.cuda.synchronize()
+        dt = rd.max_over_ranks(time.perf_counter() - t0)
+        agg = {k: sum(s[k] for s in stats) for k in STAT_KEYS}
+        ms = {k: sum(s[k] for s in stats) for k in MS_KEYS}
+        host_img = host_fb.numpy().copy() if rank == 0 else None
+        return {"dt": dt, "agg": agg, "ms": ms, "host_img": host_img, "params": params, "steps": steps, "samples_per_step": width * height * spp_total}
+
+    # ---- the headline workload
+    sd, what = build_scene(args.scene, args.width, args.height, args.tris)
+    spp_total = args.spp * world if args.scaling == "weak" else args.spp
+    workload = {"cbox": f"{what} x{args.spp}spp-per-GPU (BASELINE configs[1]; configs[3] at 8 GPUs)" if args.scaling == "weak" else f"{what} x{args.spp}spp in total (BASELINE configs[1], strong scaling)",
+                "cbox_medium": f"{what} x{args.spp}spp (BASELINE configs[4])", "living_room": f"{what} x{args.spp}spp (BASELINE configs[2])"}[args.scene]
+    scene = api.Scene(sd)
+    ctx = api.Context(scene, device_index)          # BVH build + upload: untimed, like the reference (mod.rs:280)
+    main_rec = time_workload(ctx, args.width, args.height, spp_total, args.stream_mode, args.numerics, args.steps, args.warmup,
+                             shard=(rank, world), pool=args.pool, pipe=pipeline)
+    dt, agg, ms, host_img = main_rec["dt"], main_rec["agg"], main_rec["ms"], main_rec["host_img"]
+    value = main_rec["samples_per_step"] * args.steps / dt / 1e6
     agg_all = rd.sum_over_ranks(agg)
     ranks = rd.gather_objects({"rank": rank, "device": device_index, "name": torch.cuda.get_device_name(device_index), "pid": os.getpid(),
-                               "kernel_ms_per_step": (ms["ms_other"] or sum(ms.values())) / max(1, args.steps)})
+                               "kernel_ms_per_step": ((ms["ms_other"] + ms["ms_prepass"]) or sum(ms.values())) / max(1, args.steps)})
 
     if rank == 0:
         # ---- the N-GPU image must be the 1-GPU image, bit for bit (sums with zeros are exact): re-render the last step's
@@ -171,16 +232,17 @@ def main():
         crc_single = None
         if world > 1 and not args.no_verify:
             seeds = api.IndependentSampler(args.steps - 1).block_seeds(args.width, args.height)
-            single, _ = ctx.render(seeds, params(0, 1))
+            single, _ = ctx.render(seeds, main_rec["params"](0, 1))
             crc_single = zlib.crc32(single.tobytes())
             if crc_single != crc:       # reported in the JSON (crc_match: false) rather than raised: the other ranks are waiting in a barrier
                 print(f"ERROR: {world}-GPU image CRC {crc:08x} != 1-GPU image CRC {crc_single:08x}", file=sys.stderr)
         # ---- roofline.  Algorithmic bytes per unit:
         #   k_raygen 108 B/camera sample, k_extend 44 B/ray, k_shade 280 B/vertex, k_shadow 72 B/shadow ray,
         #   k_path_fused (all four stages in one persistent launch): the whole-pipeline figure
-        #   248 B/camera sample + 352 B/expanded vertex + 12 B/pixel.
+        #   248 B/camera sample + 352 B/expanded vertex + 12 B/pixel; k_stream_chain (first pass of reference-order streams): 32 B of sampler
+        #   state written per camera sample + 44 B per extension ray
         pix = args.width * args.height / world
-        pipe_bytes = 248 * agg["camera_samples"] + 352 * agg["vertices"] + 12 * pix * args.steps
+        pipe_bytes = pipeline_bytes(agg, pix, args.steps)
         fused = ms["ms_other"] > 0.0
         names = {"ms_raygen": "k_raygen", "ms_extend": "k_extend", "ms_shade": "k_shade", "ms_shadow": "k_shadow", "ms_other": "k_path_fused"}
         per_unit = {"ms_raygen": 108, "ms_extend": 44, "ms_shade": 280, "ms_shadow": 72}
@@ -191,12 +253,17 @@ def main():
             if ms[k] > 0:
                 avg = ms[k] / n_launch[k]
                 gbs = per_unit[k] * units[k] / n_launch[k] / (avg * 1e-3) / 1e9
-                kernels[names[k]] = {"avg_launch_ms": avg, "launches": n_launch[k], "algorithmic_bytes_per_unit": per_unit[k], "achieved_GBps": gbs, "frac": gbs / 8000.0}
+                kernels[names[k]] = {"avg_launch_ms": avg, "launches": n_launch[k], "algorithmic_bytes_per_unit": per_unit[k], "achieved_GBps": gbs, "frac": gbs / PEAK_HBM_GBPS}
         if fused:
             avg = ms["ms_other"] / args.steps
             gbs = pipe_bytes / args.steps / (avg * 1e-3) / 1e9
             kernels["k_path_fused"] = {"avg_launch_ms": avg, "launches": args.steps, "algorithmic_bytes_per_unit": "248/sample + 352/vertex + 12/pixel",
-                                       "achieved_GBps": gbs, "frac": gbs / 8000.0}
+                                       "achieved_GBps": gbs, "frac": gbs / PEAK_HBM_GBPS}
+        if ms["ms_prepass"] > 0.0:
+            avg = ms["ms_prepass"] / args.steps
+            gbs = (32 * agg["camera_samples"] + 44 * agg["extension_rays"]) / args.steps / (avg * 1e-3) / 1e9
+            kernels["k_stream_chain"] = {"avg_launch_ms": avg, "launches": args.steps, "algorithmic_bytes_per_unit": "32/sample + 44/extension ray",
+                                         "achieved_GBps": gbs, "frac": gbs / PEAK_HBM_GBPS}
         dominant = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches"])
         # PMC numbers are NOT collected in this run (rocprofv3 --pmc needs its own passes: scratch/pmc_collect.sh).  They are quoted
         # only when they were collected on this very kernel source (hash of csrc/kernels + flags), with their provenance.
@@ -213,14 +280,53 @@ def main():
         except Exception:
             pass
         roofline = {"bound": (pmc_entry or {}).get("bound", "valu"), "kernel": dominant,
-                    "achieved": kernels[dominant]["achieved_GBps"], "peak": 8000.0, "unit": "GB/s", "frac": kernels[dominant]["frac"],
+                    "achieved": kernels[dominant]["achieved_GBps"], "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": kernels[dominant]["frac"],
                     "note": "achieved = ALGORITHMIC bytes (SURVEY §8(d): state a wavefront pipeline would stream) / kernel time; the fused kernel keeps that state in "
                             "registers / LDS, so measured HBM traffic (`traffic`) is far below it and the kernel is bound by VALU issue + latency, not by HBM",
                     "traffic": traffic, "avg_launch_ms": kernels[dominant]["avg_launch_ms"],
                     "launches": kernels[dominant]["launches"], "kernels": kernels,
-                    "pipeline_algorithmic_GBps": pipe_bytes / dt / 1e9, "pipeline_frac": pipe_bytes / dt / 1e9 / 8000.0,
+                    "pipeline_algorithmic_GBps": pipe_bytes / dt / 1e9, "pipeline_frac": pipe_bytes / dt / 1e9 / PEAK_HBM_GBPS,
                     "rays_per_s": (agg_all["extension_rays"] + agg_all["shadow_rays"]) / dt,
                     "kernel_src_hash": src_hash, "pmc": pmc_entry}
+
+        # ---- `also`: the other BASELINE configurations and stream modes, timed the same way in this process (default single-GPU run only)
+        also, reference_order_value = None, None
+        if is_default_workload(args) and world == 1:
+            also = []
+
+            def sub(tag, rec, what, extra=None):
+                a, m = rec["agg"], rec["ms"]
+                width, height = rec["host_img"].shape[1], rec["host_img"].shape[0]
+                kernel_ms = {k: v / rec["steps"] for k, v in (("k_path_fused", m["ms_other"]), ("k_stream_chain", m["ms_prepass"])) if v > 0}
+                kms = sum(kernel_ms.values())
+                r = {"workload": tag, "what": what, "steps": rec["steps"], "ms_per_step": rec["dt"] / rec["steps"] * 1e3,
+                     "value": rec["samples_per_step"] * rec["steps"] / rec["dt"] / 1e6, "unit": "Msamples/s",
+                     "kernel_ms": {k: round(v, 3) for k, v in kernel_ms.items()}, "kernel_ms_total": round(kms, 3),
+                     "mean_vertices_per_sample": a["vertices"] / max(1, a["camera_samples"]),
+                     "rays_per_s": (a["extension_rays"] + a["shadow_rays"]) / rec["dt"],
+                     "frac": pipeline_bytes(a, width * height, rec["steps"]) / rec["steps"] / (kms * 1e-3) / 1e9 / PEAK_HBM_GBPS if kms else None,
+                     "image_crc32": f"{zlib.crc32(rec['host_img'].tobytes()):08x}", "image_mean": float(rec["host_img"].mean())}
+                r.update(extra or {})
+                also.append(r)
+                return r
+
+            r = time_workload(ctx, 1920, 1080, 128, "reference", "exact", 1, 1)
+            rr = sub("cbox_1080p_128spp_reference_order", r, "BASELINE configs[1] in RL_STREAM_REFERENCE_ORDER: rustlight's own stream assignment (one sampler per 16x16 block, "
+                     "src/integrators/mod.rs:420-435), the plugin / CLI default; two passes: k_stream_chain + k_path_fused")
+            reference_order_value = rr["value"]
+            ctx.close()
+            for tag, name, w, h, steps, what in (
+                    ("cbox_1080x1080_128spp", "cbox", 1080, 1080, 3, "BASELINE configs[1] on a square frame (no pixels looking past the box: V/sample 2.1 instead of 1.15)"),
+                    ("cbox_medium_1080p_128spp", "cbox_medium", 1920, 1080, 3, "BASELINE configs[4]: cbox + homogeneous medium sigma_s = 0.5"),
+                    ("living_room_standin_1080p_128spp", "living_room", 1920, 1080, 3, "BASELINE configs[2] stand-in: 508 k triangles, 6 BSDF types, BVH streamed from L2 / Infinity Cache")):
+                sd2, _ = build_scene(name, w, h)
+                t_build = time.perf_counter()
+                ctx2 = api.Context(api.Scene(sd2), device_index)
+                t_build = time.perf_counter() - t_build
+                r = time_workload(ctx2, w, h, 128, "per_sample", "exact", steps, 1)
+                sub(tag, r, what, {"context_build_s": round(t_build, 2), "triangles": int(sd2.n_triangles)})
+                ctx2.close()
+
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             from oracle import orc
@@ -251,10 +357,10 @@ def main():
         except Exception:
             rccl = None
         out = {"metric": "Msamples/s (paths/s) at 1080p x 128spp cbox", "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": workload, "spp_total": spp_total, "stream_mode": args.stream_mode, "numerics": args.numerics,
-                          "pipeline": "fused (k_path_fused)" if fused else "wavefront (raygen/extend/shade/shadow)",
+                          "pipeline": ("two passes: k_stream_chain + k_path_fused" if ms["ms_prepass"] > 0 else "fused (k_path_fused)") if fused else "wavefront (raygen/extend/shade/shadow)",
                           "parallelism": f"tile-shard x{world} + 1 RCCL reduce",
                           "timed_region": "rl_render_path + framebuffer reduce (N > 1) + framebuffer download to pinned host memory (SURVEY §8(d))",
                           "mean_vertices_per_sample": agg_all["vertices"] / max(1, agg_all["camera_samples"]),
@@ -263,6 +369,9 @@ def main():
                                "ranks": ranks, "image_crc32": f"{crc:08x}", "single_gpu_image_crc32": None if crc_single is None else f"{crc_single:08x}",
                                "crc_match": None if crc_single is None else crc_single == crc},
                "roofline": roofline, "cpu_baseline": cpu}
+        if also is not None:
+            out["reference_order_value"] = reference_order_value
+            out["also"] = also
         print(json.dumps(out))
         sys.stdout.flush()
     rd.barrier()

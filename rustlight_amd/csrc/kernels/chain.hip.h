@@ -15,7 +15,7 @@
 #pragma once
 
 #ifndef RL_CHAIN_WAVES
-#define RL_CHAIN_WAVES 4             // waves per SIMD asked for on LDS-staged scenes
+#define RL_CHAIN_WAVES 6             // waves per SIMD asked for on LDS-staged scenes (73 VGPRs; 4 / 6 / 8: 912 / 867 / 907 ms for the chains of cbox 1080p x 128 spp)
 #endif
 #ifndef RL_CHAIN_WAVES_STREAMING
 #define RL_CHAIN_WAVES_STREAMING 6

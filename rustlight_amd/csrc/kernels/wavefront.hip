@@ -539,7 +539,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             // sparse item sets (reference-order streams): one item per 2^item_shift lanes, all of them resident from the start
             const unsigned resident4 = (unsigned)cus * 4u * 256u;
             while (pl.item_shift < 6u && ((size_t)pl.n_items << (pl.item_shift + 1u)) <= resident4) pl.item_shift++;
-            if (getenv("RL_ITEM_SHIFT")) pl.item_shift = std::min(6u, (unsigned)atoi(getenv("RL_ITEM_SHIFT")));
+            if (!per_pixel && getenv("RL_ITEM_SHIFT")) pl.item_shift = std::min(6u, (unsigned)atoi(getenv("RL_ITEM_SHIFT")));
             if (pl.item_shift) P = std::max(256u, (unsigned)((((size_t)pl.n_items << pl.item_shift) + 255u) / 256u * 256u));
         }
         pl.P = P;

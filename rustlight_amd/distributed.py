@@ -11,7 +11,10 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(expected_world: int = 1, backend: str | None = None):
+def init_from_env(expected_world: int = 1, backend: str | None = None, device: "torch.device | None" = None, timeout_s: float = 600.0):
+    """Join the process group the launcher described (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).  `device` (backend "nccl"): the GPU this
+    rank renders on — the caller has already made it current (torch.cuda.set_device) and it is handed to the group as `device_id`, so RCCL
+    binds its communicator to that device eagerly instead of to whatever is current at the first collective."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -21,7 +24,12 @@ def init_from_env(expected_world: int = 1, backend: str | None = None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        import datetime
+
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s), **kw)
     return rank, world, local_rank
 
 
