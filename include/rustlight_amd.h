@@ -12,6 +12,19 @@
  *   - vectors are tightly packed f32 triples, matrices are column-major 4x4 f32 (cgmath);
  *   - colours are linear RGB f32 triples (src/structure.rs:105-110);
  *   - images are row-major, origin top-left, W*H*3 f32 (src/structure.rs:383-402).
+ *
+ * Environment variables read by the library.  None of them changes a result; they exist for the tests and for measurements
+ * and are NOT part of the drop-in surface:
+ *   RL_FORCE_STREAMING=1      rl_context_create: keep small scenes out of LDS (the kernels that stream the BVH from L2 / HBM on scenes the
+ *                             oracle finishes in seconds)
+ *   RL_ITEM_SHIFT=k           reference-order streams: one block chain per 2^k lanes (auto: 5 at 1080p)
+ *   RL_REF_SINGLE_PASS=1      reference-order streams through the persistent kernel in ONE pass (the form of rounds 1-2) instead of
+ *                             k_stream_chain + per-sample evaluation
+ *   RL_STATE_BUDGET_MB=n      bytes the recorded sampler states of the two-pass form may take (default 24 GB): small values force several chunks
+ *   RL_FUSED_DYNAMIC=0|1      persistent kernel: static tile order / work items from the atomic dispenser
+ *   RL_GENERIC_LIGHTS=1       do not specialise the NEE code for area-light-only scenes
+ *   RL_NO_EVENTS=1            no HIP events around the kernels (rl_render_stats.ms_* stay 0)
+ *   RL_MULTI_FORCE_HOST_MERGE=1, RL_MULTI_NO_FALLBACK=1, RL_MULTI_REDUCE_TIMEOUT_S=s    rl_multi_*: see rl_multi_describe
  */
 #ifndef RUSTLIGHT_AMD_H
 #define RUSTLIGHT_AMD_H
@@ -219,9 +232,10 @@ typedef struct rl_path_params {
      * association). 0 = auto, 1 = one lane per pixel. Does not change results. */
     uint32_t sample_split;
     /* rl_numerics: 0 = exact (default; every f32 operation as the reference performs it — the only mode the parity tests bless),
-     * 1 = fast (opt-in: FMA contraction, v_rcp / v_rsq + one Newton step instead of the IEEE divide / sqrt sequences, hardware
-     * transcendentals; the RNG sequence stays bit-exact, pixels agree with the exact mode within BASELINE.json's per-pixel L2
-     * tolerance, not bit for bit — DESIGN.md §2 "Tolerance mode"). */
+     * 1 = fast (opt-in: FMA contraction, a * v_rcp(b) / raw v_sqrt / v_rsq (1 ulp, no refinement step) instead of the IEEE divide / sqrt
+     * sequences, hardware sin / cos / exp2 / log2; the RNG sequence stays bit-exact, pixels agree with the exact mode within
+     * BASELINE.json's per-pixel L2 tolerance in the MEAN, not bit for bit and not for every pixel on glossy scenes — DESIGN.md §2
+     * "Tolerance mode"). */
     uint32_t numerics;
 } rl_path_params;
 
@@ -312,6 +326,14 @@ typedef struct rl_multi rl_multi;
 int rl_multi_create(const rl_scene* scene, const int* devices, int n_shards, rl_multi** out);
 void rl_multi_destroy(rl_multi* m);
 int rl_multi_info(const rl_multi* m, int* n_shards, int* n_comm_ranks, int* rccl_version);
+/* Diagnostics as one JSON object (NUL-terminated, `capacity` bytes available): shards, RCCL version, communicator ranks, how the framebuffers are
+ * merged ("ncclReduce(sum) onto device D" or "host sum (<why>)": when the communicator cannot be built or a reduce fails / exceeds
+ * RL_MULTI_REDUCE_TIMEOUT_S the shards are still rendered on their GPUs and their sums added on the host — same bits —, with a line on stderr;
+ * RL_MULTI_NO_FALLBACK=1 turns that into RL_ERR_HIP), and per device: name, CUs, shards, hipDeviceCanAccessPeer towards every other device; of the
+ * last render: wall ms of the merge step and kernel ms per shard. */
+int rl_multi_describe(const rl_multi* m, char* buf, size_t capacity);
+/* Device and counters of one shard of the last rl_multi_render_path call (per-GPU kernel time: stats->ms_other [+ ms_prepass]). */
+int rl_multi_shard_stats(const rl_multi* m, int shard, int* device, rl_render_stats* stats);
 /* Integrator::compute over all shards: params->shard_index / shard_count are set per GPU by the call; `out_rgb` is a HOST
  * buffer of W*H*3 f32 (the framebuffer download from the root GPU is part of the call); `stats` = sums over the shards
  * (render_ms, ms_other: maximum).  Blocking. */

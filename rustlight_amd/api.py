@@ -33,7 +33,7 @@ PUBLIC_SYMBOLS = [
     "rl_scene_set_environment", "rl_scene_set_environment_map", "rl_scene_build_emitters", "rl_scene_enable_ats", "rl_scene_load_pbrt", "rl_scene_load_mitsuba", "rl_scene_load",
     "rl_scene_image_size", "rl_scene_counts", "rl_sampler_seed", "rl_sampler_next_u64", "rl_sampler_next_f32",
     "rl_path_params_default", "rl_device_count", "rl_context_create", "rl_context_destroy", "rl_last_error", "rl_block_count",
-    "rl_generate_block_seeds", "rl_render_path", "rl_multi_create", "rl_multi_destroy", "rl_multi_info", "rl_multi_render_path", "rl_render_ao", "rl_render_direct", "rl_trace_batch", "rl_visible_batch", "rl_load_pfm", "rl_load_image", "rl_save_pfm", "rl_save_png", "rl_save_exr", "rl_save_image", "rl_build_info",
+    "rl_generate_block_seeds", "rl_render_path", "rl_multi_create", "rl_multi_destroy", "rl_multi_info", "rl_multi_describe", "rl_multi_shard_stats", "rl_multi_render_path", "rl_render_ao", "rl_render_direct", "rl_trace_batch", "rl_visible_batch", "rl_load_pfm", "rl_load_image", "rl_save_pfm", "rl_save_png", "rl_save_exr", "rl_save_image", "rl_build_info",
 ]
 
 
@@ -101,6 +101,8 @@ def lib():
     L.rl_multi_destroy.restype = None
     L.rl_multi_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.rl_multi_render_path.argtypes = [vp, C.POINTER(abi.PathParams), u64p, C.c_size_t, vp, C.POINTER(abi.RenderStats)]
+    L.rl_multi_describe.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.rl_multi_shard_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(abi.RenderStats)]
     L.rl_trace_batch.argtypes = [vp, C.c_size_t, f32p, f32p, f32p, f32p, f32p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rl_visible_batch.argtypes = [vp, C.c_size_t, f32p, f32p, C.POINTER(C.c_uint8)]
     for fn in (L.rl_save_pfm, L.rl_save_png, L.rl_save_exr, L.rl_save_image):
@@ -319,6 +321,9 @@ class Scene:
 
 def path_params(spp=1, min_depth=0, max_depth=None, rr_depth=0, strategy=STRATEGY_ALL, single_scattering=False,
                 stream_mode=STREAM_PER_SAMPLE, seed_variant=0, shard_index=0, shard_count=1, pool_slots=0, pipeline=0, sample_split=0, numerics=0) -> abi.PathParams:
+    """rl_path_params for the tests and bench.py.  NOTE the default stream mode: this helper defaults to the throughput decomposition
+    (STREAM_PER_SAMPLE), which most parity tests exercise; the plugin-level surfaces — rl_path_params_default, the C++ / Python
+    IntegratorPathTracing, the CLI — default to rustlight's own RL_STREAM_REFERENCE_ORDER."""
     p = abi.PathParams()
     lib().rl_path_params_default(C.byref(p))
     p.spp = spp
@@ -434,6 +439,19 @@ class MultiContext:
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         _check(lib().rl_multi_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return {"shards": a.value, "comm_ranks": b.value, "rccl_version": c.value}
+
+    def describe(self) -> dict:
+        """rl_multi_describe: devices, peer access matrix, how the framebuffers are merged, per-shard kernel ms of the last render."""
+        import json
+
+        buf = C.create_string_buffer(1 << 16)
+        _check(lib().rl_multi_describe(self.h, buf, len(buf)))
+        return json.loads(buf.value.decode())
+
+    def shard_stats(self, shard: int):
+        dev, st = C.c_int(), abi.RenderStats()
+        _check(lib().rl_multi_shard_stats(self.h, shard, C.byref(dev), C.byref(st)))
+        return dev.value, st.as_dict()
 
     def render(self, seeds: np.ndarray, params: abi.PathParams):
         seeds = np.ascontiguousarray(seeds, dtype=np.uint64)

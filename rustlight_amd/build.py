@@ -19,7 +19,11 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unus
 # no SLP vectorizer for the kernels: it turns 3-vector math into packed v_pk_{add,mul}_f32, which issue at half rate on gfx950
 # and cost register-pair moves (measured: k_path_fused 65.9 -> 62.5 ms, same bits)
 HIP_EXTRA = ["-fno-slp-vectorize", "-Wno-bitwise-instead-of-logical"]
-HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HIPCC = os.environ.get("HIPCC") or os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
+# where librccl / libamdhip64 live: ROCM_PATH, else next to the compiler (<rocm>/bin/hipcc -> <rocm>/lib)
+ROCM_LIB = os.path.join(os.environ.get("ROCM_PATH") or os.path.dirname(os.path.dirname(os.path.realpath(HIPCC))), "lib")
+if not os.path.isdir(ROCM_LIB):
+    ROCM_LIB = "/opt/rocm/lib"
 CXX = os.environ.get("CXX", "g++")
 
 
@@ -66,13 +70,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(run, jobs))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-o", LIB, *objs, "-lz", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-o", LIB, *objs, "-lz", "-L" + ROCM_LIB, "-lrccl", "-Wl,-rpath," + ROCM_LIB]
     subprocess.check_call(cmd)
     # the CLI (examples/cli.rs counterpart)
     cli = os.path.join(CSRC, "host", "cli.cpp")
     if os.path.exists(cli):
         subprocess.check_call([CXX, *COMMON, cli, "-o", BIN, "-L" + LIB_DIR, "-lrustlight_amd", "-Wl,-rpath,$ORIGIN",
-                               "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
+                               "-Wl,-rpath," + ROCM_LIB, "-L" + ROCM_LIB, "-lamdhip64"])
     return LIB
 
 

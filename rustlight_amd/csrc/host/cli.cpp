@@ -145,6 +145,15 @@ int main(int argc, char** argv) {
             img = av.compute(sampler, *scene); elapsed_ms = integrator.last_stats.render_ms;
         } else { img = integrator.compute(sampler, *scene); elapsed_ms = integrator.last_stats.render_ms; }
         std::fprintf(stderr, "INFO Elapsed Integrator: %.0f ms\n", elapsed_ms);
+        if (integrator.multi) {     // --gpus N: where the shards ran, how the framebuffers were merged, kernel ms per device
+            std::vector<char> buf(1 << 16);
+            if (rl_multi_describe(integrator.multi, buf.data(), buf.size()) == RL_OK) std::fprintf(stderr, "INFO Multi-GPU: %s\n", buf.data());
+            for (int g = 0; g < gpus; g++) {
+                int dev = -1; rl_render_stats st{};
+                if (rl_multi_shard_stats(integrator.multi, g, &dev, &st) == RL_OK)
+                    std::fprintf(stderr, "INFO shard %d on device %d: kernel %.2f ms (chain pass %.2f ms), %llu camera samples\n", g, dev, st.ms_other + st.ms_prepass, st.ms_prepass, (unsigned long long)st.camera_samples);
+            }
+        }
         std::fprintf(stderr, "INFO Save final image: %s\n", output.c_str());
         img.save("primal", output);
     } catch (const std::exception& e) {

@@ -149,10 +149,14 @@ int rl_scene_set_camera(rl_scene* scene, uint32_t width, uint32_t height, float 
 }
 
 int rl_scene_scale_image(rl_scene* scene, float s) {
-    if (!scene || !scene->has_camera || s == 0.0f) return RL_ERR_INVALID_ARGUMENT;
+    if (!scene || !scene->has_camera) return RL_ERR_INVALID_ARGUMENT;
+    // the scale is caller input: a negative, NaN or infinite value must be refused before it reaches the float -> unsigned conversion
+    // (undefined behaviour outside the target's range)
+    if (!(s > 0.0f) || !std::isfinite(s)) { rl_set_error("image scale must be a positive finite number"); return RL_ERR_INVALID_ARGUMENT; }
     // Camera::scale_image only rescales `img`; the matrices keep the original aspect (camera.rs:73-78)
-    const uint32_t w = (uint32_t)(s * (float)scene->width), h = (uint32_t)(s * (float)scene->height);
-    if (!(s > 0.0f) || w == 0 || h == 0) { rl_set_error("image scale leaves no pixels"); return RL_ERR_INVALID_ARGUMENT; }
+    const float fw = s * (float)scene->width, fh = s * (float)scene->height;
+    if (!(fw >= 1.0f) || !(fh >= 1.0f) || fw >= 4294967040.0f || fh >= 4294967040.0f) { rl_set_error("image scale leaves no pixels (or more than 2^32)"); return RL_ERR_INVALID_ARGUMENT; }
+    const uint32_t w = (uint32_t)fw, h = (uint32_t)fh;
     scene->width = w;
     scene->height = h;
     return RL_OK;

@@ -115,7 +115,7 @@ RL_DEV bool tri_test(const float4 q0, const float4 q1, const float4 q2, const fl
         const bool facing = !(dot(u0, n) < 0.0f) & !(dot(w0, n) < 0.0f);
         const float uu = dot(u0, u0), ww = dot(w0, w0);
 #if defined(RL_FAST_MATH)
-        accept = facing & (__builtin_amdgcn_sqrtf(uu) + __builtin_amdgcn_sqrtf(ww) <= det);     // tolerance build: the 1-ulp estimate decides everywhere
+        accept = facing & (det > 0.0f) & (__builtin_amdgcn_sqrtf(uu) + __builtin_amdgcn_sqrtf(ww) <= det);     // tolerance build: the 1-ulp estimate decides everywhere (det > 0: a degenerate triangle is rejected as the exact build's NaN barycentrics reject it)
 #else
 #if defined(RL_TRI_REFERENCE_FORM)
         const bool in_range = false; const float s = 0.0f;

@@ -752,7 +752,26 @@ def test_multi_context_rccl_reduce(built, cbox64, ctx_cbox):
         img, mst = mc.render(seeds, api.path_params(spp=4))
         np.testing.assert_array_equal(img, full)
         assert all(mst[k] == st[k] for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws"))
+        d = mc.describe()
+        assert d["shards"] == n and d["merge"].startswith("ncclReduce") and len(d["devices"]) == d["comm_ranks"] and len(d["last_render"]["kernel_ms"]) == n
+        assert all(dev["peer_access"][i] == 1 for i, dev in enumerate(d["devices"])) and d["devices"][0]["cus"] > 0
+        assert sum(mc.shard_stats(g)[1]["camera_samples"] for g in range(n)) == st["camera_samples"]
         mc.close()
+    # the merge step when RCCL is not available (communicator cannot be built / a reduce fails): per-device sums added on the host — same bits,
+    # reported in describe(); RL_MULTI_NO_FALLBACK turns it into an error instead
+    os.environ["RL_MULTI_FORCE_HOST_MERGE"] = "1"
+    try:
+        mc = api.MultiContext(scene, 3)
+        img, mst = mc.render(seeds, api.path_params(spp=4, stream_mode=api.STREAM_REFERENCE_ORDER))
+        ref, _ = ctx_cbox.render(seeds, api.path_params(spp=4, stream_mode=api.STREAM_REFERENCE_ORDER))
+        np.testing.assert_array_equal(img, ref)
+        assert mc.describe()["merge"].startswith("host sum") and mc.info()["comm_ranks"] == 0
+        mc.close()
+        os.environ["RL_MULTI_NO_FALLBACK"] = "1"
+        with pytest.raises(api.RustlightError):
+            api.MultiContext(scene, 2)
+    finally:
+        os.environ.pop("RL_MULTI_FORCE_HOST_MERGE", None); os.environ.pop("RL_MULTI_NO_FALLBACK", None)
 
 
 def test_bench_two_ranks_on_one_gpu(built):
@@ -817,3 +836,57 @@ def test_scene_from_pod_description_renders_the_same_image(built):
         b, sb = api.Context(api.Scene.from_desc(sd), 0).render(seeds, api.path_params(spp=3, max_depth=6))
         np.testing.assert_array_equal(a, b)
         assert sa["vertices"] == sb["vertices"] and sa["rng_draws"] == sb["rng_draws"]
+
+
+def _c_initializer(v):
+    """A ctypes value as a C99 initializer (nested structs / arrays; pointers are not used here)."""
+    import ctypes as C
+    if isinstance(v, C.Structure):
+        return "{" + ", ".join(f".{n} = {_c_initializer(getattr(v, n))}" for n, _ in v._fields_) + "}"
+    if isinstance(v, C.Array):
+        return "{" + ", ".join(_c_initializer(x) for x in v) + "}"
+    if isinstance(v, float):
+        return float(np.float32(v)).hex() + "f"
+    return str(int(v))
+
+
+def test_c99_consumer_renders_the_same_image(built, tmp_path):
+    """The drop-in boundary from plain C (gcc -std=c99 -pedantic, nothing but include/rustlight_amd.h + the shared library) — what a Rust FFI
+    caller does, minus Rust: rl_scene_create_from_desc -> rl_context_create -> rl_generate_block_seeds -> rl_render_path with the CLI's
+    default parameters (reference-order streams).  Image and counters equal the ctypes binding's and the oracle's, bit for bit."""
+    import subprocess
+    from rustlight_amd import abi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    W, H, spp, seed = 48, 32, 3, 11
+    sd = scenes.cbox(W, H)
+    lines = ["#include <stdint.h>", f"#define SCENE_WIDTH {W}", f"#define SCENE_HEIGHT {H}", f"#define SCENE_SPP {spp}", f"#define SCENE_SEED {seed}ull",
+             "#define SCENE_STREAM_MODE RL_STREAM_REFERENCE_ORDER", f"#define SCENE_N_MESHES {len(sd.meshes)}",
+             f"static const float scene_fov = {float(np.float32(sd.fov)).hex()}f;", f"static const int scene_fov_axis = {int(sd.fov_axis)};", f"static const int scene_flip = {int(sd.flip)};",
+             "static const float scene_to_world[16] = {" + ", ".join(float(x).hex() + "f" for x in np.asarray(sd.to_world, np.float32).ravel()) + "};"]
+    for i, m in enumerate(sd.meshes):
+        v, idx, n, uv, e = abi.mesh_arrays(m)
+        lines.append(f"static const float mesh{i}_v[] = {{" + ", ".join(float(x).hex() + "f" for x in v.ravel()) + "};")
+        lines.append(f"static const uint32_t mesh{i}_i[] = {{" + ", ".join(str(int(x)) for x in idx.ravel()) + "};")
+        if n is not None: lines.append(f"static const float mesh{i}_n[] = {{" + ", ".join(float(x).hex() + "f" for x in n.ravel()) + "};")
+        if uv is not None: lines.append(f"static const float mesh{i}_uv[] = {{" + ", ".join(float(x).hex() + "f" for x in uv.ravel()) + "};")
+    lines.append("static const rl_mesh_desc scene_meshes[SCENE_N_MESHES] = {")
+    for i, m in enumerate(sd.meshes):
+        v, idx, n, uv, e = abi.mesh_arrays(m)
+        em = "{0.0f, 0.0f, 0.0f}" if e is None else "{" + ", ".join(float(x).hex() + "f" for x in e) + "}"
+        lines.append(f"    {{.vertices = mesh{i}_v, .n_vertices = {v.shape[0]}, .indices = mesh{i}_i, .n_triangles = {idx.shape[0]}, .normals = {'mesh%d_n' % i if n is not None else '0'}, "
+                     f".uv = {'mesh%d_uv' % i if uv is not None else '0'}, .bsdf = {_c_initializer(abi.bsdf_desc(m.bsdf))}, .has_emission = {int(e is not None)}, .emission_rgb = {em}}},")
+    lines.append("};")
+    (tmp_path / "scene_data.h").write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "render_desc"
+    libdir = os.path.join(root, "rustlight_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-I", str(tmp_path),
+                           os.path.join(root, "tests", "c_consumer", "render_desc.c"), "-o", str(exe), "-L", libdir, "-lrustlight_amd", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe), str(tmp_path / "img.raw")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    img = np.fromfile(tmp_path / "img.raw", dtype=np.float32).reshape(H, W, 3)
+    counters = dict(zip(out.stdout.split()[0::2], (int(x) for x in out.stdout.split()[1::2])))
+    ref, st = api.Context(api.Scene(sd), 0).render(api.IndependentSampler(seed).block_seeds(W, H), api.path_params(spp=spp, stream_mode=api.STREAM_REFERENCE_ORDER))
+    np.testing.assert_array_equal(img, ref)
+    oimg, ost = orc.Scene(sd).render(master_seed=seed, spp=spp, stream_mode=0, eval_order=1)
+    np.testing.assert_array_equal(img, oimg)
+    assert all(counters[k] == st[k] == ost[k] for k in ("camera_samples", "vertices", "extension_rays", "rng_draws")) and counters["shadow_rays"] == st["shadow_rays"]
