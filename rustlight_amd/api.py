@@ -408,6 +408,18 @@ class Context:
                                     m.ctypes.data_as(C.POINTER(C.c_int32)), tr.ctypes.data_as(C.POINTER(C.c_int32))))
         return t, u, v, m, tr
 
+    def trace_fast(self, origins, directions):
+        """Test hook: closest hits through the tolerance build's traversal of a streaming scene (quantised BVH4): (t, mesh, tri, node trips per ray)."""
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        t = np.zeros(n, np.float32); m = np.zeros(n, np.int32); tr = np.zeros(n, np.int32); st = np.zeros(n, np.int32)
+        i32p = C.POINTER(C.c_int32)
+        fn = lib().rl_debug_trace_batch_fast
+        fn.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), i32p, i32p, i32p]
+        _check(fn(self.h, n, abi.fptr(o), abi.fptr(d), abi.fptr(t), m.ctypes.data_as(i32p), tr.ctypes.data_as(i32p), st.ctypes.data_as(i32p)))
+        return t, m, tr, st
+
     def visible(self, p0, p1):
         a = np.ascontiguousarray(p0, dtype=np.float32).reshape(-1, 3)
         b = np.ascontiguousarray(p1, dtype=np.float32).reshape(-1, 3)

@@ -21,6 +21,21 @@ struct alignas(16) BvhNode {
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 static const int32_t RL_CHILD_NONE = (int32_t)0x80000000;
 
+// ---- BVH4 node of the tolerance build (`numerics = fast`, scenes that stream their BVH): the SAME BVH2 collapsed two levels at a time
+// (host: build_bvh4) with the child boxes quantised to 8 bits per plane on the node's own grid — conservatively (a quantised box contains the
+// child box), so a traversal visits a superset of the leaves the BVH2 visits.  One 64-byte fetch decides four children: about half the node
+// trips — and half the vector-memory instructions, which is what bounds the streaming kernel — of the BVH2.
+// plane value = org[axis] + q * 2^(exp[axis] - 127);  qlo / qhi are stored [axis][child] so that one dword holds the four children's planes.
+struct alignas(16) Bvh4Node {
+    float org[3];
+    uint32_t exps;            // biased exponents of the x | y << 8 | z << 16 grid steps
+    uint32_t qlo[3];          // per axis: child 0..3 lower plane in byte 0..3
+    uint32_t qhi[3];
+    int32_t child[4];         // child encoding as in BvhNode; inner indices refer to the BVH4 node array; RL_CHILD_NONE = empty slot
+    uint32_t pad[2];
+};
+static_assert(sizeof(Bvh4Node) == 64, "Bvh4Node must be 64 bytes");
+
 // ---- triangle record in BVH leaf order: ray-independent terms of Mesh::intersection_tri
 //      (src/geometry.rs:358-410) are precomputed once on the host with the reference's f32 ops.
 struct alignas(16) TriRecord {
@@ -122,6 +137,10 @@ struct DeviceScene {
     int32_t root;            // child encoding of the root (inner 0, a leaf, or NONE for an empty scene)
     uint32_t n_nodes, n_prims;
     uint32_t stack_depth;    // max number of simultaneously pending far children (+1)
+    // tolerance build on streaming scenes: the BVH2 above collapsed into quantised BVH4 nodes (null / NONE when the scene is staged in LDS)
+    const Bvh4Node* nodes4;
+    int32_t root4;
+    uint32_t stack_depth4;
     // shading data
     const uint32_t* tri_indices;   // 3 per global triangle, already offset by vertex_base
     const float* positions;        // 3 per vertex

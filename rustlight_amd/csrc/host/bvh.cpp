@@ -10,6 +10,7 @@
 //
 // Output layout (device_types.h): inner nodes only, each carrying both child boxes; leaves are
 // folded into the parent's child slots; triangles are pre-transformed into 64-byte TriRecords.
+#include <cmath>
 #include <algorithm>
 #include <cstring>
 
@@ -159,6 +160,94 @@ void build_bvh(const rl_scene& scene, BvhBuild* out) {
         max_depth = std::max(max_depth, depth[i] + 1);
     }
     out->stack_depth = max_depth + 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// BVH4 of the tolerance build
+namespace {
+struct Child2 { int32_t code; float lo[3], hi[3]; };
+static void children_of(const BvhNode& nd, Child2* l, Child2* r) {
+    l->code = nd.left; r->code = nd.right;
+    l->lo[0] = nd.lmin[0]; l->lo[1] = nd.lmin[1]; l->lo[2] = nd.lmin[2]; l->hi[0] = nd.lmax0; l->hi[1] = nd.lmax12[0]; l->hi[2] = nd.lmax12[1];
+    r->lo[0] = nd.rmin01[0]; r->lo[1] = nd.rmin01[1]; r->lo[2] = nd.rmin2; r->hi[0] = nd.rmax[0]; r->hi[1] = nd.rmax[1]; r->hi[2] = nd.rmax[2];
+}
+static double area_of(const Child2& c) {
+    const double dx = (double)c.hi[0] - c.lo[0], dy = (double)c.hi[1] - c.lo[1], dz = (double)c.hi[2] - c.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+}  // namespace
+
+void build_bvh4(const BvhBuild& bvh, Bvh4Build* out) {
+    *out = Bvh4Build();
+    out->root = bvh.root;
+    if (bvh.root < 0) return;                    // empty scene or a single leaf: the leaf code is the root
+    // iterative collapse: work items = (BVH2 inner node, slot of the BVH4 node that stands for it, its depth)
+    struct Work { int32_t node2; int32_t node4; uint32_t depth; };
+    std::vector<Work> todo;
+    out->nodes.emplace_back();
+    todo.push_back({bvh.root, 0, 1});
+    out->root = 0;
+    uint32_t max_depth = 1;
+    while (!todo.empty()) {
+        const Work w = todo.back();
+        todo.pop_back();
+        max_depth = std::max(max_depth, w.depth);
+        Child2 ch[4];
+        int n = 2;
+        children_of(bvh.nodes[w.node2], &ch[0], &ch[1]);
+        while (n < 4) {
+            int best = -1;
+            double best_area = -1.0;
+            for (int k = 0; k < n; k++)
+                if (ch[k].code >= 0) { const double a = area_of(ch[k]); if (a > best_area) { best_area = a; best = k; } }
+            if (best < 0) break;
+            Child2 l, r;
+            children_of(bvh.nodes[ch[best].code], &l, &r);
+            for (int k = n; k > best + 1; k--) ch[k] = ch[k - 1];     // the two grandchildren take the child's place, in order
+            ch[best] = l; ch[best + 1] = r;
+            n++;
+        }
+        // the node's grid: origin = lower corner of the union, step = smallest power of two with 255 steps covering the extent
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k = 0; k < n; k++) for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], ch[k].lo[a]); hi[a] = std::max(hi[a], ch[k].hi[a]); }
+        Bvh4Node nd;
+        std::memset(&nd, 0, sizeof(nd));
+        uint32_t exps = 0;
+        double step[3];
+        for (int a = 0; a < 3; a++) {
+            if (!(lo[a] <= hi[a]) || !std::isfinite(lo[a]) || !std::isfinite(hi[a])) { lo[a] = -3.0e38f; hi[a] = 3.0e38f; }   // non-finite geometry: a box that is always entered
+            nd.org[a] = lo[a];
+            int e = 0;
+            const double ext = ((double)hi[a] - (double)lo[a]) * (1.0 + 1e-6) / 254.0;     // one step of slack for the conservative rounding below
+            if (ext > 0.0) { (void)std::frexp(ext, &e); } else e = -125;                    // ext <= 2^e
+            e = std::max(-125, std::min(127, e));
+            step[a] = std::ldexp(1.0, e);
+            exps |= (uint32_t)(e + 127) << (8 * a);
+        }
+        nd.exps = exps;
+        for (int k = 0; k < 4; k++) {
+            uint32_t ql[3] = {255, 255, 255}, qh[3] = {0, 0, 0};      // empty slot: an inverted box, never entered
+            nd.child[k] = RL_CHILD_NONE;
+            if (k < n) {
+                for (int a = 0; a < 3; a++) {
+                    double l = std::floor(((double)ch[k].lo[a] - (double)nd.org[a]) / step[a] - 1e-3);
+                    double h = std::ceil(((double)ch[k].hi[a] - (double)nd.org[a]) / step[a] + 1e-3);
+                    if (!(l == l)) l = 0.0;
+                    if (!(h == h)) h = 255.0;
+                    ql[a] = (uint32_t)std::max(0.0, std::min(255.0, l));
+                    qh[a] = (uint32_t)std::max(0.0, std::min(255.0, h));
+                }
+                if (ch[k].code >= 0) {
+                    nd.child[k] = (int32_t)out->nodes.size();
+                    out->nodes.emplace_back();
+                    todo.push_back({ch[k].code, nd.child[k], w.depth + 1});
+                } else nd.child[k] = ch[k].code;
+            }
+            for (int a = 0; a < 3; a++) { nd.qlo[a] |= ql[a] << (8 * k); nd.qhi[a] |= qh[a] << (8 * k); }
+        }
+        out->nodes[w.node4] = nd;
+    }
+    out->stack_depth = 3 * max_depth + 1;       // at most three pending siblings per level
 }
 
 }  // namespace rl

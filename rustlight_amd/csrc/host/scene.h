@@ -88,6 +88,10 @@ struct BvhBuild {
 };
 // BVHAccel::new (src/accel.rs:115-239): full-sweep SAH over all triangles, leaves of <= 2.
 void build_bvh(const rl_scene& scene, BvhBuild* out);
+// The tolerance build's BVH4 (device_types.h: Bvh4Node): the BVH2 of `bvh` collapsed — the child with the largest box is replaced by its own two
+// children until a node has four (or only leaves are left) — and its child boxes quantised conservatively.  Same leaves, same triangle order.
+struct Bvh4Build { std::vector<Bvh4Node> nodes; int32_t root = RL_CHILD_NONE; uint32_t stack_depth = 1; };
+void build_bvh4(const BvhBuild& bvh, Bvh4Build* out);
 
 // Flattened shading arrays (global vertex / index / cdf / material tables).
 struct FlatScene {

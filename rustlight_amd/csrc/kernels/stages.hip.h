@@ -192,7 +192,7 @@ RL_DEV void extend_slot(const DeviceScene& sc, const SceneRecs& recs, const Stac
     V3 o = primary ? mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]) : load3(ps, F_OX);
     V3 d = load3(ps, F_DX);
     Hit hit; hit.t = kF32Max; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
-    traverse<false>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
+    traverse<false>(recs, Stack::kBvh4 ? sc.root4 : sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
                     o, d, kEps, kF32Max, hit, stack);
     PF(F_T) = hit.t; PF(F_U) = hit.u; PF(F_V) = hit.v;
     PU(U_PRIM) = (unsigned)hit.prim;
@@ -210,7 +210,7 @@ RL_DEV bool shadow_visible(const DeviceScene& sc, const SceneRecs& recs, const S
     float te;
     if (!slab(mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]), p0, inv_d, kEps, tfar, &te))
         return false;   // root box missed => "occluded" (accel.rs:338-340)
-    return !traverse<true>(recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
+    return !traverse<true>(recs, Stack::kBvh4 ? sc.root4 : sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
                            p0, d, kEps, tfar, hit, stack);
 }
 template <class PS, class Stack>

@@ -161,6 +161,11 @@ template <bool LDS_ONLY>
 struct TravStackT {
     using NodeFetch = typename std::conditional<LDS_ONLY, NodeFetchLds, NodeFetchGlobal>::type;   // LDS-only stacks go with LDS-staged scenes
     static constexpr bool kLdsOnly = LDS_ONLY;
+#ifdef RL_FAST_MATH
+    static constexpr bool kBvh4 = !LDS_ONLY;       // tolerance build, streaming scenes: quantised BVH4 nodes (traverse4)
+#else
+    static constexpr bool kBvh4 = false;
+#endif
     static constexpr int kTriStride4 = LDS_ONLY ? kLdsTriStride4 : 4;                              // float4s between triangle records
     static constexpr int kNodeRefScale = LDS_ONLY ? 4 * kLdsNodeStride : 1;                        // inner-node reference = index x this (LDS: byte offset)
     static constexpr int lds_stride = 256;       // every traversal kernel runs 256-lane workgroups
@@ -247,9 +252,17 @@ struct NodeFetchGlobal {
 #define RL_VOTE_NUM 3      // streaming scenes: a node trip while (lanes with node / stack work) * DEN >= NUM * (lanes holding leaves)
 #define RL_VOTE_DEN 2
 #endif
+#ifndef RL_VOTE4_NUM
+#define RL_VOTE4_NUM 3     // BVH4 form of the vote (traverse4)
+#define RL_VOTE4_DEN 2
+#endif
+template <bool ANY_HIT, class Stack>
+RL_DEV bool traverse4(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3 o, V3 d, float tnear, float tfar, Hit& hit, const Stack& st);
+
 template <bool ANY_HIT, class Stack>
 RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3 o, V3 d, float tnear, float tfar,
                      Hit& hit, const Stack& st) {
+    if constexpr (Stack::kBvh4) return traverse4<ANY_HIT>(recs, root, root_lo, root_hi, o, d, tnear, tfar, hit, st);
     V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
     float dummy;
     int cur = root >= 0 ? root * Stack::kNodeRefScale : root;
@@ -344,6 +357,119 @@ RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3
     }
     if (!ANY_HIT && found) {   // barycentrics of the closest hit (see tri_test)
         const float4* q = recs.tris + Stack::kTriStride4 * hit.prim;
+        tri_uv(q[0], q[1], q[2], q[3], o, d, hit.t, &hit.u, &hit.v);
+    }
+    return found;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// traverse4 — the tolerance build's traversal of scenes that stream their BVH: quantised BVH4 nodes (device_types.h: Bvh4Node; host: build_bvh4).
+// The streaming kernel is bound by vector-memory INSTRUCTIONS (profiles/r02_vmem_calibration.jsonl: >= 17 cycles of the CU's address path per
+// wave64 load however few lanes are live), four per 64-byte record; a BVH4 node decides four children with one record, so a ray makes about half
+// the node trips.  The boxes are conservative (they contain the BVH2 boxes), so the leaves visited are a superset of the exact build's and the
+// closest hit is the same except where two candidates tie or a hit grazes a box face — differences `numerics = fast` is allowed.
+// Order: the (up to four) entered children are sorted by entry distance, the nearest is descended, the others are pushed farthest first with
+// their entry distances and re-checked against the closest hit when popped.  Trips are voted by the wave like in `traverse`.
+RL_DEV float ubyte_f(unsigned v, int k) { return (float)((v >> (8 * k)) & 0xffu); }     // v_cvt_f32_ubyteK
+template <bool ANY_HIT, class Stack>
+RL_DEV bool traverse4(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3 o, V3 d, float tnear, float tfar, Hit& hit, const Stack& st) {
+    const V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
+    float dummy;
+    int cur = root;
+    if (!slab(root_lo, root_hi, o, inv_d, tnear, tfar, &dummy)) cur = RL_CHILD_NONE;
+    int sp = 0;
+    bool found = false;
+    constexpr int kPop = -1;
+    const bool sx = inv_d.x < 0.0f, sy = inv_d.y < 0.0f, sz = inv_d.z < 0.0f;
+    auto node_trip = [&]() {
+        if (cur >= 0) {
+            hit.steps++;
+            uint4 q0, q1, q2; uint2 q3;
+            const int cur0 = __builtin_amdgcn_readfirstlane(cur);
+            if (RL_UNIFORM_TRIPS && __ballot(cur != cur0) == 0ull) {      // every lane holds the same node: through the scalar cache
+                typedef unsigned u4v __attribute__((ext_vector_type(4)));
+                typedef const u4v __attribute__((address_space(4))) U4c;
+                const U4c* q = (const U4c*)(recs.nodes) + 4 * cur0;
+                const u4v a = q[0], b = q[1], c = q[2], e = q[3];
+                q0 = make_uint4(a.x, a.y, a.z, a.w); q1 = make_uint4(b.x, b.y, b.z, b.w); q2 = make_uint4(c.x, c.y, c.z, c.w); q3 = make_uint2(e.x, e.y);
+            } else {
+                const uint4* q = reinterpret_cast<const uint4*>(recs.nodes) + 4 * cur;
+                q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = *reinterpret_cast<const uint2*>(q + 3);
+            }
+            // plane distance t = (org + q * step - o) * inv_d = A + q * B per axis
+            const float stx = __uint_as_float((q0.w & 0xffu) << 23), sty = __uint_as_float(((q0.w >> 8) & 0xffu) << 23), stz = __uint_as_float(((q0.w >> 16) & 0xffu) << 23);
+            const float Ax = (__uint_as_float(q0.x) - o.x) * inv_d.x, Ay = (__uint_as_float(q0.y) - o.y) * inv_d.y, Az = (__uint_as_float(q0.z) - o.z) * inv_d.z;
+            const float Bx = stx * inv_d.x, By = sty * inv_d.y, Bz = stz * inv_d.z;
+            // qlo = (q1.x, q1.y, q1.z), qhi = (q1.w, q2.x, q2.y); the sign of 1/d picks the near / far plane set once per axis
+            const unsigned nx = sx ? q1.w : q1.x, fx = sx ? q1.x : q1.w, ny = sy ? q2.x : q1.y, fy = sy ? q1.y : q2.x, nz = sz ? q2.y : q1.z, fz = sz ? q1.z : q2.y;
+            const int ids[4] = {(int)q2.z, (int)q2.w, (int)q3.x, (int)q3.y};
+            float dist[4]; int code[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(Ax + ubyte_f(nx, k) * Bx, Ay + ubyte_f(ny, k) * By), Az + ubyte_f(nz, k) * Bz), tnear);
+                const float tf = __builtin_fminf(__builtin_fminf(__builtin_fminf(Ax + ubyte_f(fx, k) * Bx, Ay + ubyte_f(fy, k) * By), Az + ubyte_f(fz, k) * Bz), hit.t);
+                const bool in = !(tf <= tn) & (ids[k] != RL_CHILD_NONE);
+                dist[k] = in ? tn : f32_inf();
+                code[k] = ids[k];
+            }
+            // sort the four (distance, child) pairs, nearest first (5 compare-exchanges; missed children carry +inf)
+#define RL_CE(i, j) { const bool sw = dist[j] < dist[i]; const float td = sw ? dist[j] : dist[i]; dist[j] = sw ? dist[i] : dist[j]; dist[i] = td; \
+                      const int tc = sw ? code[j] : code[i]; code[j] = sw ? code[i] : code[j]; code[i] = tc; }
+#if defined(RL_BVH4_NOSORT)
+            RL_CE(0, 1) RL_CE(0, 2) RL_CE(0, 3)      // experiment: only the nearest child is found, the others are pushed in slot order
+#else
+            RL_CE(0, 1) RL_CE(2, 3) RL_CE(0, 2) RL_CE(1, 3) RL_CE(1, 2)
+#endif
+#undef RL_CE
+            // farthest first onto the stack, so that the nearest pending child is popped first
+            if (dist[3] < f32_inf()) { st.push(sp, code[3], dist[3]); sp++; }
+            if (dist[2] < f32_inf()) { st.push(sp, code[2], dist[2]); sp++; }
+            if (dist[1] < f32_inf()) { st.push(sp, code[1], dist[1]); sp++; }
+            cur = dist[0] < f32_inf() ? code[0] : kPop;
+        }
+        if (cur == kPop) {
+            cur = RL_CHILD_NONE;
+            if (sp > 0) {
+                sp--;
+                int c; float dd;
+                st.get(sp, &c, &dd);
+                cur = dd < hit.t ? c : kPop;
+            }
+        }
+    };
+    auto leaf_visit = [&]() -> bool {
+        const unsigned int code = (unsigned int)(~cur);
+        const int first = (int)(code >> 2), count = (int)(code & 3u);
+        const bool uni = RL_UNIFORM_TRIPS && __ballot(cur != __builtin_amdgcn_readfirstlane(cur)) == 0ull;
+        for (int k = 0; k < count; k++) {
+            hit.tris++;
+            float4 q0, q1, q2, q3;
+            if (uni) {
+                const F4c* q = (const F4c*)(recs.tris) + 4 * (__builtin_amdgcn_readfirstlane(first) + k);
+                const f4v a = q[0], b = q[1], c = q[2], e = q[3];
+                q0 = make_float4(a.x, a.y, a.z, a.w); q1 = make_float4(b.x, b.y, b.z, b.w); q2 = make_float4(c.x, c.y, c.z, c.w); q3 = make_float4(e.x, e.y, e.z, e.w);
+            } else {
+                const float4* q = recs.tris + 4 * (first + k);
+                q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+            }
+            if (tri_test(q0, q1, q2, q3, o, d, hit, first + k)) {
+                found = true;
+                if (ANY_HIT) return true;
+            }
+        }
+        cur = kPop;
+        return false;
+    };
+    for (;;) {
+        const bool in_node = cur >= 0 || cur == kPop;
+        const bool in_leaf = !in_node && cur != RL_CHILD_NONE;
+        const int n_node = __popcll(__ballot(in_node)), n_leaf = __popcll(__ballot(in_leaf));
+        if (n_node + n_leaf == 0) break;
+        if (n_node > 0 && n_node * RL_VOTE4_DEN >= RL_VOTE4_NUM * n_leaf) { if (in_node) node_trip(); }
+        else if (in_leaf && leaf_visit()) return true;
+    }
+    if (!ANY_HIT && found) {
+        const float4* q = recs.tris + 4 * hit.prim;
         tri_uv(q[0], q[1], q[2], q[3], o, d, hit.t, &hit.u, &hit.v);
     }
     return found;

@@ -324,6 +324,7 @@ extern "C" int rl_context_create(const rl_scene* scene, int device, rl_context**
         ds.n_nodes = (uint32_t)bvh.nodes.size();
         ds.n_prims = (uint32_t)bvh.tris.size();
         ds.stack_depth = bvh.stack_depth;
+        ds.nodes4 = nullptr; ds.root4 = RL_CHILD_NONE; ds.stack_depth4 = 0;
         if ((rc = upload(ctx, flat.tri_indices, &ds.tri_indices)) != RL_OK) break;
         if ((rc = upload(ctx, flat.positions, &ds.positions)) != RL_OK) break;
         if ((rc = upload(ctx, flat.normals, &ds.normals)) != RL_OK) break;
@@ -390,6 +391,13 @@ extern "C" int rl_context_create(const rl_scene* scene, int device, rl_context**
             if (worst > (size_t)lds_limit) ctx->lds_scene = false;
         }
         if (getenv("RL_FORCE_STREAMING")) ctx->lds_scene = false;     // dev / test knob: small scenes through the kernels that stream the BVH (tests/parity_fuzz.py)
+        if (!ctx->lds_scene) {
+            // scenes that stream their BVH: the tolerance build (`numerics = fast`) traverses the same tree collapsed into quantised BVH4 nodes
+            Bvh4Build b4;
+            build_bvh4(bvh, &b4);
+            if ((rc = upload(ctx, b4.nodes, &ds.nodes4)) != RL_OK) break;
+            ds.root4 = b4.root; ds.stack_depth4 = b4.stack_depth;
+        }
         if (hipMalloc((void**)&ctx->d_counters, sizeof(Counters)) != hipSuccess) { rl_set_error("hipMalloc counters"); rc = RL_ERR_HIP; break; }
         if (hipHostMalloc((void**)&ctx->h_counters, sizeof(Counters)) != hipSuccess) { rl_set_error("hipHostMalloc counters"); rc = RL_ERR_HIP; break; }
     } while (0);
@@ -439,7 +447,7 @@ static int stack_conf(rl_context* ctx, size_t n_threads, StackConf* out) {
     out->lds_levels = lds_levels_of(ctx);
     out->overflow = nullptr;
     out->overflow_stride = n_threads;
-    int extra = (int)ctx->ds.stack_depth - out->lds_levels;
+    int extra = (int)std::max(ctx->ds.stack_depth, ctx->ds.stack_depth4) - out->lds_levels;     // (the tolerance build's BVH4 stacks are the deeper ones)
     if (extra > 0) {
         size_t need = (size_t)2 * extra * n_threads;
         if (ctx->overflow_capacity < need) {
@@ -957,6 +965,26 @@ extern "C" int rl_debug_numerics(int device, size_t n, const float* a, const flo
     HIP_OK(hipGetLastError());
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemcpy(out8, d_out, 10 * n * 4, hipMemcpyDeviceToHost));
+    return RL_OK;
+}
+
+extern "C" int rl_debug_trace_batch_fast(rl_context* ctx, size_t n, const float* origins, const float* directions, float* t_out, int32_t* mesh_out, int32_t* tri_out, int32_t* steps_out) {
+    if (!ctx || !n || !origins || !directions || !t_out || !mesh_out || !tri_out || !steps_out) return RL_ERR_INVALID_ARGUMENT;
+    if (!ctx->ds.nodes4) { rl_set_error("the scene is staged in LDS: no BVH4"); return RL_ERR_UNSUPPORTED; }
+    if (n > kMaxBatch) { rl_set_error("batch too large"); return RL_ERR_INVALID_ARGUMENT; }
+    HIP_OK(hipSetDevice(ctx->device));
+    DevBuf b_o, b_d, b_t, b_m, b_tr, b_s;
+    HIP_OK(b_o.alloc(3 * n * 4)); HIP_OK(b_d.alloc(3 * n * 4)); HIP_OK(b_t.alloc(n * 4)); HIP_OK(b_m.alloc(n * 4)); HIP_OK(b_tr.alloc(n * 4)); HIP_OK(b_s.alloc(n * 4));
+    HIP_OK(hipMemcpy(b_o.as<float>(), origins, 3 * n * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(b_d.as<float>(), directions, 3 * n * 4, hipMemcpyHostToDevice));
+    StackConf stc;
+    { int r = stack_conf(ctx, (n + 255) / 256 * 256, &stc); if (r != RL_OK) return r; }
+    launch_trace_batch_fast(dim3((unsigned)((n + 255) / 256)), dim3(256), traversal_lds_bytes(ctx, false, 256, false), ctx->stream, ctx->ds, stc, (unsigned)n, b_o.as<float>(), b_d.as<float>(),
+                            b_t.as<float>(), b_m.as<int>(), b_tr.as<int>(), b_s.as<int>());
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    HIP_OK(hipMemcpy(t_out, b_t.as<float>(), n * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(mesh_out, b_m.as<int>(), n * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(tri_out, b_tr.as<int>(), n * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(steps_out, b_s.as<int>(), n * 4, hipMemcpyDeviceToHost));
     return RL_OK;
 }
 

@@ -75,6 +75,36 @@ def test_trace_batch_matches_oracle(built, maker):
     np.testing.assert_array_equal(got[0][:20000], brute[0])
 
 
+def test_bvh4_of_the_tolerance_build_finds_the_same_hits(built, monkeypatch):
+    """`numerics = fast` on scenes that stream their BVH traverses the same tree collapsed into quantised BVH4 nodes (build_bvh4 / traverse4:
+    conservative 8-bit child boxes, a superset of the leaves).  Ray by ray against the exact BVH2 traversal (which equals the oracle and the
+    brute-force loop, test_trace_batch_matches_oracle): same triangle for all but a handful of grazing rays, distances within 1e-5 relative
+    (the tolerance build's 1-ulp divide), never a hit lost or invented away from a silhouette — and about half the node trips."""
+    for maker, forced in ((lambda: scenes.living_room(64, 64, n_spheres=27, tess=12), False), (lambda: scenes.cbox(64, 64), True), (lambda: scenes.living_room(64, 64, n_spheres=64, tess=20), False)):
+        if forced: monkeypatch.setenv("RL_FORCE_STREAMING", "1")
+        else: monkeypatch.delenv("RL_FORCE_STREAMING", raising=False)
+        sd = maker()
+        ctx = api.Context(api.Scene(sd), 0)
+        assert not ctx.debug_sizes()["lds_scene"]
+        o, d = _random_rays(sd, 300000, 7)
+        if sd.n_triangles > 100:
+            o = o * 3.0
+            o[:, 1] += 4.0
+        t2, _, _, m2, tr2 = ctx.trace(o, d)
+        t4, m4, tr4, steps = ctx.trace_fast(o, d)
+        same = (m2 == m4) & (tr2 == tr4)
+        # a ray through a shared edge may take the neighbouring triangle (the tolerance build decides the barycentric verdict from 1-ulp square roots):
+        # same surface point, other primitive — counted as agreement when the distances agree
+        close = same | ((m2 >= 0) & (m4 >= 0) & (np.abs(t4 - t2) <= 1e-4 * np.maximum(1.0, np.abs(t2))))
+        assert same.mean() > 0.999 and close.mean() > 0.9998, (same.mean(), close.mean())
+        hit = (m2 >= 0) & same
+        assert hit.mean() > 0.3
+        assert np.abs(t4[hit] - t2[hit]).max() <= 2e-5 * np.abs(t2[hit]).max() + 1e-6
+        assert ((m2 >= 0) != (m4 >= 0)).mean() < 2e-4                       # hit / miss flips only on silhouettes
+        assert steps.mean() > 0.5
+    monkeypatch.delenv("RL_FORCE_STREAMING", raising=False)
+
+
 def _triangle_soup(seed=5, n=600):
     """Slivers, tiny and huge triangles at scattered positions: stresses the barycentric verdict of the triangle test (the device
     decides it from a 1-ulp sqrt estimate outside a 1e-5 band around u + v = 1 and recomputes u, v for the final hit only)."""
