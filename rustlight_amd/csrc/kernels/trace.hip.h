@@ -281,8 +281,24 @@ RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3
             hit.steps++;
             NodePlanes p;
             const int cur0 = __builtin_amdgcn_readfirstlane(cur);
+#if RL_UNIFORM_TRIPS >= 2
+            // experiment: trips on which the live lanes hold exactly TWO nodes fetch both through the scalar cache and select per lane
+            const unsigned long long other = Stack::NodeFetch::kHasUniform ? __ballot(cur != cur0) : ~0ull;
+            if (Stack::NodeFetch::kHasUniform && other == 0ull) p = fetch.uniform(cur0);
+            else if (Stack::NodeFetch::kHasUniform) {
+                const int cur1 = __builtin_amdgcn_readlane(cur, (int)__builtin_ctzll(other));
+                if (__ballot((cur != cur0) & (cur != cur1)) == 0ull) {
+                    const NodePlanes a = fetch.uniform(cur0), b = fetch.uniform(cur1);
+                    const bool f = cur == cur0;
+                    p.lnx = f ? a.lnx : b.lnx; p.lny = f ? a.lny : b.lny; p.lnz = f ? a.lnz : b.lnz; p.lfx = f ? a.lfx : b.lfx; p.lfy = f ? a.lfy : b.lfy; p.lfz = f ? a.lfz : b.lfz;
+                    p.rnx = f ? a.rnx : b.rnx; p.rny = f ? a.rny : b.rny; p.rnz = f ? a.rnz : b.rnz; p.rfx = f ? a.rfx : b.rfx; p.rfy = f ? a.rfy : b.rfy; p.rfz = f ? a.rfz : b.rfz;
+                    p.id1 = f ? a.id1 : b.id1; p.id2 = f ? a.id2 : b.id2;
+                } else p = fetch(cur);
+            } else p = fetch(cur);
+#else
             if (Stack::NodeFetch::kHasUniform && RL_UNIFORM_TRIPS && __ballot(cur != cur0) == 0ull) p = fetch.uniform(cur0);
             else p = fetch(cur);
+#endif
             const float d1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((p.lnx - o.x) * inv_d.x, (p.lny - o.y) * inv_d.y), (p.lnz - o.z) * inv_d.z), tnear);
             const float f1 = __builtin_fminf(__builtin_fminf(__builtin_fminf((p.lfx - o.x) * inv_d.x, (p.lfy - o.y) * inv_d.y), (p.lfz - o.z) * inv_d.z), hit.t);
             const float d2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((p.rnx - o.x) * inv_d.x, (p.rny - o.y) * inv_d.y), (p.rnz - o.z) * inv_d.z), tnear);

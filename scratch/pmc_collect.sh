@@ -12,7 +12,7 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_V
            "SQ_INSTS_FLAT SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_VMEM SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_LEVEL_LDS" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "GRBM_GUI_ACTIVE GRBM_COUNT" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 900 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/p$i -o p -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $O/p$i.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/p$i -o p -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-also "$@" > $O/p$i.log 2>&1
 done
 python $R/scratch/pmc_summary.py $O "$KF" "$@" > $O/pmc_summary.json
 cat $O/pmc_summary.json | head -c 3000
