@@ -23,6 +23,15 @@
 
 namespace rl {
 
+#ifdef RL_STAGE_TIMERS
+__device__ unsigned long long g_chain_timers[8];      // dev-only: cycles in raygen / extend / shade, wave-iterations, lane-iterations of each
+#define RL_CT0 { ct0 = __builtin_readcyclecounter(); }
+#define RL_CT1(K, COND) { const unsigned long long t1 = __builtin_readcyclecounter(); ctm[K] += t1 - ct0; cln[K] += __popcll(__ballot(COND)); ct0 = t1; }
+#else
+#define RL_CT0
+#define RL_CT1(K, COND)
+#endif
+
 template <int MAT, bool MEDIUM, bool LDS_SCENE, int NUM>
 __global__ void __launch_bounds__(256, LDS_SCENE ? RL_CHAIN_WAVES : RL_CHAIN_WAVES_STREAMING) k_stream_chain(RenderConst rc_arg, DeviceScene sc_arg, StackConf stc) {
     const DeviceScene& sc0 = sc_arg;
@@ -53,20 +62,94 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_CHAIN_WAVES : RL_CHAIN_WAV
     PU(U_PRIM) = 0xffffffffu;
     PU(U_FLAGS) = item0 < rc_arg.n_items ? (ST_REGEN | ST_FRESH) : ST_FINISHED;
     unsigned dummy = 0;
-    while (!(PU(U_FLAGS) & ST_FINISHED)) {
-        // scene record and render constants re-read from the kernarg segment once per iteration (see k_path_fused: SGPR pressure)
-        const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(ka));
-        constexpr size_t sc_off = (sizeof(RenderConst) + alignof(DeviceScene) - 1) / alignof(DeviceScene) * alignof(DeviceScene);
-        static_assert(sc_off == offsetof(PathKernargs, sc), "kernarg layout of k_stream_chain");
-        const DeviceScene& sc = *(const DeviceScene*)(ka + sc_off);
+#ifdef RL_STAGE_TIMERS
+    unsigned long long ctm[3] = {0, 0, 0}, cln[3] = {0, 0, 0}, ct0, n_it = 0;
+#endif
+    // scene record and render constants re-read from the kernarg segment once per iteration (see k_path_fused: SGPR pressure)
+#define RL_CHAIN_KERNARGS \
+        const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr(); \
+        asm volatile("" : "+s"(ka)); \
+        constexpr size_t sc_off = (sizeof(RenderConst) + alignof(DeviceScene) - 1) / alignof(DeviceScene) * alignof(DeviceScene); \
+        static_assert(sc_off == offsetof(PathKernargs, sc), "kernarg layout of k_stream_chain"); \
+        const DeviceScene& sc = *(const DeviceScene*)(ka + sc_off); \
         const RenderConst& rc = *(const RenderConst*)ka;
+    if (LDS_SCENE && stc.pre_group > 0) {
+        // Tiny scenes: the idle lanes of a chain's group evaluate its ray against every node and triangle at once, the chain lane walks the records
+        // (trace.hip.h: precompute_records / traverse_pre).  Every lane of the wave stays in the loop until the wave's chains are done.
+        const unsigned group = (unsigned)stc.pre_group, lane = threadIdx.x & 63u, sub = lane & (group - 1u), lead = lane & ~(group - 1u);
+        const unsigned slot = threadIdx.x / group;
+        float4* pre_nodes = reinterpret_cast<float4*>(reinterpret_cast<unsigned*>(after_scene) + 2 * 256 * stc.lds_levels) + (size_t)slot * (2u * sc0.n_nodes);
+        float2* pre_tris = reinterpret_cast<float2*>(reinterpret_cast<float4*>(reinterpret_cast<unsigned*>(after_scene) + 2 * 256 * stc.lds_levels) + (size_t)(256u / group) * (2u * sc0.n_nodes)) + (size_t)slot * sc0.n_prims;
+        while (__ballot(!(PU(U_FLAGS) & ST_FINISHED)) != 0ull) {
+            RL_CHAIN_KERNARGS
+#ifdef RL_STAGE_TIMERS
+            n_it++;
+            const bool c0 = PU(U_FLAGS) & ST_REGEN;
+#endif
+            RL_CT0
+            if (PU(U_FLAGS) & ST_REGEN) raygen_chain_slot(rc, sc, ps);
+            RL_CT1(0, c0)
+            const unsigned flags = PU(U_FLAGS);
+            const bool has_ray = (flags & ST_RAY) != 0u;
+            if (__ballot(has_ray) != 0ull) {
+                const bool primary = ((flags >> ST_PREV_SHIFT) & 3u) == PREV_SENSOR;
+                const V3 o = primary ? mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]) : load3(ps, F_OX);
+                const V3 d = load3(ps, F_DX);
+                const V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
+                // the group's ray, as its chain lane holds it
+                const bool g_ray = __shfl((int)has_ray, (int)lead, 64) != 0;
+                const V3 go = mk3(__shfl(o.x, (int)lead, 64), __shfl(o.y, (int)lead, 64), __shfl(o.z, (int)lead, 64));
+                const V3 gd = mk3(__shfl(d.x, (int)lead, 64), __shfl(d.y, (int)lead, 64), __shfl(d.z, (int)lead, 64));
+                const V3 gi = mk3(__shfl(inv_d.x, (int)lead, 64), __shfl(inv_d.y, (int)lead, 64), __shfl(inv_d.z, (int)lead, 64));
+                precompute_records(recs, sc0.n_nodes, sc0.n_prims, go, gd, gi, kEps, g_ray, sub, group, pre_nodes, pre_tris);
+                if (has_ray) {
+                    Hit hit; hit.t = kF32Max; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
+                    traverse_pre(pre_nodes, pre_tris, recs, sc.root, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
+                                 o, d, inv_d, kEps, kF32Max, hit, stack);
+                    PF(F_T) = hit.t; PF(F_U) = hit.u; PF(F_V) = hit.v;
+                    PU(U_PRIM) = (unsigned)hit.prim;
+                }
+                RL_CT1(1, has_ray)
+                if (has_ray) shade_slot<MAT, MEDIUM, LIGHTS_AREA_ONLY, true>(rc, sc, ps, flags, dummy, dummy, dummy, dummy);
+                RL_CT1(2, has_ray)
+            }
+        }
+    } else
+    while (!(PU(U_FLAGS) & ST_FINISHED)) {
+        RL_CHAIN_KERNARGS
+#ifdef RL_STAGE_TIMERS
+        n_it++;
+        const bool c0 = PU(U_FLAGS) & ST_REGEN;
+#endif
+        RL_CT0
         if (PU(U_FLAGS) & ST_REGEN) raygen_chain_slot(rc, sc, ps);
+        RL_CT1(0, c0)
+#ifdef RL_STAGE_TIMERS
+        const bool c1 = PU(U_FLAGS) & ST_RAY;
+#endif
         if (PU(U_FLAGS) & ST_RAY) {
             extend_slot(sc, recs, stack, ps);
+            RL_CT1(1, c1)
             shade_slot<MAT, MEDIUM, LIGHTS_AREA_ONLY, true>(rc, sc, ps, PU(U_FLAGS), dummy, dummy, dummy, dummy);
+            RL_CT1(2, c1)
         }
     }
+#undef RL_CHAIN_KERNARGS
+#ifdef RL_STAGE_TIMERS
+    if ((threadIdx.x & 63u) == 0u) { for (int k = 0; k < 3; k++) { atomicAdd(&g_chain_timers[k], ctm[k]); atomicAdd(&g_chain_timers[3 + k], cln[k]); } atomicAdd(&g_chain_timers[6], n_it); }
+#endif
+}
+
+template <bool LDS_SCENE>
+static void dump_chain_timers_impl() {
+#ifdef RL_STAGE_TIMERS
+    unsigned long long h[8];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_chain_timers), sizeof(h));
+    const double tot = (double)(h[0] + h[1] + h[2]);
+    const char* names[3] = {"raygen", "extend", "shade"};
+    if (tot > 0) for (int k = 0; k < 3; k++) std::fprintf(stderr, "[chain] %-7s cycles %5.1f %%  (%.0f cycles per wave-iteration, %.2f lanes)\n", names[k], 100.0 * h[k] / tot, (double)h[k] / (double)h[6], (double)h[3 + k] / (double)h[6]);
+    std::memset(h, 0, sizeof(h)); hipMemcpyToSymbol(HIP_SYMBOL(g_chain_timers), h, sizeof(h));
+#endif
 }
 
 template <bool LDS_SCENE, int MAT>

@@ -29,5 +29,7 @@ void launch_shade_sorted(bool medium, unsigned chunks, dim3 grid, dim3 block, hi
 void launch_pixel_mc(int kind, bool lds_scene, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc, const McConst& mp);
 void dump_stage_timers(bool lds_scene);   // dev-only (-DRL_STAGE_TIMERS)
 void dump_stage_timers_stream();
+void dump_chain_timers_lds();      // dev-only (-DRL_STAGE_TIMERS): cycle shares of k_stream_chain's stages
+void dump_chain_timers_stream();
 
 }  // namespace rl

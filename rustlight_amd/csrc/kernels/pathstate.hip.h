@@ -60,7 +60,7 @@ struct Counters {
 static constexpr int kLdsStackLevels = 12;   // stack levels kept in LDS per lane
 static constexpr size_t kSampleBufBudget = (size_t)16 << 30;   // bytes of HBM the per-sample parking buffer may take
 // traversal stack configuration (see TravStack)
-struct StackConf { int lds_levels; int* overflow; size_t overflow_stride; };
+struct StackConf { int lds_levels; int* overflow; size_t overflow_stride; int pre_group; };   // pre_group: k_stream_chain on tiny LDS scenes — lanes per chain that precompute its ray's records (0: off; trace.hip.h: precompute_records)
 
 template <bool LDS_ONLY = false>
 RL_DEV TravStackT<LDS_ONLY> make_stack(const StackConf& sc_, unsigned* lds_after_list, size_t global_thread) {

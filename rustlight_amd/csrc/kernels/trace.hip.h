@@ -667,6 +667,133 @@ RL_DEV bool traverse_coop(const SceneRecs& recs, int root, V3 root_lo, V3 root_h
     return found;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Lane-parallel records + serial walk (k_stream_chain on tiny LDS-staged scenes, round 3).
+// A chain of the draw-count pass traces ONE ray at a time while the other lanes of its group (32 or 64) idle, and 2/3 of the pass is that ray's
+// traversal at one instruction per ~5 cycles.  Here the group first evaluates everything about the ray that does not depend on the traversal
+// state — for every node the entry distance and the unclipped exit distance of both child boxes, for every triangle the plane distance t and
+// the barycentric verdict — one record per lane, into LDS; the chain lane then walks the tree in the reference's order reading those records:
+// per node two compares against the current closest hit instead of two slab tests, per triangle one window compare instead of a triangle test.
+// Same visits, same order, same arithmetic on the same operands (the clip with hit.t is the outermost min of `traverse`'s expression, the
+// distance window the first conjunct of tri_test's) — same bits.
+RL_DEV bool tri_inside(const float4 q0, const float4 q1, const float4 q2, const float4 q3, V3 o, V3 d, float t) {
+    // the body of tri_test's `if (window)` — keep the two in step (tests: two-pass == single-pass == oracle)
+    const V3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z);
+    const V3 n = mk3(q0.w, q1.w, q2.w);
+    const float det = q3.x;
+    const V3 pv = (o + t * d) - v0;
+    const V3 u0 = cross(e1, pv);
+    const V3 w0 = cross(pv, e2);
+    const bool facing = !(dot(u0, n) < 0.0f) & !(dot(w0, n) < 0.0f);
+    const float uu = dot(u0, u0), ww = dot(w0, w0);
+#if defined(RL_FAST_MATH)
+    return facing & (det > 0.0f) & (__builtin_amdgcn_sqrtf(uu) + __builtin_amdgcn_sqrtf(ww) <= det);
+#else
+#if defined(RL_TRI_REFERENCE_FORM)
+    const bool in_range = false; const float s = 0.0f;
+#else
+    const float s = __builtin_amdgcn_sqrtf(uu) + __builtin_amdgcn_sqrtf(ww);
+    const bool in_range = __builtin_fminf(__builtin_fminf(uu, ww), det) >= 0x1p-100f;
+#endif
+    const bool sure_in = in_range & (s <= det * 0.99999f), sure_out = in_range & (s >= det * 1.00001f);
+    bool accept = facing & sure_in;
+    if (facing & !sure_in & !sure_out) {
+        const float v = div_rn(sqrt_rn(uu), det);
+        const float u = div_rn(sqrt_rn(ww), det);
+        accept = !(u < 0.0f || v < 0.0f || u > 1.0f || v > 1.0f) && (u + v <= 1.0f);
+    }
+    return accept;
+#endif
+}
+// `sub` = this lane's index inside its chain's group of `group` lanes; `active`: the group's chain carries a ray this iteration.
+// pre_nodes: 2 float4 per node (d1, f1, d2, f2 | id1, id2 as node indices / leaf codes); pre_tris: (t, inside ? 1 : 0) per triangle.
+RL_DEV void precompute_records(const SceneRecs& recs, unsigned n_nodes, unsigned n_tris, V3 o, V3 d, V3 inv_d, float tnear, bool active, unsigned sub, unsigned group,
+                               float4* pre_nodes, float2* pre_tris) {
+    for (unsigned base = 0; base < n_tris; base += group) {
+        const unsigned idx = base + sub;
+        if (active && idx < n_tris) {
+            const float4* q = recs.tris + kLdsTriStride4 * idx;
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            const V3 v0 = mk3(q0.x, q0.y, q0.z), n = mk3(q0.w, q1.w, q2.w);
+            const float denom = dot(d, n);
+            const float t = div_rn(-dot(o - v0, n), denom);
+            const bool in = tri_inside(q0, q1, q2, q3, o, d, t);
+            pre_tris[idx] = make_float2(t, in ? 1.0f : 0.0f);
+        }
+    }
+    const NodeFetchLds fetch(recs, inv_d);
+    for (unsigned base = 0; base < n_nodes; base += group) {
+        const unsigned idx = base + sub;
+        if (active && idx < n_nodes) {
+            const NodePlanes p = fetch((int)(idx * 4u * (unsigned)kLdsNodeStride));
+            const float d1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((p.lnx - o.x) * inv_d.x, (p.lny - o.y) * inv_d.y), (p.lnz - o.z) * inv_d.z), tnear);
+            const float f1 = __builtin_fminf(__builtin_fminf((p.lfx - o.x) * inv_d.x, (p.lfy - o.y) * inv_d.y), (p.lfz - o.z) * inv_d.z);
+            const float d2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((p.rnx - o.x) * inv_d.x, (p.rny - o.y) * inv_d.y), (p.rnz - o.z) * inv_d.z), tnear);
+            const float f2 = __builtin_fminf(__builtin_fminf((p.rfx - o.x) * inv_d.x, (p.rfy - o.y) * inv_d.y), (p.rfz - o.z) * inv_d.z);
+            const int id1 = p.id1 >= 0 ? p.id1 / (4 * kLdsNodeStride) : p.id1, id2 = p.id2 >= 0 ? p.id2 / (4 * kLdsNodeStride) : p.id2;     // staged references are byte offsets
+            pre_nodes[2u * idx] = make_float4(d1, f1, d2, f2);
+            pre_nodes[2u * idx + 1u] = make_float4(__int_as_float(id1), __int_as_float(id2), 0.0f, 0.0f);
+        }
+    }
+    // the records are read back by the chain lane of this wave: LDS operations of one wave execute in order, the compiler only has to keep them so
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Acceleration::trace over the precomputed records: `traverse<false>`'s LDS-scene loop with the fetch + slab / triangle arithmetic replaced by reads.
+template <class Stack>
+RL_DEV bool traverse_pre(const float4* pre_nodes, const float2* pre_tris, const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3 o, V3 d, V3 inv_d, float tnear, float tfar,
+                         Hit& hit, const Stack& st) {
+    float dummy;
+    int cur = root;
+    if (!slab(root_lo, root_hi, o, inv_d, tnear, tfar, &dummy)) cur = RL_CHILD_NONE;
+    int sp = 0;
+    bool found = false;
+    constexpr int kPop = -1;
+    while (cur != RL_CHILD_NONE) {
+        while (cur >= 0 || cur == kPop) {
+            if (cur >= 0) {
+                hit.steps++;
+                const float4 a = pre_nodes[2 * cur], b = pre_nodes[2 * cur + 1];
+                const float d1 = a.x, f1 = __builtin_fminf(a.y, hit.t), d2 = a.z, f2 = __builtin_fminf(a.w, hit.t);
+                const int id1 = __float_as_int(b.x), id2 = __float_as_int(b.y);
+                const bool v1 = !(f1 <= d1), v2 = !(f2 <= d2);
+                const bool right_first = v2 & (!v1 | (d1 > d2));
+                st.push(sp, right_first ? id1 : id2, right_first ? d1 : d2);
+                sp += (v1 && v2) ? 1 : 0;
+                cur = (v1 || v2) ? (right_first ? id2 : id1) : kPop;
+            }
+            if (cur == kPop) {
+                cur = RL_CHILD_NONE;
+                if (sp > 0) {
+                    sp--;
+                    int code; float dist;
+                    st.get(sp, &code, &dist);
+                    cur = dist < hit.t ? code : kPop;
+                }
+            }
+        }
+        if (cur != RL_CHILD_NONE) {
+            const unsigned int code = (unsigned int)(~cur);
+            const int first = (int)(code >> 2), count = (int)(code & 3u);
+            for (int k = 0; k < count; k++) {
+                hit.tris++;
+                const float2 r = pre_tris[first + k];
+                const bool accept = (r.x < hit.t) & (r.x > 0.00001f) & (r.y != 0.0f);
+                hit.t = accept ? r.x : hit.t;
+                hit.prim = accept ? first + k : hit.prim;
+                found = found | accept;
+            }
+            cur = kPop;
+        }
+    }
+    if (found) {
+        const float4* q = recs.tris + kLdsTriStride4 * hit.prim;
+        tri_uv(q[0], q[1], q[2], q[3], o, d, hit.t, &hit.u, &hit.v);
+    }
+    return found;
+}
+
 // Stage the node / triangle records into LDS (cooperatively) in the padded layout above; inner-child references become dword offsets.
 RL_DEV void stage_scene_lds(const DeviceScene& sc, float4* lds_nodes, float4* lds_tris) {
     const float* gn = reinterpret_cast<const float*>(sc.nodes);

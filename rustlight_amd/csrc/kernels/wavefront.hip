@@ -445,6 +445,7 @@ static size_t traversal_lds_bytes(const rl_context* ctx, bool lds_scene, unsigne
 // overflow levels beyond the LDS part, [2 * levels][n_threads] ints
 static int stack_conf(rl_context* ctx, size_t n_threads, StackConf* out) {
     out->lds_levels = lds_levels_of(ctx);
+    out->pre_group = 0;          // only k_stream_chain uses it (its launch code sets it)
     out->overflow = nullptr;
     out->overflow_stride = n_threads;
     int extra = (int)std::max(ctx->ds.stack_depth, ctx->ds.stack_depth4) - out->lds_levels;     // (the tolerance build's BVH4 stacks are the deeper ones)
@@ -694,7 +695,14 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         (ctx->lds_scene ? (fast_math ? launch_fused_lds_fast : launch_fused_lds) : (fast_math ? launch_fused_stream_fast : launch_fused_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, ctx->area_lights_only, grid, block, lds_fused, st, rcl, ds, stc);
     };
     if (two_pass) {
-        const size_t lds_chain = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false);
+        // tiny LDS-staged scenes (the Cornell box: 19 nodes + 32 triangles): the lanes of a chain's group precompute its ray's node / triangle records
+        // (trace.hip.h: precompute_records) — when a chain has at least 32 lanes to itself and the records fit a few passes
+        StackConf stc_c = stc;
+        // (not with a medium: most of its vertices are scattering events whose rays end in the volume, and the pass then costs more than it saves — cbox + medium,
+        // 1080p x 16 spp: 404 vs 353 ms; a variant with ONE chain per wave, the records left in registers and a wave-uniform v_readlane walk measured no better
+        // than the LDS records at the same chains per wave: 767.5 vs 768.1 ms, and 2 chains per wave beat both: 705 ms)
+        if (ctx->lds_scene && !medium && ctx->ds.n_nodes <= 64u && ctx->ds.n_prims <= 64u && plan_chain.item_shift >= 5u && !getenv("RL_CHAIN_NO_PRE")) stc_c.pre_group = 1 << plan_chain.item_shift;
+        const size_t lds_chain = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + (stc_c.pre_group ? (size_t)(256 / stc_c.pre_group) * ((size_t)ctx->ds.n_nodes * 32 + (size_t)ctx->ds.n_prims * 8) : 0);
         for (const Chunk& ch : chunks) {
             // ---- pass 1: the chains
             HIP_OK(hipMemcpyAsync(ctx->d_item_base, ch.base.data(), ch.base.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
@@ -704,7 +712,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             ra.n_state_pixels = ch.n_pix; ra.cursor_begin = ch.c0; ra.cursor_end = ch.c1;
             hipLaunchKernelGGL(k_chunk_pixels, dim3(((unsigned)owned.size() + 63) / 64), dim3(64), 0, st, ra);
             if (timing) hipEventRecord(ctx->events[0], st);
-            (ctx->lds_scene ? (fast_math ? launch_chain_lds_fast : launch_chain_lds) : (fast_math ? launch_chain_stream_fast : launch_chain_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, dim3((plan_chain.P + 255) / 256), block, lds_chain, st, ra, ds, stc);
+            (ctx->lds_scene ? (fast_math ? launch_chain_lds_fast : launch_chain_lds) : (fast_math ? launch_chain_stream_fast : launch_chain_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, dim3((plan_chain.P + 255) / 256), block, lds_chain, st, ra, ds, stc_c);
             if (timing) hipEventRecord(ctx->events[1], st);
             // ---- pass 2: every camera sample of the chunk from its recorded state, per-pixel work items
             const Plan pb = plan_items(true, ch.n_pix, 0);
@@ -729,6 +737,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             launches += 3 + (pb.split > 1 ? 1 : 0);
         }
         dump_stage_timers(ctx->lds_scene);
+        if (ctx->lds_scene) dump_chain_timers_lds(); else dump_chain_timers_stream();     // dev-only build
         iterations = chunks.size();
     } else if (fused) {
         if (timing) hipEventRecord(ctx->events[0], st);

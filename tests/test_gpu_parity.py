@@ -726,6 +726,19 @@ def test_reference_order_two_pass_equals_single_pass(built, monkeypatch):
         for split in (0, 3):
             img, st = ctx.render(api.IndependentSampler(3).block_seeds(sd.width, sd.height), api.path_params(stream_mode=ref_mode, sample_split=split, **kw))
             np.testing.assert_array_equal(img, two[0])
+    # tiny scenes: the chain pass precomputes its ray's node / triangle records on the idle lanes of the chain's group (32 or 64 lanes; 42 triangles need
+    # two passes of a 32-lane group, and the 36 of the Cornell box too) — against the plain one-lane traversal (RL_CHAIN_NO_PRE) and the oracle
+    for sd, kw in ((scenes.cbox(96, 80), dict(spp=6)), (scenes.many_lights(64, 48, n=3, use_ats=False), dict(spp=4, max_depth=6)), (scenes.cbox_other_lights(48, 48), dict(spp=3))):
+        ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+        assert ctx.debug_sizes()["lds_scene"] and sd.n_triangles <= 64
+        base = _render_pair(sd, ctx, osc, seed=9, stream_mode=ref_mode, **kw)
+        _assert_parity(*base)
+        for env in (dict(RL_ITEM_SHIFT="5"), dict(RL_ITEM_SHIFT="6"), dict(RL_CHAIN_NO_PRE="1"), dict(RL_ITEM_SHIFT="4")):
+            for k, v in env.items(): monkeypatch.setenv(k, v)
+            img, st = ctx.render(api.IndependentSampler(9).block_seeds(sd.width, sd.height), api.path_params(stream_mode=ref_mode, **kw))
+            for k in env: monkeypatch.delenv(k)
+            np.testing.assert_array_equal(img, base[0], err_msg=str(env))
+            assert all(st[k] == base[1][k] for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws"))
     # several chunks: 1 MB of states = a few block cursors per chunk on this frame (130 blocks x 24 spp x 32 B per cursor)
     sd = scenes.cbox(160, 200)
     ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
