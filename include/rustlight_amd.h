@@ -359,7 +359,8 @@ typedef struct rl_mc_params {
     uint32_t reserved[4];
 } rl_mc_params;
 
-/* Integrator::compute for IntegratorAO (src/integrators/ao.rs:9-70). Same output / sharding contract as rl_render_path. */
+/* Integrator::compute for IntegratorAO (src/integrators/ao.rs:9-70). Same output / sharding contract as rl_render_path.  In RL_STREAM_REFERENCE_ORDER both
+ * integrators run in two passes like `path` (stats->ms_prepass: the pass that records where every camera sample starts in its block's stream). */
 int rl_render_ao(rl_context* ctx, const rl_mc_params* params, const uint64_t* block_seeds, size_t n_blocks,
                  float* out_rgb, int out_is_device, void* stream, rl_render_stats* stats);
 /* Integrator::compute for IntegratorDirect (src/integrators/direct.rs:10-233): direct lighting with the power

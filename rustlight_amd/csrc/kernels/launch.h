@@ -27,6 +27,7 @@ void launch_trace_batch_fast(dim3 grid, dim3 block, size_t lds_bytes, hipStream_
 void launch_shade_type(int type, bool medium, dim3 grid, dim3 block, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const Pool& pool);
 void launch_shade_sorted(bool medium, unsigned chunks, dim3 grid, dim3 block, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const Pool& pool);
 void launch_pixel_mc(int kind, bool lds_scene, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc, const McConst& mp);
+void launch_mc_chain(int kind, bool lds_scene, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc, const McConst& mp);   // first pass of reference-order streams for ao / direct
 void dump_stage_timers(bool lds_scene);   // dev-only (-DRL_STAGE_TIMERS)
 void dump_stage_timers_stream();
 void dump_chain_timers_lds();      // dev-only (-DRL_STAGE_TIMERS): cycle shares of k_stream_chain's stages

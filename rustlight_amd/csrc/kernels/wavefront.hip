@@ -503,7 +503,11 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     // radiance half of the integrator left out and records the sampler state at the start of each camera sample, then the per-sample form of
     // k_path_fused evaluates all samples from those states with every lane busy.  Same image, same counters as the single-pass walk
     // (RL_REF_SINGLE_PASS=1 keeps that form: a test / measurement knob).
-    const bool two_pass = !per_sample && fused && !owned.empty() && !getenv("RL_REF_SINGLE_PASS");
+    bool two_pass = !per_sample && fused && !owned.empty() && !getenv("RL_REF_SINGLE_PASS");
+    // the recorded states of ONE cursor position of every owned block must fit the budget (spp beyond ~90 000 at 1080p do not): else the single-pass walk
+    size_t state_budget = (size_t)24 << 30;
+    if (getenv("RL_STATE_BUDGET_MB")) state_budget = std::max<size_t>(1, (size_t)atoll(getenv("RL_STATE_BUDGET_MB"))) << 20;   // test knob: forces several chunks
+    if (two_pass && (size_t)owned.size() * params->spp * 32 > state_budget) two_pass = false;
     int cus = 256;
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     // ---- how a set of work items is laid over the lanes.  per_pixel: pixel items (RL_STREAM_PER_SAMPLE, or the second pass of reference-order
@@ -559,8 +563,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     struct Chunk { unsigned c0, c1, n_pix; std::vector<unsigned> base; };
     std::vector<Chunk> chunks;
     if (two_pass) {
-        size_t budget = (size_t)24 << 30;
-        if (getenv("RL_STATE_BUDGET_MB")) budget = std::max<size_t>(1, (size_t)atoll(getenv("RL_STATE_BUDGET_MB"))) << 20;   // test knob: forces several chunks
+        const size_t budget = state_budget;
         const size_t per_cursor = (size_t)owned.size() * params->spp * 32;       // bytes of states one cursor position of every block takes (upper bound)
         const unsigned cursors_per_chunk = (unsigned)std::max<size_t>(1, std::min<size_t>(256, budget / std::max<size_t>(1, per_cursor)));
         for (unsigned c0 = 0; c0 < 256u; c0 += cursors_per_chunk) {
@@ -840,16 +843,32 @@ static int render_mc(rl_context* ctx, int kind, const rl_mc_params* params, cons
         n_pixels += std::min(16u, W - bx) * std::min(16u, H - by);
     }
     const bool per_sample = params->stream_mode == RL_STREAM_PER_SAMPLE;
-    const unsigned n_items = per_sample ? n_pixels : (unsigned)owned.size();
-    const unsigned n_threads = std::max(256u, (n_items + 255u) / 256u * 256u);
+    // reference-order streams in two passes, as for `path` (chain.hip.h): k_mc_chain records where every camera sample starts in its block's stream (a sample's
+    // draw count follows from its camera ray alone), then the per-pixel form evaluates all samples from those states.  One chunk: when the states do not fit
+    // their budget the single-pass walk (one lane per block) runs instead, as it does under RL_REF_SINGLE_PASS.
+    size_t state_budget = (size_t)24 << 30;
+    if (getenv("RL_STATE_BUDGET_MB")) state_budget = std::max<size_t>(1, (size_t)atoll(getenv("RL_STATE_BUDGET_MB"))) << 20;
+    const bool two_pass = !per_sample && !owned.empty() && !getenv("RL_REF_SINGLE_PASS") && (size_t)n_pixels * params->spp * 32 <= state_budget;
+    const bool per_pixel = per_sample || two_pass;
+    const unsigned n_items = per_pixel ? n_pixels : (unsigned)owned.size();
+    unsigned chain_shift = 0;
+    if (two_pass) {
+        int cus = 256;
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        while (chain_shift < 6u && (owned.size() << (chain_shift + 1u)) <= (size_t)cus * 4u * 256u) chain_shift++;
+        if (getenv("RL_ITEM_SHIFT")) chain_shift = std::min(6u, (unsigned)atoi(getenv("RL_ITEM_SHIFT")));
+    }
+    const unsigned chain_threads = two_pass ? std::max(256u, (unsigned)((((size_t)owned.size() << chain_shift) + 255u) / 256u * 256u)) : 0u;
+    const unsigned n_threads = std::max(chain_threads, std::max(256u, (n_items + 255u) / 256u * 256u));
     int rcode;
     if ((rcode = ensure(&ctx->d_owned, &ctx->owned_capacity, owned.size())) != RL_OK) return rcode;
     if ((rcode = ensure(&ctx->d_item_base, &ctx->item_base_capacity, owned.size())) != RL_OK) return rcode;
     if ((rcode = ensure(&ctx->d_block_seeds, &ctx->seeds_capacity, n_blocks)) != RL_OK) return rcode;
-    if (per_sample) {
+    if (per_pixel) {
         if ((rcode = ensure(&ctx->d_item_seed, &ctx->item_capacity, n_pixels)) != RL_OK) return rcode;
         if ((rcode = ensure(&ctx->d_item_pixel, &ctx->item_pixel_capacity, n_pixels)) != RL_OK) return rcode;
     }
+    if (two_pass && (rcode = ensure(&ctx->d_sample_states, &ctx->sample_states_capacity, (size_t)n_pixels * params->spp * 4)) != RL_OK) return rcode;
     float* d_out = out_rgb;
     if (!out_is_device) {
         if ((rcode = ensure(&ctx->d_out, &ctx->out_capacity, (size_t)3 * W * H)) != RL_OK) return rcode;
@@ -875,13 +894,26 @@ static int render_mc(rl_context* ctx, int kind, const rl_mc_params* params, cons
     rc.out = d_out;
     rc.counters = ctx->d_counters;
     rc.partials = ctx->d_partials;
+    rc.sample_states = ctx->d_sample_states; rc.n_state_pixels = n_pixels;
     McConst mp{params->has_max_distance, params->max_distance, params->normal_correction, params->nb_bsdf_samples, params->nb_light_samples};
     StackConf stc;
     if ((rcode = stack_conf(ctx, n_threads, &stc)) != RL_OK) return rcode;
     const size_t lds = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false);
-    const dim3 grid(n_threads / 256), block(256);
-    if (per_sample && !owned.empty()) hipLaunchKernelGGL(k_seed_pixels, dim3(((unsigned)owned.size() + 63) / 64), dim3(64), 0, st, rc);
+    const dim3 grid((std::max(256u, (n_items + 255u) / 256u * 256u)) / 256), block(256);
+    const bool timing = stats != nullptr && !getenv("RL_NO_EVENTS");
+    while (timing && ctx->events.size() < 4) { hipEvent_t ev; HIP_OK(hipEventCreate(&ev)); ctx->events.push_back(ev); }
+    if (per_pixel && !owned.empty()) hipLaunchKernelGGL(k_seed_pixels, dim3(((unsigned)owned.size() + 63) / 64), dim3(64), 0, st, rc);     // (two-pass: for item_pixel)
+    if (two_pass) {
+        RenderConst ra = rc;
+        ra.n_items = (unsigned)owned.size(); ra.item_shift = chain_shift;
+        if (timing) hipEventRecord(ctx->events[0], st);
+        launch_mc_chain(kind, ctx->lds_scene, dim3(chain_threads / 256), block, lds, st, ra, ctx->ds, stc, mp);
+        if (timing) hipEventRecord(ctx->events[1], st);
+        rc.stream_mode = kStreamGivenStates;
+    }
+    if (timing) hipEventRecord(ctx->events[2], st);
     launch_pixel_mc(kind, ctx->lds_scene, grid, block, lds, st, rc, ctx->ds, stc, mp);
+    if (timing) hipEventRecord(ctx->events[3], st);
     if (!out_is_device) HIP_OK(hipMemcpyAsync(out_rgb, d_out, (size_t)3 * W * H * sizeof(float), hipMemcpyDeviceToHost, st));
     std::vector<unsigned long long> partials(n_rows * STAT_COUNT);
     HIP_OK(hipMemcpyAsync(partials.data(), ctx->d_partials, partials.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -893,7 +925,13 @@ static int render_mc(rl_context* ctx, int kind, const rl_mc_params* params, cons
         for (size_t r = 0; r < n_rows; r++) for (int k = 0; k < STAT_COUNT; k++) totals[k] += partials[r * STAT_COUNT + k];
         stats->camera_samples = totals[STAT_SAMPLES]; stats->vertices = totals[STAT_VERTICES]; stats->extension_rays = totals[STAT_EXT_RAYS];
         stats->shadow_rays = totals[STAT_SHADOW_RAYS]; stats->rng_draws = totals[STAT_DRAWS];
-        stats->iterations = 1; stats->kernel_launches = per_sample ? 2 : 1;
+        stats->iterations = 1; stats->kernel_launches = per_sample ? 2 : (two_pass ? 3 : 1);
+        if (timing) {
+            float t = 0.0f;
+            if (hipEventElapsedTime(&t, ctx->events[2], ctx->events[3]) == hipSuccess) stats->ms_other = t;
+            if (two_pass && hipEventElapsedTime(&t, ctx->events[0], ctx->events[1]) == hipSuccess) stats->ms_prepass = t;
+            (void)hipGetLastError();
+        }
         stats->render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     }
     return RL_OK;

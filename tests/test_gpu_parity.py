@@ -351,6 +351,21 @@ def test_ao_and_direct_integrators_parity(built, mode):
             np.testing.assert_array_equal(img, ref)
             assert all(st[k] == ost[k] for k in ("camera_samples", "extension_rays", "shadow_rays", "rng_draws"))
             assert img.mean() > 0
+        if mode == api.STREAM_REFERENCE_ORDER:
+            # the mode runs in two passes (k_mc_chain records where each camera sample starts in its block's stream, the per-pixel form evaluates them);
+            # the single-pass walk (one lane per block) must give the same images
+            two_ao, sa = ctx.render_ao(seeds, spp=3, stream_mode=mode, max_distance=0.3, normal_correction=True)
+            two_di, sd2 = ctx.render_direct(seeds, spp=3, stream_mode=mode, nb_bsdf_samples=2, nb_light_samples=3)
+            assert sa["ms_prepass"] > 0.0 and sd2["ms_prepass"] > 0.0
+            os.environ["RL_REF_SINGLE_PASS"] = "1"
+            try:
+                one_ao, sb = ctx.render_ao(seeds, spp=3, stream_mode=mode, max_distance=0.3, normal_correction=True)
+                one_di, _ = ctx.render_direct(seeds, spp=3, stream_mode=mode, nb_bsdf_samples=2, nb_light_samples=3)
+            finally:
+                del os.environ["RL_REF_SINGLE_PASS"]
+            assert sb["ms_prepass"] == 0.0
+            np.testing.assert_array_equal(two_ao, one_ao)
+            np.testing.assert_array_equal(two_di, one_di)
 
 
 @pytest.mark.parametrize("fmt", ["obj", "serialized"])
@@ -749,7 +764,13 @@ def test_reference_order_two_pass_equals_single_pass(built, monkeypatch):
     assert st["iterations"] > 10                                                  # chunks
     np.testing.assert_array_equal(img, whole[0])
     assert all(st[k] == whole[1][k] for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws"))
+    # a budget that not even one cursor position of every block fits (130 blocks x 300 spp x 32 B > 1 MB): the single-pass walk takes over, same image
+    big, stb = ctx.render(api.IndependentSampler(2).block_seeds(160, 200), api.path_params(stream_mode=ref_mode, spp=300))
+    assert stb["ms_prepass"] == 0.0
     monkeypatch.delenv("RL_STATE_BUDGET_MB")
+    big2, stb2 = ctx.render(api.IndependentSampler(2).block_seeds(160, 200), api.path_params(stream_mode=ref_mode, spp=300))
+    assert stb2["ms_prepass"] > 0.0 and stb2["rng_draws"] == stb["rng_draws"]
+    np.testing.assert_array_equal(big, big2)
     # shards: the chains of a shard's blocks only
     parts = [ctx.render(api.IndependentSampler(1).block_seeds(160, 200), api.path_params(stream_mode=ref_mode, spp=24, shard_index=r, shard_count=3))[0] for r in range(3)]
     np.testing.assert_array_equal(parts[0] + parts[1] + parts[2], whole[0])
