@@ -249,3 +249,17 @@ def test_scene_from_one_pod_description_equals_the_builder_calls(built):
         api.Scene.from_desc(bad)
     with pytest.raises(api.RustlightError, match="bitmap"):
         api.Scene(bad)
+
+
+def test_scale_image_refuses_what_cannot_be_a_pixel_count(built, cbox64):
+    """Camera::scale_image (src/camera.rs:73-78, the CLI's -s): the scale is caller input — negative, zero, NaN, infinite or absurdly large values
+    are refused before the float -> unsigned conversion (undefined behaviour outside the target's range), valid ones rescale the image only."""
+    import ctypes as C
+    import math
+    L = api.lib()
+    sc = api.Scene(cbox64)
+    for bad in (0.0, -1.0, -0.5, math.nan, math.inf, -math.inf, 1e-9, 1e30):
+        assert L.rl_scene_scale_image(sc.h, C.c_float(bad)) == -1, bad      # RL_ERR_INVALID_ARGUMENT
+    assert sc.size == (64, 64)
+    assert L.rl_scene_scale_image(sc.h, C.c_float(0.5)) == api.RL_OK and sc.size == (32, 32)
+    assert L.rl_scene_scale_image(sc.h, C.c_float(3.0)) == api.RL_OK and sc.size == (96, 96)
