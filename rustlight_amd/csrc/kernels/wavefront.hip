@@ -698,7 +698,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         (ctx->lds_scene ? (fast_math ? launch_fused_lds_fast : launch_fused_lds) : (fast_math ? launch_fused_stream_fast : launch_fused_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, ctx->area_lights_only, grid, block, lds_fused, st, rcl, ds, stc);
     };
     if (two_pass) {
-        // tiny LDS-staged scenes (the Cornell box: 19 nodes + 32 triangles): the lanes of a chain's group precompute its ray's node / triangle records
+        // tiny LDS-staged scenes (the Cornell box: 19 nodes + 36 triangles): the lanes of a chain's group precompute its ray's node / triangle records
         // (trace.hip.h: precompute_records) — when a chain has at least 32 lanes to itself and the records fit a few passes
         StackConf stc_c = stc;
         // (not with a medium: most of its vertices are scattering events whose rays end in the volume, and the pass then costs more than it saves — cbox + medium,
