@@ -866,7 +866,7 @@ def test_fast_numerics_tolerance_mode(built):
     # (scene, render options, bound on the 99.9th percentile): SURVEY §8(d) makes the MEAN per-pixel squared L2 the target (< 1e-3) and asks for
     # the 99.9th percentile and the maximum to be reported.  On the diffuse scenes 99.9 % of the pixels are inside the tolerance even at these low
     # sample counts; with mirrors and glass a path whose decision flips (a ray grazing an edge now passes on the other side) can move a pixel by a
-    # whole light-source sample / spp, so only the mean is bounded there (1080p numbers: profiles/r02_fast_numerics_parity.json).
+    # whole light-source sample / spp, so there the mean is bounded by the tolerance and single pixels only in number (1080p numbers: profiles/r03_fast_numerics_parity.json).
     cases = [(scenes.cbox(96, 96), dict(spp=16), L2_TOL), (scenes.living_room(96, 64, n_spheres=27, tess=10), dict(spp=8, max_depth=8), None),
              (scenes.cbox_medium(64, 64, 0.5), dict(spp=4), L2_TOL)]
     for sd, kw, p999_bound in cases:
@@ -881,6 +881,11 @@ def test_fast_numerics_tolerance_mode(built):
         assert e.mean() < L2_TOL and np.isfinite(fast).all(), (e.mean(), np.quantile(e, 0.999), e.max())
         if p999_bound is not None:
             assert e.mean() < 1e-5 and np.quantile(e, 0.999) < p999_bound, (e.mean(), np.quantile(e, 0.999), e.max())
+        else:
+            # glossy scene (mirrors, glass; the tolerance build also traverses quantised BVH4 nodes here): no bound on single pixels, but on how MANY miss the
+            # per-pixel tolerance and by how much at the 99.9th percentile (measured over three seeds at 8 spp: 0.18-0.42 % of the pixels over 1e-3, p99.9
+            # 1.6e-3 ... 5.2e-3; at 64 spp 0.02-0.08 %) — BASELINE's bar holds in the mean, not per pixel, on such scenes, and the README says so
+            assert (e > L2_TOL).mean() < 0.015 and np.quantile(e, 0.999) < 2e-2, ((e > L2_TOL).mean(), np.quantile(e, 0.999))
         assert abs(float(fast.mean()) / float(ref.mean()) - 1.0) < 0.01          # never systematic: the image mean agrees within 1 %
         assert stf["camera_samples"] == ost["camera_samples"]
         # paths whose decisions flipped change the draw count: a fraction of a percent
