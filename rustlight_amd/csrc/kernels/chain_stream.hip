@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 
+#define RL_TRAVERSE_SPARSE 1      // trace.hip.h: no voted trips in this translation unit (k_stream_chain: one or two live lanes per wave)
 #include "common.hip.h"
 #include "chain.hip.h"
 

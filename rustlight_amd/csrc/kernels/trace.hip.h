@@ -362,6 +362,14 @@ RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3
         // 82.5 / 84.8 / 89.3 / 98.7 ms, both kinds in every trip: 98.1 ms; a different ratio for shadow rays — 1/2, 1, 2, 3 with 3/2 for extension rays:
         // 84.3 / 82.7 / 81.7 / 82.2 vs 81.8 ms.  On LDS-staged scenes the ballots cost more than they save: 62 vs 50 ms; so does the lighter form that
         // only leaves the nested node loop early, when the lanes still in it are fewer than 1/8 ... 1 x the lanes waiting: 56.1 ... 60.1 vs 49.5 ms)
+#if defined(RL_TRAVERSE_SPARSE)
+        // k_stream_chain (chain_stream.hip defines this): one or two live lanes per wave, bound by the latency of the dependent fetches — a vote would only make
+        // one chain wait for the other's trip, so every lane takes the trip it needs
+        while (cur != RL_CHILD_NONE) {
+            if (cur >= 0 || cur == kPop) node_trip();
+            else if (leaf_visit()) return true;
+        }
+#else
         for (;;) {
             const bool in_node = cur >= 0 || cur == kPop;
             const bool in_leaf = !in_node && cur != RL_CHILD_NONE;
@@ -370,6 +378,7 @@ RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3
             if (n_node > 0 && n_node * RL_VOTE_DEN >= RL_VOTE_NUM * n_leaf) { if (in_node) node_trip(); }
             else if (in_leaf && leaf_visit()) return true;
         }
+#endif
     }
     if (!ANY_HIT && found) {   // barycentrics of the closest hit (see tri_test)
         const float4* q = recs.tris + Stack::kTriStride4 * hit.prim;
@@ -476,6 +485,12 @@ RL_DEV bool traverse4(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V
         cur = kPop;
         return false;
     };
+#if defined(RL_TRAVERSE_SPARSE)
+    while (cur != RL_CHILD_NONE) {          // k_stream_chain: no vote (see traverse)
+        if (cur >= 0 || cur == kPop) node_trip();
+        else if (leaf_visit()) return true;
+    }
+#else
     for (;;) {
         const bool in_node = cur >= 0 || cur == kPop;
         const bool in_leaf = !in_node && cur != RL_CHILD_NONE;
@@ -484,6 +499,7 @@ RL_DEV bool traverse4(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V
         if (n_node > 0 && n_node * RL_VOTE4_DEN >= RL_VOTE4_NUM * n_leaf) { if (in_node) node_trip(); }
         else if (in_leaf && leaf_visit()) return true;
     }
+#endif
     if (!ANY_HIT && found) {
         const float4* q = recs.tris + 4 * hit.prim;
         tri_uv(q[0], q[1], q[2], q[3], o, d, hit.t, &hit.u, &hit.v);
