@@ -197,7 +197,10 @@ typedef enum rl_path_strategy { RL_STRATEGY_ALL = 0, RL_STRATEGY_BSDF = 1, RL_ST
 
 /* How the per-block random stream is mapped onto GPU lanes:
  *  RL_STREAM_REFERENCE_ORDER: one serial stream per 16x16 block, consumed over (iy, ix, sample)
- *      exactly as compute_mc does (src/integrators/mod.rs:420-435) — equals rustlight proper, slow.
+ *      exactly as compute_mc does (src/integrators/mod.rs:420-435) — equals rustlight proper.  Runs in two passes on the
+ *      GPU: a draw-count walk of every block's stream records the sampler state at the start of each camera sample (what is
+ *      serial is only how many numbers a sample takes), then all samples are evaluated in parallel from those states; 15x
+ *      slower than RL_STREAM_PER_SAMPLE on the Cornell box, same image and counters as the one-lane-per-block walk.
  *  RL_STREAM_PER_SAMPLE: the block stream is forked with the reference's own clone_box rule
  *      (samplers/independent.rs:18-22) once per pixel and once per sample — throughput mode. */
 typedef enum rl_stream_mode { RL_STREAM_REFERENCE_ORDER = 0, RL_STREAM_PER_SAMPLE = 1 } rl_stream_mode;
@@ -225,8 +228,8 @@ typedef struct rl_path_params {
     /* 0 = auto, 1 = wavefront stage kernels (raygen / extend / shade / shadow per iteration, state in HBM),
      * 2 = persistent fused kernel (same stages in one launch, state in registers; the BSDF code is specialised when the scene has
      * one BSDF type and switches per vertex otherwise).  Auto takes the fused kernel whenever pool_slots = 0 (reference-order
-     * streams too: their few work items — one per 16x16 block — are spread over every 32nd lane so that all SIMDs have waves) and the
-     * wavefront kernels otherwise.  Does not change results. */
+     * streams too: k_stream_chain walks the block streams — one per 16x16 block, dealt to every 32nd lane so that all SIMDs have waves — and
+     * the fused kernel evaluates the samples from the recorded states) and the wavefront kernels otherwise.  Does not change results. */
     uint32_t pipeline;
     /* per-sample stream mode: lanes working on one pixel at a time (sample s of a pixel runs on lane s % sample_split; the
      * per-sample radiances are parked in HBM and added up in sample order afterwards, so the sum keeps the reference's
