@@ -21,6 +21,7 @@
  *   RL_REF_SINGLE_PASS=1      reference-order streams through the persistent kernel in ONE pass (the form of rounds 1-2) instead of
  *                             k_stream_chain + per-sample evaluation
  *   RL_CHAIN_NO_PRE=1         k_stream_chain on tiny scenes without the lane-parallel node / triangle records (the plain one-lane traversal)
+ *   RL_CHAIN_NO_TREELETS=1    k_stream_chain on streaming scenes without the 16-node treelet blocks (plain per-node fetches)
  *   RL_STATE_BUDGET_MB=n      bytes the recorded sampler states of the two-pass form may take (default 24 GB): small values force several chunks
  *   RL_FUSED_DYNAMIC=0|1      persistent kernel: static tile order / work items from the atomic dispenser
  *   RL_GENERIC_LIGHTS=1       do not specialise the NEE code for area-light-only scenes

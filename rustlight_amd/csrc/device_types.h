@@ -137,6 +137,10 @@ struct DeviceScene {
     int32_t root;            // child encoding of the root (inner 0, a leaf, or NONE for an empty scene)
     uint32_t n_nodes, n_prims;
     uint32_t stack_depth;    // max number of simultaneously pending far children (+1)
+    // streaming scenes: a copy of `nodes` laid out in blocks of 16 (1 KB) that each hold connected pieces of the tree (host: treelet_blocks) — k_stream_chain fetches
+    // a whole block with the idle lanes of a chain's group and walks up to four levels without another round trip to memory (null when the scene is staged in LDS)
+    const BvhNode* nodes_t;
+    int32_t root_t;
     // tolerance build on streaming scenes: the BVH2 above collapsed into quantised BVH4 nodes (null / NONE when the scene is staged in LDS)
     const Bvh4Node* nodes4;
     int32_t root4;

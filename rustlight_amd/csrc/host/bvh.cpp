@@ -177,6 +177,49 @@ static double area_of(const Child2& c) {
 }
 }  // namespace
 
+void treelet_blocks(const BvhBuild& bvh, std::vector<BvhNode>* nodes_out, int32_t* root_out) {
+    nodes_out->clear();
+    *root_out = bvh.root;
+    const size_t n = bvh.nodes.size();
+    if (bvh.root < 0 || n == 0) return;
+    std::vector<int32_t> new_index(n, -1);
+    std::vector<int32_t> roots{bvh.root};
+    size_t n_slots = 0;                       // slots handed out so far (whole blocks of 16; the last block may be open)
+    auto less = [](const std::pair<double, int32_t>& a, const std::pair<double, int32_t>& b) { return a.first < b.first || (a.first == b.first && a.second > b.second); };
+    while (!roots.empty()) {
+        const int32_t r = roots.back();
+        roots.pop_back();
+        // the treelet around r: largest box first, at most 16 nodes
+        std::vector<std::pair<double, int32_t>> heap{{1e300, r}};
+        std::vector<int32_t> picked;
+        while (!heap.empty() && picked.size() < 16) {
+            std::pop_heap(heap.begin(), heap.end(), less);
+            const int32_t i = heap.back().second;
+            heap.pop_back();
+            picked.push_back(i);
+            Child2 l, rr;
+            children_of(bvh.nodes[i], &l, &rr);
+            if (l.code >= 0) { heap.push_back({area_of(l), l.code}); std::push_heap(heap.begin(), heap.end(), less); }
+            if (rr.code >= 0) { heap.push_back({area_of(rr), rr.code}); std::push_heap(heap.begin(), heap.end(), less); }
+        }
+        for (const auto& e : heap) roots.push_back(e.second);        // the frontier's inner children start treelets of their own
+        // into the open block if it still has room for the whole treelet, else into a fresh block
+        const size_t free_slots = (16 - n_slots % 16) % 16;
+        if (picked.size() > free_slots) n_slots = (n_slots + 15) / 16 * 16;
+        for (int32_t i : picked) new_index[i] = (int32_t)n_slots++;
+    }
+    nodes_out->assign((n_slots + 15) / 16 * 16, BvhNode{});
+    for (BvhNode& d : *nodes_out) { d.left = RL_CHILD_NONE; d.right = RL_CHILD_NONE; }
+    for (size_t i = 0; i < n; i++) {
+        if (new_index[i] < 0) continue;          // (unreachable nodes: none in a tree)
+        BvhNode d = bvh.nodes[i];
+        if (d.left >= 0) d.left = new_index[d.left];
+        if (d.right >= 0) d.right = new_index[d.right];
+        (*nodes_out)[new_index[i]] = d;
+    }
+    *root_out = new_index[bvh.root];
+}
+
 void build_bvh4(const BvhBuild& bvh, Bvh4Build* out) {
     *out = Bvh4Build();
     out->root = bvh.root;

@@ -114,6 +114,38 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_CHAIN_WAVES : RL_CHAIN_WAV
                 RL_CT1(2, has_ray)
             }
         }
+    } else if (!LDS_SCENE && !TravStackT<false>::kBvh4 && stc.pre_group > 0) {
+        // Scenes that stream their BVH (exact build): the lanes of a chain's group fetch whole 16-node blocks of the treelet-ordered node array for it
+        // (trace.hip.h: traverse_treelet).  Every lane of the wave stays in the loop until the wave's chains are done.
+        const unsigned group = (unsigned)stc.pre_group, lane = threadIdx.x & 63u, sub = lane & (group - 1u), lead = lane & ~(group - 1u);
+        const unsigned slot = threadIdx.x / group;
+        // LDS per chain: 64 float4 of nodes + 8 of triangles + the whole traversal stack (stack_depth entries of 8 bytes, rounded to float4s)
+        const unsigned per_chain = 72u + (sc0.stack_depth + 1u) / 2u;
+        float4* cache_nodes = reinterpret_cast<float4*>(reinterpret_cast<unsigned*>(after_scene) + 2 * 256 * stc.lds_levels) + (size_t)slot * per_chain;
+        float4* cache_tris = cache_nodes + 64;
+        ChainStack cstack; cstack.base = reinterpret_cast<int2*>(cache_nodes + 72);
+        while (__ballot(!(PU(U_FLAGS) & ST_FINISHED)) != 0ull) {
+            RL_CHAIN_KERNARGS
+            if (PU(U_FLAGS) & ST_REGEN) raygen_chain_slot(rc, sc, ps);
+            const unsigned flags = PU(U_FLAGS);
+            const bool has_ray = (flags & ST_RAY) != 0u;
+            if (__ballot(has_ray) != 0ull) {
+                const bool primary = ((flags >> ST_PREV_SHIFT) & 3u) == PREV_SENSOR;
+                const V3 o = primary ? mk3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]) : load3(ps, F_OX);
+                const V3 d = load3(ps, F_DX);
+                Hit hit; hit.t = kF32Max; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
+                traverse_treelet(reinterpret_cast<const float4*>(sc0.nodes_t), recs.tris, sc0.root_t, mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]),
+                                 o, d, kEps, kF32Max, has_ray, lead, sub, group, cache_nodes, cache_tris, hit, cstack);
+                if (has_ray) {
+                    PF(F_T) = hit.t; PF(F_U) = hit.u; PF(F_V) = hit.v;
+                    PU(U_PRIM) = (unsigned)hit.prim;
+#ifdef RL_STAGE_TIMERS
+                    atomicAdd(&g_chain_timers[7], ((unsigned long long)hit.fetches << 32) | (unsigned long long)hit.steps);      // dev-only: block fetches | node steps
+#endif
+                    shade_slot<MAT, MEDIUM, LIGHTS_AREA_ONLY, true>(rc, sc, ps, flags, dummy, dummy, dummy, dummy);
+                }
+            }
+        }
     } else
     while (!(PU(U_FLAGS) & ST_FINISHED)) {
         RL_CHAIN_KERNARGS
@@ -148,6 +180,7 @@ static void dump_chain_timers_impl() {
     const double tot = (double)(h[0] + h[1] + h[2]);
     const char* names[3] = {"raygen", "extend", "shade"};
     if (tot > 0) for (int k = 0; k < 3; k++) std::fprintf(stderr, "[chain] %-7s cycles %5.1f %%  (%.0f cycles per wave-iteration, %.2f lanes)\n", names[k], 100.0 * h[k] / tot, (double)h[k] / (double)h[6], (double)h[3 + k] / (double)h[6]);
+    if (h[7]) std::fprintf(stderr, "[chain] treelet walk: %llu node steps, %llu block fetches (%.2f steps per fetch)\n", h[7] & 0xffffffffull, h[7] >> 32, (double)(h[7] & 0xffffffffull) / (double)(h[7] >> 32));
     std::memset(h, 0, sizeof(h)); hipMemcpyToSymbol(HIP_SYMBOL(g_chain_timers), h, sizeof(h));
 #endif
 }

@@ -18,7 +18,7 @@
 
 namespace rl {
 
-struct Hit { float t, u, v; int prim; int steps = 0, tris = 0; };   // steps / tris: dev-only traversal statistics (dead code unless read)
+struct Hit { float t, u, v; int prim; int steps = 0, tris = 0, fetches = 0; };   // steps / tris: dev-only traversal statistics (dead code unless read)
 
 // Layout of a scene staged in LDS.  A 64-byte record stride puts the same field of every node on two LDS banks (bank = dword
 // address mod 32) and the 16-byte quarters of every triangle on four bank groups, so lanes that read different records collide
@@ -805,6 +805,101 @@ RL_DEV bool traverse_pre(const float4* pre_nodes, const float2* pre_tris, const 
     }
     if (found) {
         const float4* q = recs.tris + kLdsTriStride4 * hit.prim;
+        tri_uv(q[0], q[1], q[2], q[3], o, d, hit.t, &hit.u, &hit.v);
+    }
+    return found;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// traverse_treelet — k_stream_chain on scenes that stream their BVH (round 3).  A chain traces one ray at a time and each node / leaf it visits is a
+// dependent fetch from L2 / the Infinity Cache (~25 per ray on the 508 k-triangle scene: four fifths of the pass).  The node array this function reads
+// is laid out in 1 KB blocks of 16 nodes that hold connected pieces of the tree (host: treelet_blocks): when the chain lane needs a node outside the
+// block it has, the `group` lanes of its chain fetch the WHOLE block — 64 x 16 bytes, one or two loads per lane, one round trip — into LDS, and the walk
+// then descends up to four levels out of LDS; a leaf's one or two triangle records are fetched the same way.  Visits, order and arithmetic per ray are those
+// of `traverse`.  Called by EVERY lane of the wave in step (`has_ray`: this lane is a chain lane with a ray; the others only fetch).
+// a chain's whole traversal stack in LDS, one contiguous column per chain (the [level][lane] stacks of the other kernels keep only a few levels there and spill
+// the rest to global memory — for a chain every pop from that part is one more dependent round trip)
+struct ChainStack {
+    int2* base;
+    RL_DEV void push(int sp, int code, float dist) const { base[sp] = make_int2(code, __float_as_int(dist)); }
+    RL_DEV void get(int sp, int* code, float* dist) const { const int2 e = base[sp]; *code = e.x; *dist = __int_as_float(e.y); }
+};
+template <class Stack>
+RL_DEV bool traverse_treelet(const float4* nodes_t, const float4* tris, int root, V3 root_lo, V3 root_hi, V3 o, V3 d, float tnear, float tfar, bool has_ray,
+                             unsigned lead, unsigned sub, unsigned group, float4* cache_nodes, float4* cache_tris, Hit& hit, const Stack& st) {
+    const V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
+    float dummy;
+    int cur = RL_CHILD_NONE;
+    if (has_ray && slab(root_lo, root_hi, o, inv_d, tnear, tfar, &dummy)) cur = root;
+    int sp = 0, cached = -1;
+    bool found = false;
+    constexpr int kPop = -1;
+    const bool sx = inv_d.x < 0.0f, sy = inv_d.y < 0.0f, sz = inv_d.z < 0.0f;
+    while (__ballot(cur != RL_CHILD_NONE) != 0ull) {
+        // ---- inner node (or stack entry)
+        const bool need = cur >= 0 && (cur >> 4) != cached;
+        if (__ballot(need) != 0ull) {         // (no cross-lane traffic on the common path: a node of the block the chain already has)
+            const int g_blk = __shfl(need ? (cur >> 4) : -1, (int)lead, 64);
+            const bool g_need = g_blk >= 0;
+            if (g_need) {
+                const float4* src = nodes_t + (size_t)g_blk * 64;
+                for (unsigned i = sub; i < 64u; i += group) cache_nodes[i] = src[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (need) { cached = cur >> 4; hit.fetches++; }
+        }
+        if (cur >= 0) {
+            hit.steps++;
+            const float4* q = cache_nodes + 4 * (cur & 15);
+            const float4 a = q[0], b = q[1], c = q[2], e = q[3];
+            NodePlanes p;
+            p.lnx = sx ? a.w : a.x; p.lfx = sx ? a.x : a.w; p.lny = sy ? b.x : a.y; p.lfy = sy ? a.y : b.x; p.lnz = sz ? b.y : a.z; p.lfz = sz ? a.z : b.y;
+            p.rnx = sx ? c.y : b.z; p.rfx = sx ? b.z : c.y; p.rny = sy ? c.z : b.w; p.rfy = sy ? b.w : c.z; p.rnz = sz ? c.w : c.x; p.rfz = sz ? c.x : c.w;
+            p.id1 = __float_as_int(e.x); p.id2 = __float_as_int(e.y);
+            const float d1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((p.lnx - o.x) * inv_d.x, (p.lny - o.y) * inv_d.y), (p.lnz - o.z) * inv_d.z), tnear);
+            const float f1 = __builtin_fminf(__builtin_fminf(__builtin_fminf((p.lfx - o.x) * inv_d.x, (p.lfy - o.y) * inv_d.y), (p.lfz - o.z) * inv_d.z), hit.t);
+            const float d2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((p.rnx - o.x) * inv_d.x, (p.rny - o.y) * inv_d.y), (p.rnz - o.z) * inv_d.z), tnear);
+            const float f2 = __builtin_fminf(__builtin_fminf(__builtin_fminf((p.rfx - o.x) * inv_d.x, (p.rfy - o.y) * inv_d.y), (p.rfz - o.z) * inv_d.z), hit.t);
+            const bool v1 = !(f1 <= d1), v2 = !(f2 <= d2);
+            const bool right_first = v2 & (!v1 | (d1 > d2));
+            st.push(sp, right_first ? p.id1 : p.id2, right_first ? d1 : d2);
+            sp += (v1 && v2) ? 1 : 0;
+            cur = (v1 || v2) ? (right_first ? p.id2 : p.id1) : kPop;
+        }
+        if (cur == kPop) {
+            cur = RL_CHILD_NONE;
+            if (sp > 0) {
+                sp--;
+                int code; float dist;
+                st.get(sp, &code, &dist);
+                cur = dist < hit.t ? code : kPop;
+            }
+        }
+        // ---- leaf (<= 2 triangles, tested in order)
+        const bool in_leaf = cur != RL_CHILD_NONE && cur != kPop && cur < 0;
+        if (__ballot(in_leaf) != 0ull) {
+            const unsigned code = (unsigned)(~cur);
+            const unsigned g_code = (unsigned)__shfl(in_leaf ? (int)code : 0, (int)lead, 64);      // 0: this group's chain holds no leaf
+            const int g_first = (int)(g_code >> 2), g_count = (int)(g_code & 3u);
+            if ((int)sub < 4 * g_count) cache_tris[sub] = tris[4 * (size_t)g_first + sub];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (in_leaf) {
+                const int first = (int)(code >> 2), count = (int)(code & 3u);
+                for (int k = 0; k < count; k++) {
+                    hit.tris++;
+                    const float4* q = cache_tris + 4 * k;
+                    found = found | tri_test(q[0], q[1], q[2], q[3], o, d, hit, first + k);
+                }
+                cur = kPop;
+            }
+        }
+    }
+    if (found) {
+        const float4* q = tris + 4 * (size_t)hit.prim;
         tri_uv(q[0], q[1], q[2], q[3], o, d, hit.t, &hit.u, &hit.v);
     }
     return found;

@@ -325,6 +325,7 @@ extern "C" int rl_context_create(const rl_scene* scene, int device, rl_context**
         ds.n_prims = (uint32_t)bvh.tris.size();
         ds.stack_depth = bvh.stack_depth;
         ds.nodes4 = nullptr; ds.root4 = RL_CHILD_NONE; ds.stack_depth4 = 0;
+        ds.nodes_t = nullptr; ds.root_t = RL_CHILD_NONE;
         if ((rc = upload(ctx, flat.tri_indices, &ds.tri_indices)) != RL_OK) break;
         if ((rc = upload(ctx, flat.positions, &ds.positions)) != RL_OK) break;
         if ((rc = upload(ctx, flat.normals, &ds.normals)) != RL_OK) break;
@@ -397,6 +398,12 @@ extern "C" int rl_context_create(const rl_scene* scene, int device, rl_context**
             build_bvh4(bvh, &b4);
             if ((rc = upload(ctx, b4.nodes, &ds.nodes4)) != RL_OK) break;
             ds.root4 = b4.root; ds.stack_depth4 = b4.stack_depth;
+            // ... and the draw-count pass of reference-order streams reads the exact BVH2 through a copy laid out in 16-node treelet blocks (traverse_treelet)
+            std::vector<BvhNode> blocks;
+            int32_t root_t = RL_CHILD_NONE;
+            treelet_blocks(bvh, &blocks, &root_t);
+            if ((rc = upload(ctx, blocks, &ds.nodes_t)) != RL_OK) break;
+            ds.root_t = root_t;
         }
         if (hipMalloc((void**)&ctx->d_counters, sizeof(Counters)) != hipSuccess) { rl_set_error("hipMalloc counters"); rc = RL_ERR_HIP; break; }
         if (hipHostMalloc((void**)&ctx->h_counters, sizeof(Counters)) != hipSuccess) { rl_set_error("hipHostMalloc counters"); rc = RL_ERR_HIP; break; }
@@ -705,7 +712,11 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         // 1080p x 16 spp: 404 vs 353 ms; a variant with ONE chain per wave, the records left in registers and a wave-uniform v_readlane walk measured no better
         // than the LDS records at the same chains per wave: 767.5 vs 768.1 ms, and 2 chains per wave beat both: 705 ms)
         if (ctx->lds_scene && !medium && ctx->ds.n_nodes <= 64u && ctx->ds.n_prims <= 64u && plan_chain.item_shift >= 5u && !getenv("RL_CHAIN_NO_PRE")) stc_c.pre_group = 1 << plan_chain.item_shift;
-        const size_t lds_chain = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + (stc_c.pre_group ? (size_t)(256 / stc_c.pre_group) * ((size_t)ctx->ds.n_nodes * 32 + (size_t)ctx->ds.n_prims * 8) : 0);
+        // scenes that stream their BVH (exact build): the group fetches 16-node treelet blocks for its chain (traverse_treelet); 72 float4 of LDS per chain
+        const bool treelets = !ctx->lds_scene && !fast_math && ctx->ds.nodes_t && ctx->ds.root_t >= 0 && plan_chain.item_shift >= 5u && ctx->ds.stack_depth <= 512u && !getenv("RL_CHAIN_NO_TREELETS");
+        if (treelets) stc_c.pre_group = 1 << plan_chain.item_shift;
+        const size_t lds_chain = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + (treelets ? (size_t)(256 / stc_c.pre_group) * (72 + (ctx->ds.stack_depth + 1) / 2) * 16
+                                 : (stc_c.pre_group ? (size_t)(256 / stc_c.pre_group) * ((size_t)ctx->ds.n_nodes * 32 + (size_t)ctx->ds.n_prims * 8) : 0));
         for (const Chunk& ch : chunks) {
             // ---- pass 1: the chains
             HIP_OK(hipMemcpyAsync(ctx->d_item_base, ch.base.data(), ch.base.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));

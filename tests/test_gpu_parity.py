@@ -269,6 +269,13 @@ def test_small_scenes_through_the_streaming_kernels(built, monkeypatch, pipeline
         assert not ctx.debug_sizes()["lds_scene"]
         _assert_parity(*_render_pair(sd, ctx=ctx, pipeline=pipeline, **kw))
         _assert_parity(*_render_pair(sd, ctx=ctx, pipeline=pipeline, stream_mode=api.STREAM_REFERENCE_ORDER, **kw))
+        if pipeline == api.PIPELINE_FUSED:
+            # the chain pass of reference-order streams reads the BVH through 16-node treelet blocks (traverse_treelet): against the plain per-node fetches
+            a = ctx.render(api.IndependentSampler(0).block_seeds(sd.width, sd.height), api.path_params(stream_mode=api.STREAM_REFERENCE_ORDER, **kw))[0]
+            monkeypatch.setenv("RL_CHAIN_NO_TREELETS", "1")
+            b = ctx.render(api.IndependentSampler(0).block_seeds(sd.width, sd.height), api.path_params(stream_mode=api.STREAM_REFERENCE_ORDER, **kw))[0]
+            monkeypatch.delenv("RL_CHAIN_NO_TREELETS")
+            np.testing.assert_array_equal(a, b)
     sd = scenes.living_room(48, 32, n_spheres=20, tess=8)
     ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
     seeds = api.IndependentSampler(4).block_seeds(sd.width, sd.height)
