@@ -294,3 +294,75 @@ void build_bvh4(const BvhBuild& bvh, Bvh4Build* out) {
 }
 
 }  // namespace rl
+
+// ------------------------------------------------------------------------------------------
+// Host-only check of the two structures derived from the BVH2 (test hook, no GPU): the treelet-blocked copy must be the same tree (same boxes, same
+// leaves, every inner node in exactly one slot), and every BVH4 node must cover the same set of BVH2 subtrees with boxes that contain the originals.
+// out[0] = BVH2 inner nodes, [1] = slots of the blocked copy, [2] = BVH4 nodes, [3] = violations found, [4] = BVH4 leaves, [5] = BVH2 leaves.
+extern "C" int rl_debug_check_derived_bvhs(const rl_scene* scene, uint64_t* out6) {
+    using namespace rl;
+    if (!scene || !out6) return -1;
+    BvhBuild bvh;
+    build_bvh(*scene, &bvh);
+    std::vector<BvhNode> blocks;
+    int32_t root_t = RL_CHILD_NONE;
+    treelet_blocks(bvh, &blocks, &root_t);
+    Bvh4Build b4;
+    build_bvh4(bvh, &b4);
+    uint64_t bad = 0, leaves2 = 0, leaves4 = 0;
+    // ---- blocked copy: walk both trees in step
+    if (bvh.root >= 0) {
+        std::vector<char> seen(blocks.size(), 0);
+        std::vector<std::pair<int32_t, int32_t>> todo{{bvh.root, root_t}};
+        while (!todo.empty()) {
+            const auto [a, b] = todo.back();
+            todo.pop_back();
+            if (b < 0 || (size_t)b >= blocks.size() || seen[b]) { bad++; continue; }
+            seen[b] = 1;
+            const BvhNode &x = bvh.nodes[a], &y = blocks[b];
+            if (std::memcmp(&x, &y, 48) != 0) bad++;                      // the twelve planes
+            const int32_t xa[2] = {x.left, x.right}, ya[2] = {y.left, y.right};
+            for (int k = 0; k < 2; k++) {
+                if (xa[k] >= 0) { if (ya[k] < 0) bad++; else todo.push_back({xa[k], ya[k]}); }
+                else { if (xa[k] != ya[k]) bad++; if (xa[k] != RL_CHILD_NONE) leaves2++; }
+            }
+        }
+        size_t used = 0;
+        for (char c : seen) used += c;
+        if (used != bvh.nodes.size()) bad++;
+    }
+    // ---- BVH4: every node stands for a BVH2 node; its children are that node's descendants, boxes conservative
+    if (bvh.root >= 0 && b4.root >= 0) {
+        std::vector<std::pair<int32_t, int32_t>> todo{{bvh.root, b4.root}};
+        while (!todo.empty()) {
+            const auto [a, b] = todo.back();
+            todo.pop_back();
+            const Bvh4Node& nd = b4.nodes[b];
+            // the frontier the collapse must have produced: expand `a` exactly as build_bvh4 does
+            Child2 ch[4];
+            int n = 2;
+            children_of(bvh.nodes[a], &ch[0], &ch[1]);
+            while (n < 4) {
+                int best = -1; double best_area = -1.0;
+                for (int k = 0; k < n; k++) if (ch[k].code >= 0) { const double ar = area_of(ch[k]); if (ar > best_area) { best_area = ar; best = k; } }
+                if (best < 0) break;
+                Child2 l, r;
+                children_of(bvh.nodes[ch[best].code], &l, &r);
+                for (int k = n; k > best + 1; k--) ch[k] = ch[k - 1];
+                ch[best] = l; ch[best + 1] = r; n++;
+            }
+            for (int k = 0; k < 4; k++) {
+                if (k >= n) { if (nd.child[k] != RL_CHILD_NONE) bad++; continue; }
+                for (int ax = 0; ax < 3; ax++) {
+                    const float step = std::ldexp(1.0f, (int)((nd.exps >> (8 * ax)) & 0xffu) - 127);
+                    const float lo = nd.org[ax] + (float)((nd.qlo[ax] >> (8 * k)) & 0xffu) * step, hi = nd.org[ax] + (float)((nd.qhi[ax] >> (8 * k)) & 0xffu) * step;
+                    if (std::isfinite(ch[k].lo[ax]) && std::isfinite(ch[k].hi[ax]) && (!(lo <= ch[k].lo[ax]) || !(hi >= ch[k].hi[ax]))) bad++;
+                }
+                if (ch[k].code >= 0) { if (nd.child[k] < 0) bad++; else todo.push_back({ch[k].code, nd.child[k]}); }
+                else { if (nd.child[k] != ch[k].code) bad++; leaves4++; }
+            }
+        }
+    }
+    out6[0] = bvh.nodes.size(); out6[1] = blocks.size(); out6[2] = b4.nodes.size(); out6[3] = bad; out6[4] = leaves4; out6[5] = leaves2;
+    return 0;
+}

@@ -263,3 +263,21 @@ def test_scale_image_refuses_what_cannot_be_a_pixel_count(built, cbox64):
     assert sc.size == (64, 64)
     assert L.rl_scene_scale_image(sc.h, C.c_float(0.5)) == api.RL_OK and sc.size == (32, 32)
     assert L.rl_scene_scale_image(sc.h, C.c_float(3.0)) == api.RL_OK and sc.size == (96, 96)
+
+
+@pytest.mark.parametrize("maker", [lambda: scenes.cbox(64, 64), lambda: scenes.living_room(64, 64, n_spheres=27, tess=12), lambda: scenes.living_room(64, 64, n_spheres=64, tess=24),
+                                   lambda: scenes.single_triangle(), lambda: scenes.many_lights(64, 48, n=5, use_ats=False)])
+def test_structures_derived_from_the_bvh2_are_the_same_tree(built, maker):
+    """Host-only: the treelet-blocked copy of the node array (k_stream_chain on streaming scenes) is the BVH2 itself — same boxes, same leaves, every inner node in
+    exactly one slot — and every BVH4 node of the tolerance build covers the BVH2 subtrees build_bvh4's collapse rule gives it, with quantised boxes that contain
+    the originals (so a BVH4 traversal visits a superset of the BVH2's leaves)."""
+    import ctypes as C
+    sc = api.Scene(maker())
+    out = (C.c_uint64 * 6)()
+    fn = api.lib().rl_debug_check_derived_bvhs
+    fn.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    assert fn(sc.h, out) == 0
+    n2, slots, n4, bad, leaves4, leaves2 = (int(x) for x in out)
+    assert bad == 0, list(out)
+    if n2:
+        assert slots % 16 == 0 and n2 <= slots <= 16 * n2 and leaves4 == leaves2 == n2 + 1 and 0 < n4 <= n2
