@@ -53,3 +53,21 @@ def test_stored_counter_keys_follow_the_workload():
         w, h, spp = (int(x) for x in dims.split("x"))
         assert (w, h, spp) == (1920, 1080, 128) and stream in ("per_sample", "reference") and numerics in ("exact", "fast")
         assert e["key"] == key and len(e["kernel_src_hash"]) == 16 and e["commit"]
+
+
+def test_also_records_only_on_the_default_single_gpu_run():
+    """The `also` sub-records (the other BASELINE configs / stream modes, timed in the same process) ride on the run the driver makes — `python bench.py --gpus 1
+    [--steps K --warmup W]` — and on nothing else: any other scene, size, stream mode, numerics, pipeline, pool, GPU count or --no-also is a single-workload run."""
+    assert bench.is_default_workload(bench.parse_args([]))
+    assert bench.is_default_workload(bench.parse_args(["--gpus", "1", "--steps", "20", "--warmup", "3"]))
+    assert bench.is_default_workload(bench.parse_args(["--no-cpu-baseline"]))
+    for argv in (["--gpus", "2"], ["--scene", "living_room"], ["--stream-mode", "reference"], ["--numerics", "fast"], ["--width", "1080"], ["--spp", "64"],
+                 ["--pipeline", "wavefront"], ["--pool", "4096"], ["--tris", "4000000"], ["--no-also"]):
+        assert not bench.is_default_workload(bench.parse_args(argv)), argv
+    a = bench.parse_args(["--scaling", "strong", "--gpus", "8"])
+    assert a.scaling == "strong" and bench.parse_args([]).scaling == "weak" and a.init_timeout > 0
+
+
+def test_pipeline_bytes_is_the_survey_formula():
+    """algorithmic bytes = 248 B per camera sample + 352 B per expanded vertex + 12 B per pixel per pass."""
+    assert bench.pipeline_bytes({"camera_samples": 10, "vertices": 7}, pixels=5, steps=2) == 248 * 10 + 352 * 7 + 12 * 5 * 2
