@@ -240,7 +240,8 @@ typedef struct rl_path_params {
      * 1 = fast (opt-in: FMA contraction, a * v_rcp(b) / raw v_sqrt / v_rsq (1 ulp, no refinement step) instead of the IEEE divide / sqrt
      * sequences, hardware sin / cos / exp2 / log2; the RNG sequence stays bit-exact, pixels agree with the exact mode within
      * BASELINE.json's per-pixel L2 tolerance in the MEAN, not bit for bit and not for every pixel on glossy scenes — DESIGN.md §2
-     * "Tolerance mode"). */
+     * "Tolerance mode").  With RL_STREAM_REFERENCE_ORDER the first flipped decision of a block shifts the rest of that block's stream: the render is then
+     * statistically, not seed-for-seed, the exact build's. */
     uint32_t numerics;
 } rl_path_params;
 
