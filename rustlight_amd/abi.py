@@ -72,7 +72,10 @@ class RenderStats(C.Structure):
                 ("reserved", C.c_uint64 * 4)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        # k_stream_spec's counters (reference-order streams, first pass): samples walked speculatively / serially / by the estimate probes, lanes per block (0: the serial chain ran)
+        d["spec_samples"], d["spec_serial_samples"], d["spec_probe_samples"], d["spec_group"] = (int(v) for v in self.reserved)
+        return d
 
 
 def color_desc(d: dict) -> ColorDesc:

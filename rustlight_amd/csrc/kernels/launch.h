@@ -22,6 +22,9 @@ void launch_chain_lds(int mat, bool medium, dim3 grid, dim3 block, size_t lds_by
 void launch_chain_stream(int mat, bool medium, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc);
 void launch_chain_lds_fast(int mat, bool medium, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc);
 void launch_chain_stream_fast(int mat, bool medium, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc);
+// k_stream_spec (spec.hip.h): the same first pass with every lane busy — windows of the stream walked speculatively per pixel, the chain threaded through them
+void launch_spec_lds(int mat, bool medium, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc, const SpecConf& spc);
+void launch_spec_stream(int mat, bool medium, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc, const SpecConf& spc);
 void launch_trace_batch_fast(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const DeviceScene& ds, const StackConf& stc, unsigned n, const float* o, const float* d, float* t_out,
                              int* mesh_out, int* tri_out, int* steps_out);   // test hook: the tolerance build's BVH4 traversal, batched
 void launch_shade_type(int type, bool medium, dim3 grid, dim3 block, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const Pool& pool);

@@ -62,6 +62,20 @@ static constexpr size_t kSampleBufBudget = (size_t)16 << 30;   // bytes of HBM t
 // traversal stack configuration (see TravStack)
 struct StackConf { int lds_levels; int* overflow; size_t overflow_stride; int pre_group; };   // pre_group: k_stream_chain on tiny LDS scenes — lanes per chain that precompute its ray's records (0: off; trace.hip.h: precompute_records)
 
+static constexpr int kSpecColdWords = 29;      // k_stream_spec: words of per-thread state parked in LDS, + 4 u64 per group (host: LDS bytes of the launch)
+// k_stream_spec (spec.hip.h): launch configuration and scratch of the speculative first pass of reference-order streams
+struct SpecConf {
+    unsigned group;              // lanes per 16x16 block: 16, 32 or 64 (a batch = `group` consecutive pixels of the block, one per lane)
+    unsigned cap;                // entries a lane's track can hold
+    unsigned probe;              // samples of the estimate probe (lanes that have no resolved pixel to go by: the first batch)
+    unsigned lead;               // samples of lead-in before a window (a track needs a few samples to fall in with the chain)
+    float ks, ke;                // window margins in standard deviations of the predicted start / end offset
+    unsigned* trk_off;           // [thread][cap] stream offsets of the samples a lane walked, relative to the batch's anchor, ascending
+    ulonglong2* trk_st;          // [thread][cap][2] the sampler state at each of them
+    const unsigned* trivial;     // [owned block][8] bit c: every camera ray of block cursor c misses the scene (two draws per sample)
+    unsigned long long* stats;   // dev / bench: [0] spec samples walked, [1] slow samples, [2] probe samples, [3] wave loop iterations
+};
+
 template <bool LDS_ONLY = false>
 RL_DEV TravStackT<LDS_ONLY> make_stack(const StackConf& sc_, unsigned* lds_after_list, size_t global_thread) {
     TravStackT<LDS_ONLY> st;

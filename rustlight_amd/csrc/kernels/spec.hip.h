@@ -1,0 +1,425 @@
+// spec.hip.h — k_stream_spec: the first pass of RL_STREAM_REFERENCE_ORDER with every lane busy (round 4), and its launcher; instantiated by
+// spec_lds.hip / spec_stream.hip.  Writes exactly what k_stream_chain (chain.hip.h) writes — the block sampler's state at the start of every
+// camera sample — and is followed by the same second pass (k_path_fused from the recorded states).
+//
+// rustlight's compute_mc (src/integrators/mod.rs:420-435) consumes ONE sampler per 16x16 block over (iy, ix, sample): where sample k+1 starts
+// in the block's stream is where sample k stopped, so the stream positions of a block form a serial chain t -> t + n_p(t), with n_p(t) the number
+// of draws a camera sample of pixel p takes when it starts at stream offset t.  k_stream_chain walks that chain with one lane.  Here the chain is
+// still followed exactly, but almost none of it is walked serially:
+//   * n_p is a pure function of (block seed, pixel, offset).  Two walks of the SAME pixel that ever stand on the same offset stay together
+//     for good — and walks started a few draws apart meet after a sample count of the order of the mean draws per sample (the offsets a walk
+//     visits are a renewal process: measured on the Cornell box, 16 samples on average; scratch/r4/merge_sim.py).
+//   * So the lanes of a block's group each take ONE pixel of the next `group` pixels and walk that pixel's function over a WINDOW of stream
+//     offsets around where the pixel is expected to lie — expected from the lengths the same lanes resolved a batch earlier (the pixel one or
+//     a few rows up), wide enough for the spread those lengths showed — recording (offset, sampler state) of every sample start: a TRACK.
+//   * Then the true chain is threaded through the tracks pixel by pixel: the pixel's true start offset is looked up in its track; if it is
+//     not on it, the owner lane walks from the true start (slow path, one lane) until it lands on a track entry — from there on the track
+//     IS the chain, and the pixel's remaining samples and its end offset are read off the track.  A track that starts too late, ends too
+//     early or never meets the chain only costs slow samples; nothing a track holds is used unless the chain provably stands on it.
+//   * Pixels whose camera rays cannot reach the scene's bounding box (host: conservative test on the pixel's footprint) take exactly two draws
+//     per sample: their states are skip-aheads (rng_advance), no walk.
+// The result is bit-for-bit the serial chain (tests: test_reference_order_two_pass_equals_single_pass, the fuzzer's reference-order cases;
+// RL_CHAIN_SERIAL=1 keeps k_stream_chain as the cross-check).  What it buys: a block's serial work drops from 256 x spp samples to a few
+// samples per pixel, and the rest runs on full waves.
+#pragma once
+#include "rngjump.h"
+
+#ifndef RL_SPEC_WAVES
+#define RL_SPEC_WAVES 4
+#endif
+#ifndef RL_SPEC_WAVES_STREAMING
+#define RL_SPEC_WAVES_STREAMING 4
+#endif
+
+namespace rl {
+
+
+enum : unsigned { SM_IDLE = 0u, SM_PROBE, SM_WALK, SM_TRUTH, SM_EXT };
+enum : unsigned { SP_PROBE = 0u, SP_WALK, SP_RESOLVE, SP_DONE };
+
+RL_DEV Rng shfl_rng(const Rng& r, int src) {
+    Rng o;
+    o.s0 = __shfl(r.s0, src, 64); o.s1 = __shfl(r.s1, src, 64); o.s2 = __shfl(r.s2, src, 64); o.s3 = __shfl(r.s3, src, 64);
+    return o;
+}
+
+template <int MAT, bool MEDIUM, bool LDS_SCENE, int NUM>
+__global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES_STREAMING) k_stream_spec(RenderConst rc_arg, DeviceScene sc_arg, StackConf stc, SpecConf spc) {
+    const DeviceScene& sc0 = sc_arg;
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    SceneRecs recs;
+    float4* after_scene = smem;
+    if (LDS_SCENE) {
+        stage_scene_lds(sc0, smem, smem + lds_nodes_float4s(sc0.n_nodes));
+        recs.nodes = smem; recs.tris = smem + lds_nodes_float4s(sc0.n_nodes);
+        after_scene = smem + lds_scene_float4s(sc0.n_nodes, sc0.n_prims);
+    } else {
+        recs.nodes = reinterpret_cast<const float4*>(sc0.nodes);
+        recs.tris = reinterpret_cast<const float4*>(sc0.tris);
+    }
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const TravStackT<LDS_SCENE> stack = make_stack<LDS_SCENE>(stc, reinterpret_cast<unsigned*>(after_scene), tid);
+    RegState ps;
+#pragma unroll
+    for (int i = 0; i < F_COUNT; i++) ps.fv[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < U_COUNT; i++) ps.uv[i] = 0u;
+#pragma unroll
+    for (int i = 0; i < Q_COUNT; i++) ps.qv[i] = 0ull;
+    PU(U_PRIM) = 0xffffffffu;
+    PU(U_FLAGS) = 0u;
+
+    // ---- the group: `G` lanes of one wave own one block
+    const unsigned G = spc.group, lane = threadIdx.x & 63u, gl = lane & (G - 1u), gbase = lane & ~(G - 1u);
+    const unsigned long long gmask = (G >= 64u ? ~0ull : ((1ull << G) - 1ull)) << gbase;
+    const unsigned item = tid / G;
+    const bool have_block = item < rc_arg.n_owned;
+    const unsigned spp = rc_arg.spp;
+    unsigned bx = 0, by = 0, bw = 1, bh = 1;
+    if (have_block) block_geometry(rc_arg, rc_arg.owned_blocks[item], &bx, &by, &bw, &bh);
+    const unsigned c_begin = rc_arg.cursor_begin, c_end = have_block ? min(rc_arg.cursor_end, bw * bh) : 0u;
+    const unsigned pix_base = have_block ? rc_arg.block_item_base[item] : 0u;
+    Rng anc; anc.s0 = anc.s1 = anc.s2 = anc.s3 = 0ull;            // the block sampler where the batch begins
+    if (have_block && c_begin < c_end) {
+        if (c_begin == 0u) anc = rng_seed(rc_arg.block_seeds[rc_arg.owned_blocks[item]], rc_arg.seed_variant);      // the block's own sampler (mod.rs:371)
+        else { const unsigned long long* q = rc_arg.chain_states + 4 * (size_t)item; anc.s0 = q[0]; anc.s1 = q[1]; anc.s2 = q[2]; anc.s3 = q[3]; }
+    }
+    unsigned phase = (have_block && c_begin < c_end) ? SP_PROBE : SP_DONE;
+#define my_off (spc.trk_off + (size_t)tid * spc.cap)
+#define my_st (spc.trk_st + (size_t)tid * spc.cap * 2u)
+    const unsigned* const triv_bits = spc.trivial + (size_t)(have_block ? item : 0u) * 8u;
+
+    // ---- per-lane state.  Only what the traversal and shading code touches lives in registers; everything the bookkeeping between two samples
+    // needs is parked in LDS ([field][thread], conflict-free) — with it in VGPRs the kernel spilled into scratch inside the traversal loop
+    // (128 VGPRs + 16..74 spilled: 30 us per wave iteration against 3 us of issue time)
+    unsigned* const cold = reinterpret_cast<unsigned*>(after_scene) + 2 * 256 * stc.lds_levels + threadIdx.x;
+    enum { K_CUR_OFF, K_M, K_HI, K_CNT, K_SUM_N, K_SUM_N2, K_EST_L, K_EST_V, K_RES_I, K_RES_J, K_START_OFF, K_CP_I0, K_CP_J0, K_CP_K0, K_RES_OFF, K_RES_ST,
+           K_PIX = K_RES_ST + 8, K_C, K_Q0, K_ST_SPEC, K_ST_SLOW, K_ST_PROBE, K_COLD_COUNT };
+    static_assert(K_COLD_COUNT == kSpecColdWords, "LDS budget of k_stream_spec (host: wavefront.hip)");
+#define COLD(k) cold[(k) * 256]
+    unsigned& cur_off = COLD(K_CUR_OFF);          // stream offset (relative to the anchor) where the sample being walked started
+    unsigned& M = COLD(K_M);                      // track: entries 0..M-1 are walked samples, entry M the frontier
+    unsigned& hi = COLD(K_HI);                    // window end
+    unsigned& cnt = COLD(K_CNT); unsigned& sum_n = COLD(K_SUM_N); float& sum_n2 = reinterpret_cast<float&>(COLD(K_SUM_N2));     // draw statistics of this lane's walk
+    float& estL = reinterpret_cast<float&>(COLD(K_EST_L)); float& estV = reinterpret_cast<float&>(COLD(K_EST_V));   // predicted length of this lane's pixel in draws, its variance
+    unsigned& res_i = COLD(K_RES_I); unsigned& res_j = COLD(K_RES_J); unsigned& start_off = COLD(K_START_OFF);   // resolve: truth samples done, track pointer, true start offset of the pixel
+    unsigned& cp_i0 = COLD(K_CP_I0); unsigned& cp_j0 = COLD(K_CP_J0); unsigned& cp_k0 = COLD(K_CP_K0);        // samples cp_i0 .. cp_i0 + cp_k0 - 1 of the pixel are track entries cp_j0 ..
+    unsigned& res_off = COLD(K_RES_OFF);          // where the chain stands after this lane's pixel (offset; the state: K_RES_ST, 8 words)
+    unsigned& pix = COLD(K_PIX); unsigned& c = COLD(K_C);      // this lane's pixel in the batch: index into sample_states, block cursor
+    unsigned& q0 = COLD(K_Q0);                    // first block cursor of the current batch (group-uniform)
+    unsigned& st_spec = COLD(K_ST_SPEC); unsigned& st_slow = COLD(K_ST_SLOW); unsigned& st_probe = COLD(K_ST_PROBE);
+    for (int k = 0; k < K_COLD_COUNT; k++) COLD(k) = 0u;
+    q0 = c_begin;
+    // the block sampler where the batch begins: one copy per group, after the per-thread planes
+    unsigned long long* const ganc = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned*>(after_scene) + 2 * 256 * stc.lds_levels + K_COLD_COUNT * 256) + 4u * (threadIdx.x / G);
+    auto load_anc = [&]() -> Rng { Rng r; r.s0 = ganc[0]; r.s1 = ganc[1]; r.s2 = ganc[2]; r.s3 = ganc[3]; return r; };
+    auto store_anc = [&](const Rng& r) { ganc[0] = r.s0; ganc[1] = r.s1; ganc[2] = r.s2; ganc[3] = r.s3; };      // (every lane of the group writes the same value)
+    store_anc(anc);
+    // res_st of thread `t` of this workgroup (the owner reads its predecessor's)
+    auto load_res_st = [&](unsigned t) -> Rng {
+        const unsigned* q = reinterpret_cast<unsigned*>(after_scene) + 2 * 256 * stc.lds_levels + K_RES_ST * 256 + t;
+        Rng r;
+        r.s0 = (unsigned long long)q[0] | ((unsigned long long)q[256] << 32); r.s1 = (unsigned long long)q[512] | ((unsigned long long)q[768] << 32);
+        r.s2 = (unsigned long long)q[1024] | ((unsigned long long)q[1280] << 32); r.s3 = (unsigned long long)q[1536] | ((unsigned long long)q[1792] << 32);
+        return r;
+    };
+    auto store_res_st = [&](const Rng& r) {
+        COLD(K_RES_ST) = (unsigned)r.s0; COLD(K_RES_ST + 1) = (unsigned)(r.s0 >> 32); COLD(K_RES_ST + 2) = (unsigned)r.s1; COLD(K_RES_ST + 3) = (unsigned)(r.s1 >> 32);
+        COLD(K_RES_ST + 4) = (unsigned)r.s2; COLD(K_RES_ST + 5) = (unsigned)(r.s2 >> 32); COLD(K_RES_ST + 6) = (unsigned)r.s3; COLD(K_RES_ST + 7) = (unsigned)(r.s3 >> 32);
+    };
+    unsigned mode = SM_IDLE;
+    unsigned pxy = 0;                             // image position of this lane's pixel, x | y << 16
+    bool valid = false, triv = false, resolved = false, copied = false, have_est = false, planned = false;
+    unsigned nd = 0;                              // draws the sample being walked has taken so far
+    unsigned own = 0;                             // resolve: the group's lane whose pixel the chain stands in (group-uniform)
+    unsigned dummy = 0;
+    unsigned st_iter = 0;
+#ifdef RL_SPEC_TIMERS
+    unsigned long long tmr[6] = {0, 0, 0, 0, 0, 0}, e_lanes = 0, e_iters = 0, e_slow_iters = 0, tq;
+    const unsigned long long wave_t0 = wall_clock64();
+    unsigned long long it_t0 = 0, cyc_serial = 0, cyc_full = 0, n_serial = 0, n_full = 0, n_idle = 0; bool it_serial = false, it_traced = false;
+#define RL_ST0 { tq = __builtin_readcyclecounter(); }
+#define RL_ST1(K) { const unsigned long long t1 = __builtin_readcyclecounter(); tmr[K] += t1 - tq; tq = t1; }
+#else
+#define RL_ST0
+#define RL_ST1(K)
+#endif
+
+#define RL_SPEC_KERNARGS \
+        const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr(); \
+        asm volatile("" : "+s"(ka)); \
+        constexpr size_t sc_off = (sizeof(RenderConst) + alignof(DeviceScene) - 1) / alignof(DeviceScene) * alignof(DeviceScene); \
+        static_assert(sc_off == offsetof(PathKernargs, sc), "kernarg layout of k_stream_spec"); \
+        const DeviceScene& sc = *(const DeviceScene*)(ka + sc_off); \
+        const RenderConst& rc = *(const RenderConst*)ka;
+
+    // Path::from_sensor + Camera::generate for the sample that starts at `rng` (raygen_chain_slot without the cursor logic)
+    auto begin_sample = [&](const RenderConst& rc, const DeviceScene& sc, Rng rng) {
+        const float u = (float)(pxy & 0xffffu) + rng_next_f32(rng);
+        const float v = (float)(pxy >> 16) + rng_next_f32(rng);
+        nd = 2u;
+        const bool expand = (!rc.has_max || 1u < rc.max_depth);
+        if (!expand) { store_rng(ps, Q_R0, rng); PU(U_FLAGS) = ST_REGEN; return; }
+        store3(ps, F_DX, camera_direction(sc, u, v));
+        if (sc.medium.enabled) { PF(F_XI) = rng_next_f32(rng); nd++; }
+        store_rng(ps, Q_R0, rng);
+        PU(U_DEPTH) = 1u;
+        PU(U_FLAGS) = ST_RAY | (PREV_SENSOR << ST_PREV_SHIFT) | ST_PDF_SA;
+    };
+    auto load_entry_state = [&](unsigned k) -> Rng {
+        const ulonglong2 a = my_st[2u * k], b = my_st[2u * k + 1u];
+        Rng r; r.s0 = a.x; r.s1 = a.y; r.s2 = b.x; r.s3 = b.y;
+        return r;
+    };
+    // the chain has reached the end of this lane's pixel
+    auto finish_pixel = [&](unsigned off, const Rng& st) {
+        res_off = off; store_res_st(st);
+        resolved = true; mode = SM_IDLE;
+        PU(U_FLAGS) = 0u;
+        estL = (float)(off - start_off);
+        if (cnt >= 8u) { const float m = (float)sum_n / (float)cnt; estV = fmaxf(sum_n2 / (float)cnt - m * m, 0.0f) * (float)spp; }
+        have_est = true;
+    };
+    // the chain stands on track entry j with i samples of the pixel done: the track is the chain from here to its frontier
+    auto fast_forward = [&](const RenderConst& rc, const DeviceScene& sc, unsigned i, unsigned j) {
+        const unsigned k = min(spp - i, M - j);
+        cp_i0 = i; cp_j0 = j; cp_k0 = k;
+        const unsigned off = my_off[j + k];
+        const Rng st = load_entry_state(j + k);
+        i += k;
+        if (i == spp) { finish_pixel(off, st); return; }
+        // the track ends before the pixel does: the owner walks the rest
+        res_i = i; cur_off = off; mode = SM_EXT;
+        store_sample_state(rc, i, pix, st);
+        begin_sample(rc, sc, st);
+    };
+
+    for (;;) {
+        RL_SPEC_KERNARGS
+        st_iter++;
+#ifdef RL_SPEC_TIMERS
+        { const unsigned long long tn = wall_clock64();
+          if (it_t0) { if (!it_traced) n_idle++; else if (it_serial) { cyc_serial += tn - it_t0; n_serial++; } else { cyc_full += tn - it_t0; n_full++; } }
+          it_t0 = tn; }
+#endif
+        RL_ST0
+        // ---- A. a sample of a walking lane has ended (or its walk is about to start): bookkeeping by mode
+        bool fin_now = false;
+        {
+            const unsigned flags = PU(U_FLAGS);
+            if (mode != SM_IDLE && (flags & ST_REGEN)) {
+                const bool fresh = (flags & ST_FRESH) != 0u;
+                const Rng rng = load_rng(ps, Q_R0);            // the sampler after the sample (or where the walk starts)
+                if (mode == SM_PROBE) {
+                    if (!fresh) { cnt++; sum_n += nd; sum_n2 += (float)nd * (float)nd; st_probe++; }
+                    if (cnt >= spc.probe) { mode = SM_IDLE; PU(U_FLAGS) = 0u; }
+                    else begin_sample(rc, sc, rng);
+                } else if (mode == SM_WALK) {
+                    if (!fresh) { cnt++; sum_n += nd; sum_n2 += (float)nd * (float)nd; cur_off += nd; st_spec++; }
+                    my_off[M] = cur_off;
+                    my_st[2u * M] = make_ulonglong2(rng.s0, rng.s1); my_st[2u * M + 1u] = make_ulonglong2(rng.s2, rng.s3);
+                    if (cur_off >= hi || M + 1u >= spc.cap) { mode = SM_IDLE; PU(U_FLAGS) = 0u; }      // entry M is the frontier
+                    else { M++; begin_sample(rc, sc, rng); }
+                } else if (mode == SM_TRUTH) {
+                    res_i++; cur_off += nd; st_slow++;
+                    while (res_j <= M && my_off[res_j] < cur_off) res_j++;
+                    if (res_i == spp) { finish_pixel(cur_off, rng); fin_now = true; }
+                    else if (res_j <= M && my_off[res_j] == cur_off) { fast_forward(rc, sc, res_i, res_j); fin_now = resolved; }
+                    else { store_sample_state(rc, res_i, pix, rng); begin_sample(rc, sc, rng); }
+                } else {   // SM_EXT
+                    res_i++; cur_off += nd; st_slow++;
+                    if (res_i == spp) { finish_pixel(cur_off, rng); fin_now = true; }
+                    else { store_sample_state(rc, res_i, pix, rng); begin_sample(rc, sc, rng); }
+                }
+            }
+        }
+        if ((__ballot(fin_now) & gmask) != 0ull) own++;
+        RL_ST1(0)
+
+        // ---- B. group transitions, taken when no lane of the group is walking
+        const bool group_idle = (__ballot(mode != SM_IDLE) & gmask) == 0ull;
+        if (group_idle && phase == SP_PROBE) {
+            if (!planned) {
+                // a new batch: this lane's pixel
+                planned = true;
+                c = q0 + gl;
+                valid = c < c_end;
+                pxy = (bx + c % bw) | ((by + c / bw) << 16);
+                pix = pix_base + (c - c_begin);
+                triv = valid && ((triv_bits[(c >> 5) & 7u] >> (c & 31u)) & 1u) != 0u;
+                resolved = false; copied = false; cp_k0 = 0u; M = 0u;
+                cnt = 0u; sum_n = 0u; sum_n2 = 0.0f;
+                if (valid && !triv && !have_est && spc.probe > 0u) {
+                    // nothing to predict this pixel's length from: a short walk somewhere in the stream nobody else probes
+                    Rng r = load_anc(); rng_advance(r, (gl << 10) + 512u);
+                    store_rng(ps, Q_R0, r);
+                    PU(U_FLAGS) = ST_REGEN | ST_FRESH;
+                    mode = SM_PROBE;
+                }
+            }
+        }
+        const bool group_idle2 = (__ballot(mode != SM_IDLE) & gmask) == 0ull;
+        if (group_idle2 && phase == SP_PROBE && planned) {
+            // ---- the windows of the batch
+            if (valid && !triv && !have_est) {
+                const float m = cnt ? (float)sum_n / (float)cnt : 16.0f;
+                const float var = cnt ? fmaxf(sum_n2 / (float)cnt - m * m, 0.0f) : m * m;
+                estL = m * (float)spp;
+                estV = var * (float)spp * (1.0f + (float)spp / (float)(cnt ? cnt : 1u));      // spread of the pixel's length + error of this estimate of its mean
+                have_est = true;
+            }
+            cnt = 0u; sum_n = 0u; sum_n2 = 0.0f;
+            const float Lp = valid ? (triv ? 2.0f * (float)spp : estL) : 0.0f;
+            const float Vp = (valid && !triv) ? 2.0f * estV : 0.0f;        // the length it is predicted from is itself one draw of the same spread
+            float Ti = Lp, Si = Vp;
+            for (unsigned d = 1u; d < G; d <<= 1) {
+                const float t = __shfl_up(Ti, d, 64), s = __shfl_up(Si, d, 64);
+                if (gl >= d) { Ti += t; Si += s; }
+            }
+            const float T_ex = Ti - Lp, S_ex = Si - Vp;
+            const bool any_walk = (__ballot(valid && !triv) & gmask) != 0ull;
+            if (!any_walk) {
+                // every pixel of the batch looks past the scene: two draws per sample, the states are skip-aheads
+                const unsigned n_valid = min(G, c_end - q0);
+                Rng r = load_anc(); rng_advance(r, 2u * spp * min(gl, n_valid));
+                if (valid) for (unsigned s = 0; s < spp; s++) { store_sample_state(rc, s, pix, r); rng_next_u64(r); rng_next_u64(r); }
+                store_res_st(r); res_off = 0u;
+                resolved = true; copied = true;
+                own = G;
+            } else {
+                if (valid && !triv) {
+                    const float nbar = fmaxf(Lp / (float)spp, 1.0f);
+                    const unsigned nn = (unsigned)(nbar + 0.5f);
+                    const unsigned t_ex = (unsigned)fminf(T_ex + 0.5f, 4.0e9f);
+                    unsigned margin = gl == 0u ? 0u : (unsigned)fminf(spc.ks * __builtin_sqrtf(S_ex) + (float)spc.lead * nbar, 1.0e9f);
+                    margin = (margin + nn - 1u) / nn * nn;          // a pixel whose samples all take nn draws only meets the chain on its own residue
+                    margin = min(margin, t_ex / nn * nn);
+                    const unsigned lo = t_ex - margin;
+                    hi = (unsigned)fminf(T_ex + Lp + spc.ke * __builtin_sqrtf(Si) + 0.5f, 4.0e9f);
+                    Rng r = load_anc(); rng_advance(r, lo);
+                    store_rng(ps, Q_R0, r);
+                    PU(U_FLAGS) = ST_REGEN | ST_FRESH;
+                    cur_off = lo;
+                    mode = SM_WALK;
+                }
+                own = 0u;
+            }
+            phase = any_walk ? SP_WALK : SP_RESOLVE;
+        } else if (group_idle2 && phase == SP_WALK) {
+            phase = SP_RESOLVE;
+        }
+
+        RL_ST1(1)
+        // ---- C. thread the chain through the tracks: owners that can finish at once do so back to back
+        if (__ballot(phase == SP_RESOLVE && own < G) != 0ull) {
+            for (;;) {
+                bool fin = false;
+                if (phase == SP_RESOLVE && own < G && gl == own && mode == SM_IDLE && !resolved) {
+                    // where the chain stands: after the predecessor's pixel (its parked res_off / res_st), or at the anchor
+                    unsigned b_off = 0u; Rng b_st;
+                    if (own == 0u) b_st = load_anc();
+                    else { b_off = cold[K_RES_OFF * 256 - 1]; b_st = load_res_st(threadIdx.x - 1u); }
+                    start_off = b_off;
+                    if (!valid) { res_off = b_off; store_res_st(b_st); resolved = true; copied = true; fin = true; }       // past the block's end: hand the chain on
+                    else if (triv) {
+                        my_st[0] = make_ulonglong2(b_st.s0, b_st.s1); my_st[1] = make_ulonglong2(b_st.s2, b_st.s3);      // the copy-out steps through the pixel from here
+                        Rng r = b_st; rng_advance(r, 2u * spp);
+                        res_off = b_off + 2u * spp; store_res_st(r); resolved = true; fin = true;
+                    } else {
+                        unsigned lo = 0u, hi_e = M + 1u;            // entries 0 .. M
+                        while (lo < hi_e) { const unsigned mid = (lo + hi_e) >> 1; if (my_off[mid] < b_off) lo = mid + 1u; else hi_e = mid; }
+                        res_j = lo;
+                        if (lo <= M && my_off[lo] == b_off) { fast_forward(rc, sc, 0u, lo); fin = resolved; }
+                        else {
+                            // not on the track: walk from the true start until the track is met (or the pixel ends)
+                            res_i = 0u; cur_off = b_off; mode = SM_TRUTH;
+                            store_sample_state(rc, 0u, pix, b_st);
+                            begin_sample(rc, sc, b_st);
+                        }
+                    }
+                }
+                const unsigned long long fm = __ballot(fin);
+                if ((fm & gmask) != 0ull) own++;
+                if (fm == 0ull) break;
+            }
+        }
+
+        RL_ST1(2)
+        // ---- D. the batch is threaded: copy the track entries the chain ran over into sample_states, then the next batch
+        if (__ballot(phase == SP_RESOLVE && own >= G) != 0ull) {
+            if (phase == SP_RESOLVE && own >= G) {
+                if (valid && !copied) {
+                    if (triv) {
+                        Rng r = load_entry_state(0u);
+                        for (unsigned s = 0; s < spp; s++) { store_sample_state(rc, s, pix, r); rng_next_u64(r); rng_next_u64(r); }
+                    } else {
+                        for (unsigned t = 0; t < cp_k0; t++) {
+                            const ulonglong2 a = my_st[2u * (cp_j0 + t)], b = my_st[2u * (cp_j0 + t) + 1u];
+                            ulonglong2* q = reinterpret_cast<ulonglong2*>(rc.sample_states + 4 * ((size_t)(cp_i0 + t) * rc.n_state_pixels + pix));
+                            q[0] = a; q[1] = b;
+                        }
+                    }
+                    copied = true;
+                }
+            }
+            if (phase == SP_RESOLVE && own >= G) {
+                const Rng last = load_res_st(threadIdx.x - gl + G - 1u);      // the chain after the group's last pixel = the next batch's anchor
+                store_anc(last);
+                q0 += G;
+                planned = false;
+                own = 0u;
+                if (q0 >= c_end) {
+                    if (gl == 0u) { unsigned long long* q = rc.chain_states + 4 * (size_t)item; q[0] = last.s0; q[1] = last.s1; q[2] = last.s2; q[3] = last.s3; }   // the next chunk resumes here
+                    phase = SP_DONE;
+                } else phase = SP_PROBE;
+            }
+        }
+        RL_ST1(3)
+        if (__ballot(phase != SP_DONE) == 0ull) break;
+
+        // ---- E. one vertex of every walking lane
+#ifdef RL_SPEC_TIMERS
+        { const unsigned long long rm = __ballot((PU(U_FLAGS) & ST_RAY) != 0u); it_traced = rm != 0ull; it_serial = __ballot(mode == SM_WALK || mode == SM_PROBE) == 0ull; if (rm) { e_iters++; e_lanes += __popcll(rm); if (__ballot(mode == SM_WALK || mode == SM_PROBE) == 0ull) e_slow_iters++; } }
+#endif
+        if (PU(U_FLAGS) & ST_RAY) {
+            extend_slot(sc, recs, stack, ps);
+            shade_slot<MAT, MEDIUM, LIGHTS_AREA_ONLY, true>(rc, sc, ps, PU(U_FLAGS), dummy, nd, dummy, dummy);
+        }
+#ifdef RL_SPEC_TIMERS
+        { const unsigned long long rm = __ballot(true); (void)rm; }
+        RL_ST1(4)
+#endif
+    }
+#undef RL_SPEC_KERNARGS
+#undef my_off
+#undef my_st
+#undef COLD
+#ifdef RL_SPEC_TIMERS
+    if (spc.stats && lane == 0u) { { unsigned long long* w = spc.stats + 16 + 8 * (tid >> 6); w[0] = wave_t0; w[1] = wall_clock64(); w[2] = n_full; w[3] = n_serial; w[4] = cyc_full; w[5] = cyc_serial; w[6] = n_idle; w[7] = st_slow; }
+        for (int k = 0; k < 5; k++) atomicAdd(&spc.stats[4 + k], tmr[k]); atomicAdd(&spc.stats[9], e_lanes); atomicAdd(&spc.stats[10], e_iters); atomicAdd(&spc.stats[11], e_slow_iters); }
+#endif
+    if (spc.stats) {
+        unsigned a = st_spec, b = st_slow, p = st_probe;
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); p += __shfl_down(p, off, 64); }
+        if (lane == 0u) { atomicAdd(&spc.stats[0], (unsigned long long)a); atomicAdd(&spc.stats[1], (unsigned long long)b); atomicAdd(&spc.stats[2], (unsigned long long)p); atomicAdd(&spc.stats[3], (unsigned long long)st_iter); }
+    }
+}
+
+template <bool LDS_SCENE, int MAT>
+static void launch_spec_mat(bool medium, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc, const SpecConf& spc) {
+    if (medium) hipLaunchKernelGGL((k_stream_spec<MAT, true, LDS_SCENE, 0>), grid, block, lds_bytes, st, rc, ds, stc, spc);
+    else hipLaunchKernelGGL((k_stream_spec<MAT, false, LDS_SCENE, 0>), grid, block, lds_bytes, st, rc, ds, stc, spc);
+}
+template <bool LDS_SCENE>
+static void launch_spec_impl(int mat, bool medium, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc, const SpecConf& spc) {
+    switch (mat) {
+        case BSDF_DIFFUSE: launch_spec_mat<LDS_SCENE, BSDF_DIFFUSE>(medium, grid, block, lds_bytes, st, rc, ds, stc, spc); break;
+        case BSDF_PHONG: launch_spec_mat<LDS_SCENE, BSDF_PHONG>(medium, grid, block, lds_bytes, st, rc, ds, stc, spc); break;
+        case BSDF_METAL: launch_spec_mat<LDS_SCENE, BSDF_METAL>(medium, grid, block, lds_bytes, st, rc, ds, stc, spc); break;
+        case BSDF_GLASS: launch_spec_mat<LDS_SCENE, BSDF_GLASS>(medium, grid, block, lds_bytes, st, rc, ds, stc, spc); break;
+        case -1: launch_spec_mat<LDS_SCENE, -1>(medium, grid, block, lds_bytes, st, rc, ds, stc, spc); break;
+        default: launch_spec_mat<LDS_SCENE, BSDF_SUBSTRATE>(medium, grid, block, lds_bytes, st, rc, ds, stc, spc); break;
+    }
+}
+
+}  // namespace rl

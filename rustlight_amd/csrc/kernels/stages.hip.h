@@ -403,7 +403,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
             const bool smooth = !is_volume && mat->smooth;
             bool shadow = false;
             if (DRAWS_ONLY) {
-                if (use_light && !smooth) { rng_next_u64(rng); rng_next_u64(rng); rng_next_u64(rng); rng_next_u64(rng); }   // the light sample's four draws
+                if (use_light && !smooth) { rng_next_u64(rng); rng_next_u64(rng); rng_next_u64(rng); rng_next_u64(rng); n_draws += 4; }   // the light sample's four draws
             } else
             if (use_light && !smooth) {
                 float a = rng_next_f32(rng);

@@ -29,13 +29,16 @@
 //   trace.hip.h      BVH2 traversal;   shading.hip.h  BSDFs, emitters, light tree, medium;   devmath.hip.h  f32 contract, RNG
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "common.hip.h"
+#include "rngjump.h"
 #include "fused.hip.h"     // RL_COOP_FETCH (LDS budget of the persistent kernel); the kernel template is not instantiated here
 #include "../host/scene.h"
 #include "wavefront.h"
@@ -270,6 +273,12 @@ struct rl_context {
     float* d_sample_buf = nullptr; size_t sample_buf_capacity = 0;   // sample-parallel pixels: [spp][pixel item][3]
     unsigned long long* d_sample_states = nullptr; size_t sample_states_capacity = 0;   // reference-order streams, two passes: [spp][chunk pixel][4]
     unsigned long long* d_chain_states = nullptr; size_t chain_states_capacity = 0;     // [owned block][4]
+    // k_stream_spec (spec.hip.h): per-lane tracks of the speculative first pass, the trivial-pixel masks and its counters
+    unsigned* d_trk_off = nullptr; size_t trk_off_capacity = 0;
+    ulonglong2* d_trk_st = nullptr; size_t trk_st_capacity = 0;
+    unsigned* d_trivial = nullptr; size_t trivial_capacity = 0;
+    uint64_t trivial_key = ~0ull;         // (shard index, shard count, sensor expanded?) the masks on the device were computed for
+    unsigned long long* d_spec_stats = nullptr; size_t spec_stats_capacity = 0;
     std::vector<hipEvent_t> events;
     BvhBuild bvh_dump;                // kept for rl_debug_bvh
 };
@@ -419,7 +428,7 @@ extern "C" void rl_context_destroy(rl_context* ctx) {
     for (void* p : ctx->allocs) hipFree(p);
     void* scratch[] = {ctx->pool.f, ctx->pool.u, ctx->pool.q, ctx->d_owned, ctx->d_item_base, ctx->d_block_seeds, ctx->d_item_seed,
                        ctx->d_item_pixel, ctx->d_queues, ctx->d_qcounts, ctx->d_out, ctx->d_counters, ctx->d_partials, ctx->d_overflow, ctx->d_sample_buf,
-                       ctx->d_sample_states, ctx->d_chain_states};
+                       ctx->d_sample_states, ctx->d_chain_states, ctx->d_trk_off, ctx->d_trk_st, ctx->d_trivial, ctx->d_spec_stats};
     for (void* p : scratch) if (p) hipFree(p);
     if (ctx->h_counters) hipHostFree(ctx->h_counters);
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
@@ -467,6 +476,87 @@ static int stack_conf(rl_context* ctx, size_t n_threads, StackConf* out) {
         out->overflow = ctx->d_overflow;
     }
     return RL_OK;
+}
+
+// ---- k_stream_spec: pixels whose camera samples take exactly two draws (Path::from_sensor's jitter) whatever the stream holds.
+// Without a medium a camera ray that misses the scene ends its path at once (path.rs:152-166), and every camera ray of a pixel misses when the
+// scene's bounding box lies outside the pyramid spanned by the camera position and the pixel's footprint [ix, ix+1) x [iy, iy+1).  The rays
+// through a rectangle of the image plane (Camera::generate is a projective map of the raster position, camera.rs:81-91) fill the convex cone of its four
+// corner rays; a box that lies wholly beyond ONE side plane of that cone touches none of them.  Evaluated in f64 on a footprint grown by a quarter
+// pixel and a box grown by 1e-3 of its size — orders of magnitude more than the f32 rounding of the device's ray generation and slab / triangle
+// tests — so a pixel flagged here cannot produce a hit on the device.  Bit c of words [8 b .. 8 b + 7]: block cursor c of owned block b.
+static void trivial_pixel_masks(const rl_context* ctx, const rl_path_params* params, const std::vector<unsigned>& owned, size_t nby, std::vector<unsigned>* out) {
+    const uint32_t W = ctx->width, H = ctx->height;
+    out->assign(owned.size() * 8, 0u);
+    const bool expand = !params->has_max_depth || 1u < params->max_depth;
+    auto all_of_block = [&](size_t j, unsigned npx) { for (unsigned c = 0; c < npx; c++) (*out)[j * 8 + (c >> 5)] |= 1u << (c & 31u); };
+    if (!expand) {      // the sensor vertex is never expanded: two draws per sample everywhere
+        for (size_t j = 0; j < owned.size(); j++) {
+            const unsigned bx = (unsigned)(owned[j] / nby) * 16u, by = (unsigned)(owned[j] % nby) * 16u;
+            all_of_block(j, std::min(16u, W - bx) * std::min(16u, H - by));
+        }
+        return;
+    }
+    if (ctx->ds.medium.enabled || getenv("RL_SPEC_NO_TRIVIAL")) return;      // Edge::from_ray samples the medium on a miss too: no shortcut
+    const DeviceScene& ds = ctx->ds;
+    const bool empty = ds.root == RL_CHILD_NONE || ds.n_prims == 0;
+    double lo[3], hi[3];
+    for (int k = 0; k < 3; k++) {
+        lo[k] = ds.root_min[k]; hi[k] = ds.root_max[k];
+        if (!empty && !(std::isfinite(lo[k]) && std::isfinite(hi[k]) && lo[k] <= hi[k])) return;      // hostile geometry: no shortcut
+        const double grow = 1e-3 * (hi[k] - lo[k]) + 1e-4 * std::max(1.0, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
+        lo[k] -= grow; hi[k] += grow;
+    }
+    const float* m = ds.camera.sample_to_camera; const float* tw = ds.camera.to_world;
+    const double cam[3] = {ds.camera.position[0], ds.camera.position[1], ds.camera.position[2]};
+    // direction of the ray through raster position (u, v), not normalised; false when the projective map degenerates there
+    auto ray_dir = [&](double u, double v, double* d) -> bool {
+        const double sx = u / (double)W, sy = v / (double)H;
+        const double hx = m[0] * sx + m[4] * sy + m[12], hy = m[1] * sx + m[5] * sy + m[13], hz = m[2] * sx + m[6] * sy + m[14], hw = m[3] * sx + m[7] * sy + m[15];
+        if (!(std::fabs(hw) > 1e-12) || !std::isfinite(hx + hy + hz + hw)) return false;
+        const double nx = hx / hw, ny = hy / hw, nz = hz / hw;
+        d[0] = tw[0] * nx + tw[4] * ny + tw[8] * nz; d[1] = tw[1] * nx + tw[5] * ny + tw[9] * nz; d[2] = tw[2] * nx + tw[6] * ny + tw[10] * nz;
+        d[3] = hw;
+        const double len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        if (!(len > 1e-30) || !std::isfinite(len)) return false;
+        d[0] /= len; d[1] /= len; d[2] /= len;
+        return true;
+    };
+    // true when no ray through the raster rectangle [u0, u1] x [v0, v1] can meet the grown box
+    auto misses = [&](double u0, double v0, double u1, double v1) -> bool {
+        if (empty) return true;
+        double d[4][4];
+        const double us[4] = {u0, u1, u1, u0}, vs[4] = {v0, v0, v1, v1};
+        for (int k = 0; k < 4; k++) if (!ray_dir(us[k], vs[k], d[k])) return false;
+        for (int k = 1; k < 4; k++) if ((d[k][3] > 0) != (d[0][3] > 0)) return false;       // the footprint crosses the map's pole
+        for (int k = 0; k < 4; k++) {
+            const double* a = d[k]; const double* b = d[(k + 1) & 3]; const double* o = d[(k + 2) & 3];
+            double n[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+            const double nl = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            if (!(nl > 1e-14)) return false;
+            double inside = (n[0] * o[0] + n[1] * o[1] + n[2] * o[2]) / nl;          // the cone lies on the side of the opposite corner
+            if (!(std::fabs(inside) > 1e-9)) return false;
+            const double sgn = inside > 0 ? 1.0 : -1.0;
+            bool all_out = true;
+            for (int cbit = 0; cbit < 8 && all_out; cbit++) {
+                const double p[3] = {((cbit & 1) ? hi[0] : lo[0]) - cam[0], ((cbit & 2) ? hi[1] : lo[1]) - cam[1], ((cbit & 4) ? hi[2] : lo[2]) - cam[2]};
+                const double pl = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+                const double s = sgn * (n[0] * p[0] + n[1] * p[1] + n[2] * p[2]) / nl;
+                if (!(s < -1e-7 * pl - 1e-12)) all_out = false;
+            }
+            if (all_out) return true;
+        }
+        return false;
+    };
+    for (size_t j = 0; j < owned.size(); j++) {
+        const unsigned bx = (unsigned)(owned[j] / nby) * 16u, by = (unsigned)(owned[j] % nby) * 16u;
+        const unsigned bw = std::min(16u, W - bx), bh = std::min(16u, H - by);
+        if (misses(bx - 0.25, by - 0.25, bx + bw + 0.25, by + bh + 0.25)) { all_of_block(j, bw * bh); continue; }
+        for (unsigned c = 0; c < bw * bh; c++) {
+            const double x = bx + c % bw, y = by + c / bw;
+            if (misses(x - 0.25, y - 0.25, x + 1.25, y + 1.25)) (*out)[j * 8 + (c >> 5)] |= 1u << (c & 31u);
+        }
+    }
 }
 
 extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, const uint64_t* block_seeds, size_t n_blocks, float* out_rgb,
@@ -700,6 +790,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         return RL_OK;
     };
     double ms_fused = 0.0, ms_chain = 0.0;
+    unsigned long long spec_stat[3] = {0, 0, 0}; unsigned spec_group = 0;     // k_stream_spec's counters (rl_render_stats.reserved)
     const size_t lds_fused = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + kFusedColdBytes + ((ctx->lds_scene || RL_COOP_FETCH != 1) ? 0 : (size_t)4 * kCoopStageFloat4s * sizeof(float4));
     auto launch_fused = [&](const RenderConst& rcl, dim3 grid) {
         (ctx->lds_scene ? (fast_math ? launch_fused_lds_fast : launch_fused_lds) : (fast_math ? launch_fused_stream_fast : launch_fused_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, ctx->area_lights_only, grid, block, lds_fused, st, rcl, ds, stc);
@@ -717,6 +808,53 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         if (treelets) stc_c.pre_group = 1 << plan_chain.item_shift;
         const size_t lds_chain = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + (treelets ? (size_t)(256 / stc_c.pre_group) * (72 + (ctx->ds.stack_depth + 1) / 2) * 16
                                  : (stc_c.pre_group ? (size_t)(256 / stc_c.pre_group) * ((size_t)ctx->ds.n_nodes * 32 + (size_t)ctx->ds.n_prims * 8) : 0));
+        // ---- k_stream_spec (spec.hip.h): the chains with every lane busy — exact build; RL_CHAIN_SERIAL=1 keeps the one-lane-per-block walk (the cross-check)
+        bool spec = !fast_math && !getenv("RL_CHAIN_SERIAL");
+        SpecConf spc{};
+        unsigned spec_threads = 0;
+        unsigned long long spec_totals[16] = {0};
+        if (spec) {
+            // lanes per block: the fewest that still give every SIMD about two waves (a wider batch looks further ahead, so its windows are wider)
+            unsigned group = 16u;
+            while (group < 64u && (size_t)owned.size() * group < (size_t)cus * 4u * 2u * 64u) group <<= 1;
+            if (getenv("RL_SPEC_GROUP")) { const int g = atoi(getenv("RL_SPEC_GROUP")); if (g == 16 || g == 32 || g == 64) group = (unsigned)g; }
+            spc.group = group;
+            spc.cap = std::max(96u, std::min(3u * params->spp + 64u, 1u << 20));
+            if (getenv("RL_SPEC_CAP")) spc.cap = std::max(4u, (unsigned)atoi(getenv("RL_SPEC_CAP")));
+            spc.probe = getenv("RL_SPEC_PROBE") ? (unsigned)atoi(getenv("RL_SPEC_PROBE")) : std::min(32u, std::max(4u, params->spp));
+            spc.lead = getenv("RL_SPEC_LEAD") ? (unsigned)atoi(getenv("RL_SPEC_LEAD")) : 24u;
+            spc.ks = getenv("RL_SPEC_KS") ? (float)atof(getenv("RL_SPEC_KS")) : 1.65f;
+            spc.ke = getenv("RL_SPEC_KE") ? (float)atof(getenv("RL_SPEC_KE")) : 1.65f;
+            spec_threads = (unsigned)((((size_t)owned.size() * group) + 255u) / 256u * 256u);
+            // the tracks: 36 B per entry; when they do not fit what the device has free the serial walk runs instead
+            const size_t need = (size_t)spec_threads * spc.cap * 36u;
+            size_t free_b = 0, total_b = 0;
+            const size_t have = ctx->trk_off_capacity * 4u + ctx->trk_st_capacity * 16u;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+            if (need > have && need - have > free_b / 2u) spec = false;
+            if (spec && (ensure(&ctx->d_trk_off, &ctx->trk_off_capacity, (size_t)spec_threads * spc.cap) != RL_OK ||
+                         ensure(&ctx->d_trk_st, &ctx->trk_st_capacity, (size_t)spec_threads * spc.cap * 2u) != RL_OK)) { (void)hipGetLastError(); spec = false; }
+        }
+        if (spec) {
+            // the masks depend on the camera, the scene bounds and the shard only: computed once per context and shard
+            const bool expand = !params->has_max_depth || 1u < params->max_depth;
+            const uint64_t key = ((uint64_t)params->shard_index << 33) | ((uint64_t)shard_count << 1) | (expand ? 1u : 0u);
+            if (key != ctx->trivial_key || ctx->trivial_capacity < owned.size() * 8 || getenv("RL_SPEC_NO_TRIVIAL")) {
+                std::vector<unsigned> masks;
+                trivial_pixel_masks(ctx, params, owned, nby, &masks);
+                if ((rcode = ensure(&ctx->d_trivial, &ctx->trivial_capacity, masks.size())) != RL_OK) return rcode;
+                HIP_OK(hipMemcpyAsync(ctx->d_trivial, masks.data(), masks.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
+                HIP_OK(hipStreamSynchronize(st));        // (`masks` is a local)
+                ctx->trivial_key = getenv("RL_SPEC_NO_TRIVIAL") ? ~0ull : key;
+            }
+            if ((rcode = ensure(&ctx->d_spec_stats, &ctx->spec_stats_capacity, 16 + 8 * (size_t)(spec_threads / 64u))) != RL_OK) return rcode;
+            HIP_OK(hipMemsetAsync(ctx->d_spec_stats, 0, 16 * sizeof(unsigned long long), st));
+            spc.trk_off = ctx->d_trk_off; spc.trk_st = ctx->d_trk_st; spc.trivial = ctx->d_trivial;
+            spc.stats = (stats || getenv("RL_SPEC_STATS")) ? ctx->d_spec_stats : nullptr;
+        }
+        StackConf stc_s = stc;
+        if (spec && (rcode = stack_conf(ctx, std::max<size_t>((size_t)((P + 255) / 256) * 256, spec_threads), &stc_s)) != RL_OK) return rcode;
+        if (spec) stc = stc_s;      // (one overflow buffer serves both passes: the stride is the larger launch)
         for (const Chunk& ch : chunks) {
             // ---- pass 1: the chains
             HIP_OK(hipMemcpyAsync(ctx->d_item_base, ch.base.data(), ch.base.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
@@ -726,6 +864,8 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             ra.n_state_pixels = ch.n_pix; ra.cursor_begin = ch.c0; ra.cursor_end = ch.c1;
             hipLaunchKernelGGL(k_chunk_pixels, dim3(((unsigned)owned.size() + 63) / 64), dim3(64), 0, st, ra);
             if (timing) hipEventRecord(ctx->events[0], st);
+            if (spec) (ctx->lds_scene ? launch_spec_lds : launch_spec_stream)(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, dim3(spec_threads / 256u), block, traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + (size_t)kSpecColdWords * 256 * 4 + (256 / 16) * 32, st, ra, ds, stc, spc);
+            else
             (ctx->lds_scene ? (fast_math ? launch_chain_lds_fast : launch_chain_lds) : (fast_math ? launch_chain_stream_fast : launch_chain_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, dim3((plan_chain.P + 255) / 256), block, lds_chain, st, ra, ds, stc_c);
             if (timing) hipEventRecord(ctx->events[1], st);
             // ---- pass 2: every camera sample of the chunk from its recorded state, per-pixel work items
@@ -752,6 +892,26 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         }
         dump_stage_timers(ctx->lds_scene);
         if (ctx->lds_scene) dump_chain_timers_lds(); else dump_chain_timers_stream();     // dev-only build
+        if (spec && spc.stats) {
+            HIP_OK(hipMemcpy(spec_totals, ctx->d_spec_stats, sizeof(spec_totals), hipMemcpyDeviceToHost));
+            spec_group = spc.group; spec_stat[0] = spec_totals[0]; spec_stat[1] = spec_totals[1]; spec_stat[2] = spec_totals[2];
+            if (getenv("RL_SPEC_STATS")) std::fprintf(stderr, "[spec] group %u cap %u: %llu speculative + %llu serial + %llu probe samples for %llu camera samples (%.2f x, %.2f serial per pixel), %llu wave iterations\n",
+                spc.group, spc.cap, spec_totals[0], spec_totals[1], spec_totals[2], (unsigned long long)n_pixels * params->spp,
+                (double)(spec_totals[0] + spec_totals[1] + spec_totals[2]) / std::max(1.0, (double)n_pixels * params->spp), (double)spec_totals[1] / std::max(1u, n_pixels), spec_totals[3]);
+            if (getenv("RL_SPEC_WAVE_TIMES") && spec_totals[8]) {     // dev build: lifetime of every wave (100 MHz clock)
+                std::vector<unsigned long long> wt(8 * (size_t)(spec_threads / 64u));
+                HIP_OK(hipMemcpy(wt.data(), ctx->d_spec_stats + 16, wt.size() * 8, hipMemcpyDeviceToHost));
+                FILE* f = std::fopen(getenv("RL_SPEC_WAVE_TIMES"), "w");
+                if (f) { unsigned long long t0 = ~0ull; for (size_t w = 0; w < wt.size() / 8; w++) if (wt[8 * w]) t0 = std::min(t0, wt[8 * w]);
+                         for (size_t w = 0; w < wt.size() / 8; w++) std::fprintf(f, "%zu %.3f %.3f %llu %llu %.3f %.3f %llu %llu\n", w, (wt[8 * w] - t0) * 1e-5, (wt[8 * w + 1] - t0) * 1e-5, wt[8 * w + 2], wt[8 * w + 3], wt[8 * w + 4] * 1e-5, wt[8 * w + 5] * 1e-5, wt[8 * w + 6], wt[8 * w + 7]); std::fclose(f); }
+            }
+            if (getenv("RL_SPEC_STATS") && spec_totals[8]) {     // dev build (-DRL_SPEC_TIMERS)
+                const double tot = (double)(spec_totals[4] + spec_totals[5] + spec_totals[6] + spec_totals[7] + spec_totals[8]);
+                std::fprintf(stderr, "[spec] cycles: bookkeeping %.1f %%, plan %.1f %%, thread %.1f %%, copy-out %.1f %%, extend+shade %.1f %%; %.1f lanes per traced iteration, %.1f %% of the traced iterations serial only, %.0f cycles per wave iteration\n",
+                    100.0 * spec_totals[4] / tot, 100.0 * spec_totals[5] / tot, 100.0 * spec_totals[6] / tot, 100.0 * spec_totals[7] / tot, 100.0 * spec_totals[8] / tot,
+                    (double)spec_totals[9] / std::max<double>(1.0, (double)spec_totals[10]), 100.0 * spec_totals[11] / std::max<double>(1.0, (double)spec_totals[10]), tot / std::max<double>(1.0, (double)spec_totals[3]));
+            }
+        }
         iterations = chunks.size();
     } else if (fused) {
         if (timing) hipEventRecord(ctx->events[0], st);
@@ -826,7 +986,31 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         stats->ms_other = ms_fused;   // the persistent fused kernel (pipeline 2)
         stats->ms_prepass = ms_chain;  // k_stream_chain (reference-order streams, first pass)
         stats->n_extend_launches = n_extend;
+        stats->reserved[0] = spec_stat[0]; stats->reserved[1] = spec_stat[1]; stats->reserved[2] = spec_stat[2]; stats->reserved[3] = spec_group;   // speculative / serial / probe samples of k_stream_spec, its lanes per block (0: the serial chain ran)
     }
+    return RL_OK;
+}
+
+// test hook: rng_advance (rngjump.h) on the device — states_out[i] = the sampler states_in[i] after counts[i] more draws
+namespace rl {
+__global__ void k_debug_rng_advance(unsigned n, const unsigned long long* in, const unsigned* counts, unsigned long long* out) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    Rng r; r.s0 = r.s1 = r.s2 = r.s3 = 0ull;
+    if (i < n) { r.s0 = in[4 * i]; r.s1 = in[4 * i + 1]; r.s2 = in[4 * i + 2]; r.s3 = in[4 * i + 3]; }
+    rng_advance(r, i < n ? counts[i] : 0u);
+    if (i < n) { out[4 * i] = r.s0; out[4 * i + 1] = r.s1; out[4 * i + 2] = r.s2; out[4 * i + 3] = r.s3; }
+}
+}  // namespace rl
+extern "C" int rl_debug_rng_advance(int device, size_t n, const uint64_t* states_in, const uint32_t* counts, uint64_t* states_out) {
+    if (!states_in || !counts || !states_out || n == 0 || n > (1u << 24)) return RL_ERR_INVALID_ARGUMENT;
+    HIP_OK(hipSetDevice(device));
+    unsigned long long *d_in = nullptr, *d_out = nullptr; unsigned* d_c = nullptr;
+    HIP_OK(hipMalloc((void**)&d_in, n * 32)); HIP_OK(hipMalloc((void**)&d_out, n * 32)); HIP_OK(hipMalloc((void**)&d_c, n * 4));
+    HIP_OK(hipMemcpy(d_in, states_in, n * 32, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(d_c, counts, n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rl::k_debug_rng_advance, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, (unsigned)n, d_in, d_c, d_out);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpy(states_out, d_out, n * 32, hipMemcpyDeviceToHost));
+    hipFree(d_in); hipFree(d_out); hipFree(d_c);
     return RL_OK;
 }
 
