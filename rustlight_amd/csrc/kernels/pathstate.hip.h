@@ -62,13 +62,15 @@ static constexpr size_t kSampleBufBudget = (size_t)16 << 30;   // bytes of HBM t
 // traversal stack configuration (see TravStack)
 struct StackConf { int lds_levels; int* overflow; size_t overflow_stride; int pre_group; };   // pre_group: k_stream_chain on tiny LDS scenes — lanes per chain that precompute its ray's records (0: off; trace.hip.h: precompute_records)
 
-static constexpr int kSpecColdWords = 29;      // k_stream_spec: words of per-thread state parked in LDS, + 4 u64 per group (host: LDS bytes of the launch)
+static constexpr int kSpecColdWords = 33;      // k_stream_spec: words of per-thread state parked in LDS, + 4 u64 per group (host: LDS bytes of the launch)
 // k_stream_spec (spec.hip.h): launch configuration and scratch of the speculative first pass of reference-order streams
 struct SpecConf {
     unsigned group;              // lanes per 16x16 block: 16, 32 or 64 (a batch = `group` consecutive pixels of the block, one per lane)
+    unsigned sub;                // lanes per pixel: 1, 2, 4 or 8 (the pixel's window is walked in `sub` segments); group / sub pixels per batch
     unsigned cap;                // entries a lane's track can hold
     unsigned probe;              // samples of the estimate probe (lanes that have no resolved pixel to go by: the first batch)
     unsigned lead;               // samples of lead-in before a window (a track needs a few samples to fall in with the chain)
+    float serial_ratio;          // a batch whose samples take more than spp / serial_ratio draws on average is walked serially (0: never)
     float ks, ke;                // window margins in standard deviations of the predicted start / end offset
     unsigned* trk_off;           // [thread][cap] stream offsets of the samples a lane walked, relative to the batch's anchor, ascending
     ulonglong2* trk_st;          // [thread][cap][2] the sampler state at each of them

@@ -18,6 +18,10 @@
 //     early or never meets the chain only costs slow samples; nothing a track holds is used unless the chain provably stands on it.
 //   * Pixels whose camera rays cannot reach the scene's bounding box (host: conservative test on the pixel's footprint) take exactly two draws
 //     per sample: their states are skip-aheads (rng_advance), no walk.
+//   * A pixel's window can be cut into `sub` segments walked by `sub` lanes (one wave then holds fewer pixels per batch: a shorter look-ahead,
+//     narrower windows, and `sub` times fewer samples per lane): each lane walks its segment and on into the next one for a lead-in's length,
+//     then finds where its walk first stands on an entry of the next lane's walk (LINK) — from there the two are the same walk.  The chain follows
+//     a pixel's sub-tracks link by link; a missing link is bridged by the slow path.
 // The result is bit-for-bit the serial chain (tests: test_reference_order_two_pass_equals_single_pass, the fuzzer's reference-order cases;
 // RL_CHAIN_SERIAL=1 keeps k_stream_chain as the cross-check).  What it buys: a block's serial work drops from 256 x spp samples to a few
 // samples per pixel, and the rest runs on full waves.
@@ -57,7 +61,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
         recs.nodes = reinterpret_cast<const float4*>(sc0.nodes);
         recs.tris = reinterpret_cast<const float4*>(sc0.tris);
     }
-    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, tid0 = blockIdx.x * blockDim.x;
     const TravStackT<LDS_SCENE> stack = make_stack<LDS_SCENE>(stc, reinterpret_cast<unsigned*>(after_scene), tid);
     RegState ps;
 #pragma unroll
@@ -69,9 +73,11 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
     PU(U_PRIM) = 0xffffffffu;
     PU(U_FLAGS) = 0u;
 
-    // ---- the group: `G` lanes of one wave own one block
-    const unsigned G = spc.group, lane = threadIdx.x & 63u, gl = lane & (G - 1u), gbase = lane & ~(G - 1u);
-    const unsigned long long gmask = (G >= 64u ? ~0ull : ((1ull << G) - 1ull)) << gbase;
+    // ---- the group: G lanes of one wave own one block; S of them share a pixel (lane sk walks segment sk of the pixel's window), so a batch is
+    // NP = G / S consecutive pixels.  The pixel's first lane (sk = 0, the LEADER) keeps the pixel's state and threads the chain through it.
+    const unsigned G = spc.group, S = spc.sub, NP = G / S, lane = threadIdx.x & 63u, gl = lane & (G - 1u);
+    const unsigned pl = gl / S, sk = gl - pl * S, lt = threadIdx.x - sk;          // pixel slot, segment, the leader's thread index in the workgroup
+    const unsigned long long gmask = (G >= 64u ? ~0ull : ((1ull << G) - 1ull)) << (lane & ~(G - 1u));
     const unsigned item = tid / G;
     const bool have_block = item < rc_arg.n_owned;
     const unsigned spp = rc_arg.spp;
@@ -85,39 +91,47 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
         else { const unsigned long long* q = rc_arg.chain_states + 4 * (size_t)item; anc.s0 = q[0]; anc.s1 = q[1]; anc.s2 = q[2]; anc.s3 = q[3]; }
     }
     unsigned phase = (have_block && c_begin < c_end) ? SP_PROBE : SP_DONE;
-#define my_off (spc.trk_off + (size_t)tid * spc.cap)
-#define my_st (spc.trk_st + (size_t)tid * spc.cap * 2u)
     const unsigned* const triv_bits = spc.trivial + (size_t)(have_block ? item : 0u) * 8u;
+    // a lane's track: trk_off / trk_st rows of workgroup thread t
+#define OFF_OF(t) (spc.trk_off + (size_t)(tid0 + (t)) * spc.cap)
+#define ST_OF(t) (spc.trk_st + (size_t)(tid0 + (t)) * spc.cap * 2u)
+#define my_off OFF_OF(threadIdx.x)
+#define my_st ST_OF(threadIdx.x)
 
     // ---- per-lane state.  Only what the traversal and shading code touches lives in registers; everything the bookkeeping between two samples
-    // needs is parked in LDS ([field][thread], conflict-free) — with it in VGPRs the kernel spilled into scratch inside the traversal loop
-    // (128 VGPRs + 16..74 spilled: 30 us per wave iteration against 3 us of issue time)
-    unsigned* const cold = reinterpret_cast<unsigned*>(after_scene) + 2 * 256 * stc.lds_levels + threadIdx.x;
-    enum { K_CUR_OFF, K_M, K_HI, K_CNT, K_SUM_N, K_SUM_N2, K_EST_L, K_EST_V, K_RES_I, K_RES_J, K_START_OFF, K_CP_I0, K_CP_J0, K_CP_K0, K_RES_OFF, K_RES_ST,
-           K_PIX = K_RES_ST + 8, K_C, K_Q0, K_ST_SPEC, K_ST_SLOW, K_ST_PROBE, K_COLD_COUNT };
+    // needs is parked in LDS ([field][thread], conflict-free) — with it in VGPRs the kernel spilled into scratch inside the traversal loop.
+    // Fields of the second row are the pixel's: only its leader's copy is used (the owner of a pixel reads and writes the other lanes' rows).
+    unsigned* const coldbase = reinterpret_cast<unsigned*>(after_scene) + 2 * 256 * stc.lds_levels;
+    unsigned* const cold = coldbase + threadIdx.x;
+    enum { K_CUR_OFF, K_M, K_STOP, K_NB_LO, K_CNT, K_SUM_N, K_SUM_N2, K_LINK_I, K_LINK_J, K_CP_I0, K_CP_J0, K_CP_K0, K_PIX, K_C, K_Q0, K_ST_SPEC,
+           K_EST_L, K_EST_V, K_RES_I, K_RES_J, K_RES_K, K_START_OFF, K_RES_OFF, K_RES_ST, K_ST_SLOW = K_RES_ST + 8, K_ST_PROBE, K_COLD_COUNT };
     static_assert(K_COLD_COUNT == kSpecColdWords, "LDS budget of k_stream_spec (host: wavefront.hip)");
 #define COLD(k) cold[(k) * 256]
+#define COLD_OF(t, k) coldbase[(k) * 256 + (t)]
     unsigned& cur_off = COLD(K_CUR_OFF);          // stream offset (relative to the anchor) where the sample being walked started
     unsigned& M = COLD(K_M);                      // track: entries 0..M-1 are walked samples, entry M the frontier
-    unsigned& hi = COLD(K_HI);                    // window end
+    unsigned& nb_lo = COLD(K_NB_LO);              // where the next lane's segment (same pixel) begins
+    unsigned& stop = COLD(K_STOP);                // the walk ends with the first sample that starts at or beyond this offset
     unsigned& cnt = COLD(K_CNT); unsigned& sum_n = COLD(K_SUM_N); float& sum_n2 = reinterpret_cast<float&>(COLD(K_SUM_N2));     // draw statistics of this lane's walk
-    float& estL = reinterpret_cast<float&>(COLD(K_EST_L)); float& estV = reinterpret_cast<float&>(COLD(K_EST_V));   // predicted length of this lane's pixel in draws, its variance
-    unsigned& res_i = COLD(K_RES_I); unsigned& res_j = COLD(K_RES_J); unsigned& start_off = COLD(K_START_OFF);   // resolve: truth samples done, track pointer, true start offset of the pixel
-    unsigned& cp_i0 = COLD(K_CP_I0); unsigned& cp_j0 = COLD(K_CP_J0); unsigned& cp_k0 = COLD(K_CP_K0);        // samples cp_i0 .. cp_i0 + cp_k0 - 1 of the pixel are track entries cp_j0 ..
-    unsigned& res_off = COLD(K_RES_OFF);          // where the chain stands after this lane's pixel (offset; the state: K_RES_ST, 8 words)
+    unsigned& link_i = COLD(K_LINK_I); unsigned& link_j = COLD(K_LINK_J);     // entry link_i of this track = entry link_j of the next lane's (0xffffffff: no link)
+    unsigned& cp_i0 = COLD(K_CP_I0); unsigned& cp_j0 = COLD(K_CP_J0); unsigned& cp_k0 = COLD(K_CP_K0);        // samples cp_i0 .. cp_i0 + cp_k0 - 1 of the pixel are this track's entries cp_j0 ..
     unsigned& pix = COLD(K_PIX); unsigned& c = COLD(K_C);      // this lane's pixel in the batch: index into sample_states, block cursor
     unsigned& q0 = COLD(K_Q0);                    // first block cursor of the current batch (group-uniform)
-    unsigned& st_spec = COLD(K_ST_SPEC); unsigned& st_slow = COLD(K_ST_SLOW); unsigned& st_probe = COLD(K_ST_PROBE);
+    unsigned& st_spec = COLD(K_ST_SPEC);
+    float& estL = reinterpret_cast<float&>(COLD(K_EST_L)); float& estV = reinterpret_cast<float&>(COLD(K_EST_V));   // leader: predicted length of the pixel in draws, its variance
+    unsigned& res_i = COLD(K_RES_I); unsigned& res_j = COLD(K_RES_J); unsigned& res_k = COLD(K_RES_K);      // leader, slow walk: truth samples done, the sub-track ahead (segment, entry)
+    unsigned& start_off = COLD(K_START_OFF);      // leader: true start offset of the pixel
+    unsigned& res_off = COLD(K_RES_OFF);          // leader: where the chain stands after the pixel (offset; the state: K_RES_ST, 8 words)
+    unsigned& st_slow = COLD(K_ST_SLOW); unsigned& st_probe = COLD(K_ST_PROBE);
     for (int k = 0; k < K_COLD_COUNT; k++) COLD(k) = 0u;
     q0 = c_begin;
     // the block sampler where the batch begins: one copy per group, after the per-thread planes
-    unsigned long long* const ganc = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned*>(after_scene) + 2 * 256 * stc.lds_levels + K_COLD_COUNT * 256) + 4u * (threadIdx.x / G);
+    unsigned long long* const ganc = reinterpret_cast<unsigned long long*>(coldbase + K_COLD_COUNT * 256) + 4u * (threadIdx.x / G);
     auto load_anc = [&]() -> Rng { Rng r; r.s0 = ganc[0]; r.s1 = ganc[1]; r.s2 = ganc[2]; r.s3 = ganc[3]; return r; };
     auto store_anc = [&](const Rng& r) { ganc[0] = r.s0; ganc[1] = r.s1; ganc[2] = r.s2; ganc[3] = r.s3; };      // (every lane of the group writes the same value)
     store_anc(anc);
-    // res_st of thread `t` of this workgroup (the owner reads its predecessor's)
-    auto load_res_st = [&](unsigned t) -> Rng {
-        const unsigned* q = reinterpret_cast<unsigned*>(after_scene) + 2 * 256 * stc.lds_levels + K_RES_ST * 256 + t;
+    auto load_res_st = [&](unsigned t) -> Rng {        // of workgroup thread t (a leader)
+        const unsigned* q = coldbase + K_RES_ST * 256 + t;
         Rng r;
         r.s0 = (unsigned long long)q[0] | ((unsigned long long)q[256] << 32); r.s1 = (unsigned long long)q[512] | ((unsigned long long)q[768] << 32);
         r.s2 = (unsigned long long)q[1024] | ((unsigned long long)q[1280] << 32); r.s3 = (unsigned long long)q[1536] | ((unsigned long long)q[1792] << 32);
@@ -127,19 +141,26 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
         COLD(K_RES_ST) = (unsigned)r.s0; COLD(K_RES_ST + 1) = (unsigned)(r.s0 >> 32); COLD(K_RES_ST + 2) = (unsigned)r.s1; COLD(K_RES_ST + 3) = (unsigned)(r.s1 >> 32);
         COLD(K_RES_ST + 4) = (unsigned)r.s2; COLD(K_RES_ST + 5) = (unsigned)(r.s2 >> 32); COLD(K_RES_ST + 6) = (unsigned)r.s3; COLD(K_RES_ST + 7) = (unsigned)(r.s3 >> 32);
     };
+    auto entry_state = [&](unsigned t, unsigned k) -> Rng {      // state of entry k of workgroup thread t's track
+        const ulonglong2* q = ST_OF(t) + 2u * k;
+        const ulonglong2 a = q[0], b = q[1];
+        Rng r; r.s0 = a.x; r.s1 = a.y; r.s2 = b.x; r.s3 = b.y;
+        return r;
+    };
     unsigned mode = SM_IDLE;
     unsigned pxy = 0;                             // image position of this lane's pixel, x | y << 16
-    bool valid = false, triv = false, resolved = false, copied = false, have_est = false, planned = false;
+    bool valid = false, triv = false, resolved = false, copied = false, have_est = false, planned = false, linked = false;
     unsigned nd = 0;                              // draws the sample being walked has taken so far
-    unsigned own = 0;                             // resolve: the group's lane whose pixel the chain stands in (group-uniform)
+    unsigned own = 0;                             // resolve: the pixel slot the chain stands in (group-uniform)
     unsigned dummy = 0;
     unsigned st_iter = 0;
 #ifdef RL_SPEC_TIMERS
+    unsigned long long tms[6] = {0, 0, 0, 0, 0, 0}; bool ser_prev = false;
     unsigned long long tmr[6] = {0, 0, 0, 0, 0, 0}, e_lanes = 0, e_iters = 0, e_slow_iters = 0, tq;
     const unsigned long long wave_t0 = wall_clock64();
     unsigned long long it_t0 = 0, cyc_serial = 0, cyc_full = 0, n_serial = 0, n_full = 0, n_idle = 0; bool it_serial = false, it_traced = false;
 #define RL_ST0 { tq = __builtin_readcyclecounter(); }
-#define RL_ST1(K) { const unsigned long long t1 = __builtin_readcyclecounter(); tmr[K] += t1 - tq; tq = t1; }
+#define RL_ST1(K) { const unsigned long long t1 = __builtin_readcyclecounter(); tmr[K] += t1 - tq; if (ser_prev) tms[K] += t1 - tq; tq = t1; }
 #else
 #define RL_ST0
 #define RL_ST1(K)
@@ -166,12 +187,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
         PU(U_DEPTH) = 1u;
         PU(U_FLAGS) = ST_RAY | (PREV_SENSOR << ST_PREV_SHIFT) | ST_PDF_SA;
     };
-    auto load_entry_state = [&](unsigned k) -> Rng {
-        const ulonglong2 a = my_st[2u * k], b = my_st[2u * k + 1u];
-        Rng r; r.s0 = a.x; r.s1 = a.y; r.s2 = b.x; r.s3 = b.y;
-        return r;
-    };
-    // the chain has reached the end of this lane's pixel
+    // (leader) the chain has reached the end of this lane's pixel
     auto finish_pixel = [&](unsigned off, const Rng& st) {
         res_off = off; store_res_st(st);
         resolved = true; mode = SM_IDLE;
@@ -180,18 +196,31 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
         if (cnt >= 8u) { const float m = (float)sum_n / (float)cnt; estV = fmaxf(sum_n2 / (float)cnt - m * m, 0.0f) * (float)spp; }
         have_est = true;
     };
-    // the chain stands on track entry j with i samples of the pixel done: the track is the chain from here to its frontier
-    auto fast_forward = [&](const RenderConst& rc, const DeviceScene& sc, unsigned i, unsigned j) {
-        const unsigned k = min(spp - i, M - j);
-        cp_i0 = i; cp_j0 = j; cp_k0 = k;
-        const unsigned off = my_off[j + k];
-        const Rng st = load_entry_state(j + k);
-        i += k;
-        if (i == spp) { finish_pixel(off, st); return; }
-        // the track ends before the pixel does: the owner walks the rest
-        res_i = i; cur_off = off; mode = SM_EXT;
+    // (leader) the pixel's chain leaves the tracks at (off, st) with i samples done: walk on, one lane, towards entry j of segment k's track
+    auto slow_walk = [&](const RenderConst& rc, const DeviceScene& sc, unsigned off, const Rng& st, unsigned i, unsigned k, unsigned j) {
+        res_i = i; res_k = k; res_j = j; cur_off = off; mode = SM_TRUTH;
         store_sample_state(rc, i, pix, st);
         begin_sample(rc, sc, st);
+    };
+    // (leader) the chain stands on entry j of segment k's track with i samples of the pixel done: that track is the chain up to its link into the next
+    // segment's track (or to its frontier), and so on
+    auto follow = [&](const RenderConst& rc, const DeviceScene& sc, unsigned i, unsigned k, unsigned j) {
+        for (;;) {
+            const unsigned t = lt + k;
+            const unsigned Mk = COLD_OF(t, K_M), li = COLD_OF(t, K_LINK_I);
+            const bool lk = li != 0xffffffffu && j <= li;
+            const unsigned lim = lk ? li : Mk;
+            const unsigned take = min(spp - i, lim - j);
+            COLD_OF(t, K_CP_I0) = i; COLD_OF(t, K_CP_J0) = j; COLD_OF(t, K_CP_K0) = take;
+            i += take;
+            if (i == spp) { finish_pixel(OFF_OF(t)[j + take], entry_state(t, j + take)); return; }
+            if (lk) { j = COLD_OF(t, K_LINK_J); k++; continue; }
+#ifdef RL_SPEC_TIMERS
+            if (spc.stats) atomicAdd(&spc.stats[k + 1u < S ? 13 : 14], 1ull);
+#endif
+            slow_walk(rc, sc, OFF_OF(t)[Mk], entry_state(t, Mk), i, k + 1u, 0u);      // this track ends before the pixel does (and nothing links it on)
+            return;
+        }
     };
 
     for (;;) {
@@ -218,17 +247,32 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
                     if (!fresh) { cnt++; sum_n += nd; sum_n2 += (float)nd * (float)nd; cur_off += nd; st_spec++; }
                     my_off[M] = cur_off;
                     my_st[2u * M] = make_ulonglong2(rng.s0, rng.s1); my_st[2u * M + 1u] = make_ulonglong2(rng.s2, rng.s3);
-                    if (cur_off >= hi || M + 1u >= spc.cap) { mode = SM_IDLE; PU(U_FLAGS) = 0u; }      // entry M is the frontier
+                    // past its own segment the lane walks on until it stands on an entry of the next lane's walk (same pixel): from there the two are one walk.
+                    // (the neighbour writes its track while this lane reads it: entries below its M are complete; the loads bypass this CU's L1)
+                    bool met = false;
+                    if (sk + 1u < S && cur_off >= nb_lo) {
+                        const unsigned* b = OFF_OF(threadIdx.x + 1u);
+                        const unsigned Mb = COLD_OF(threadIdx.x + 1u, K_M);
+                        unsigned lj = link_j, bv = 0u;
+                        while (lj < Mb && (bv = __hip_atomic_load(b + lj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < cur_off) lj++;
+                        link_j = lj;
+                        if (lj < Mb && bv == cur_off) { link_i = M; met = true; }
+                    }
+                    if (met || cur_off >= stop || M + 1u >= spc.cap) { mode = SM_IDLE; PU(U_FLAGS) = 0u; }      // entry M is the frontier
                     else { M++; begin_sample(rc, sc, rng); }
-                } else if (mode == SM_TRUTH) {
+                } else {   // SM_TRUTH: the pixel's leader walks where no track carries the chain
                     res_i++; cur_off += nd; st_slow++;
-                    while (res_j <= M && my_off[res_j] < cur_off) res_j++;
+                    // the first entry at or beyond the chain in the tracks ahead (segment res_k, then the next ones)
+                    for (;;) {
+                        if (res_k >= S) break;
+                        const unsigned t = lt + res_k, Mk = COLD_OF(t, K_M);
+                        const unsigned* offs = OFF_OF(t);
+                        while (res_j <= Mk && offs[res_j] < cur_off) res_j++;
+                        if (res_j <= Mk) break;
+                        res_k++; res_j = 0u;
+                    }
                     if (res_i == spp) { finish_pixel(cur_off, rng); fin_now = true; }
-                    else if (res_j <= M && my_off[res_j] == cur_off) { fast_forward(rc, sc, res_i, res_j); fin_now = resolved; }
-                    else { store_sample_state(rc, res_i, pix, rng); begin_sample(rc, sc, rng); }
-                } else {   // SM_EXT
-                    res_i++; cur_off += nd; st_slow++;
-                    if (res_i == spp) { finish_pixel(cur_off, rng); fin_now = true; }
+                    else if (res_k < S && OFF_OF(lt + res_k)[res_j] == cur_off) { follow(rc, sc, res_i, res_k, res_j); fin_now = resolved; }
                     else { store_sample_state(rc, res_i, pix, rng); begin_sample(rc, sc, rng); }
                 }
             }
@@ -242,16 +286,16 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
             if (!planned) {
                 // a new batch: this lane's pixel
                 planned = true;
-                c = q0 + gl;
+                c = q0 + pl;
                 valid = c < c_end;
                 pxy = (bx + c % bw) | ((by + c / bw) << 16);
                 pix = pix_base + (c - c_begin);
                 triv = valid && ((triv_bits[(c >> 5) & 7u] >> (c & 31u)) & 1u) != 0u;
-                resolved = false; copied = false; cp_k0 = 0u; M = 0u;
+                resolved = false; copied = false; linked = false; cp_k0 = 0u; M = 0u; link_i = 0xffffffffu;
                 cnt = 0u; sum_n = 0u; sum_n2 = 0.0f;
-                if (valid && !triv && !have_est && spc.probe > 0u) {
+                if (sk == 0u && valid && !triv && !have_est && spc.probe > 0u) {
                     // nothing to predict this pixel's length from: a short walk somewhere in the stream nobody else probes
-                    Rng r = load_anc(); rng_advance(r, (gl << 10) + 512u);
+                    Rng r = load_anc(); rng_advance(r, (pl << 10) + 512u);
                     store_rng(ps, Q_R0, r);
                     PU(U_FLAGS) = ST_REGEN | ST_FRESH;
                     mode = SM_PROBE;
@@ -261,7 +305,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
         const bool group_idle2 = (__ballot(mode != SM_IDLE) & gmask) == 0ull;
         if (group_idle2 && phase == SP_PROBE && planned) {
             // ---- the windows of the batch
-            if (valid && !triv && !have_est) {
+            if (sk == 0u && valid && !triv && !have_est) {
                 const float m = cnt ? (float)sum_n / (float)cnt : 16.0f;
                 const float var = cnt ? fmaxf(sum_n2 / (float)cnt - m * m, 0.0f) : m * m;
                 estL = m * (float)spp;
@@ -269,56 +313,99 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
                 have_est = true;
             }
             cnt = 0u; sum_n = 0u; sum_n2 = 0.0f;
-            const float Lp = valid ? (triv ? 2.0f * (float)spp : estL) : 0.0f;
-            const float Vp = (valid && !triv) ? 2.0f * estV : 0.0f;        // the length it is predicted from is itself one draw of the same spread
-            float Ti = Lp, Si = Vp;
+            const float eL = reinterpret_cast<const float&>(COLD_OF(lt, K_EST_L)), eV = reinterpret_cast<const float&>(COLD_OF(lt, K_EST_V));      // the pixel's (its leader's)
+            const float Lp = valid ? (triv ? 2.0f * (float)spp : eL) : 0.0f;
+            const float Vp = (valid && !triv) ? 2.0f * eV : 0.0f;        // the length it is predicted from is itself one draw of the same spread
+            float Ti = sk == 0u ? Lp : 0.0f, Si = sk == 0u ? Vp : 0.0f;      // sums over the pixels up to and including this lane's
             for (unsigned d = 1u; d < G; d <<= 1) {
                 const float t = __shfl_up(Ti, d, 64), s = __shfl_up(Si, d, 64);
                 if (gl >= d) { Ti += t; Si += s; }
             }
             const float T_ex = Ti - Lp, S_ex = Si - Vp;
             const bool any_walk = (__ballot(valid && !triv) & gmask) != 0ull;
+            // Two walks of a pixel meet after about as many samples as a sample takes draws (their sample starts are renewal processes of that density), so a
+            // pixel of spp samples can only be threaded through a speculative track when its samples are short next to spp: a batch whose pixels take more
+            // than spp / serial_ratio draws per sample on average (participating media, deep specular chains, few samples per pixel) is walked by its
+            // leaders alone, pixel after pixel — the one-lane walk of k_stream_chain — instead of paying for tracks the chain would not land on.
+            bool serial_batch = false;
+            if (any_walk && spc.serial_ratio > 0.0f) {
+                float sl = (sk == 0u && valid && !triv) ? Lp : 0.0f, sn = (sk == 0u && valid && !triv) ? 1.0f : 0.0f;
+                for (unsigned d = 1u; d < G; d <<= 1) { sl += __shfl_xor(sl, d, 64); sn += __shfl_xor(sn, d, 64); }
+                serial_batch = sl * spc.serial_ratio > sn * (float)spp * (float)spp;       // mean draws per sample = sl / (sn spp)
+            }
+            if (any_walk && serial_batch) {
+                if (valid && !triv) { my_off[0] = 0xffffffffu; M = 0u; }        // an empty track: an offset no chain reaches
+                linked = true;
+                own = 0u;
+            } else
             if (!any_walk) {
                 // every pixel of the batch looks past the scene: two draws per sample, the states are skip-aheads
-                const unsigned n_valid = min(G, c_end - q0);
-                Rng r = load_anc(); rng_advance(r, 2u * spp * min(gl, n_valid));
-                if (valid) for (unsigned s = 0; s < spp; s++) { store_sample_state(rc, s, pix, r); rng_next_u64(r); rng_next_u64(r); }
-                store_res_st(r); res_off = 0u;
+                const unsigned n_valid = min(NP, c_end - q0);
+                Rng r = load_anc(); rng_advance(r, 2u * spp * min(pl, n_valid));
+                if (valid && sk == 0u) for (unsigned s = 0; s < spp; s++) { store_sample_state(rc, s, pix, r); rng_next_u64(r); rng_next_u64(r); }
+                if (sk == 0u) { store_res_st(r); res_off = 0u; }
                 resolved = true; copied = true;
-                own = G;
+                own = NP;
             } else {
                 if (valid && !triv) {
                     const float nbar = fmaxf(Lp / (float)spp, 1.0f);
                     const unsigned nn = (unsigned)(nbar + 0.5f);
                     const unsigned t_ex = (unsigned)fminf(T_ex + 0.5f, 4.0e9f);
-                    unsigned margin = gl == 0u ? 0u : (unsigned)fminf(spc.ks * __builtin_sqrtf(S_ex) + (float)spc.lead * nbar, 1.0e9f);
+                    const unsigned lead_d = (unsigned)fminf((float)spc.lead * nbar, 1.0e9f);
+                    unsigned margin = pl == 0u ? 0u : (unsigned)fminf(spc.ks * __builtin_sqrtf(S_ex), 1.0e9f) + lead_d;
                     margin = (margin + nn - 1u) / nn * nn;          // a pixel whose samples all take nn draws only meets the chain on its own residue
                     margin = min(margin, t_ex / nn * nn);
                     const unsigned lo = t_ex - margin;
-                    hi = (unsigned)fminf(T_ex + Lp + spc.ke * __builtin_sqrtf(Si) + 0.5f, 4.0e9f);
-                    Rng r = load_anc(); rng_advance(r, lo);
+                    const unsigned hi = max(lo, (unsigned)fminf(T_ex + Lp + spc.ke * __builtin_sqrtf(Si) + 0.5f, 4.0e9f));
+                    // this lane's segment of [lo, hi): it walks on into the next one for a lead-in's length, so that the two walks can fall in with each other
+                    const unsigned seg = ((hi - lo) / S + nn - 1u) / nn * nn;
+                    const unsigned s_lo = lo + sk * seg;
+                    nb_lo = lo + (sk + 1u) * seg;
+                    stop = sk + 1u == S ? hi : min(hi, lo + (sk + 2u) * seg);        // (a walk that has not met the next lane's by the end of THAT lane's segment gives up)
+                    link_j = 0u;
+                    Rng r = load_anc(); rng_advance(r, s_lo);
                     store_rng(ps, Q_R0, r);
                     PU(U_FLAGS) = ST_REGEN | ST_FRESH;
-                    cur_off = lo;
+                    cur_off = s_lo;
                     mode = SM_WALK;
                 }
                 own = 0u;
             }
-            phase = any_walk ? SP_WALK : SP_RESOLVE;
+            phase = (any_walk && !serial_batch) ? SP_WALK : SP_RESOLVE;
         } else if (group_idle2 && phase == SP_WALK) {
             phase = SP_RESOLVE;
         }
+        // ---- the walks of the batch are done: where does each lane's walk first stand on an entry of the next lane's (same pixel)?  Lane-parallel;
+        // the tracks were written by other lanes of this wave: their stores are made visible first.
+        if (S > 1u && __ballot(phase == SP_RESOLVE && !linked && own < NP) != 0ull) {
+            __threadfence();
+            if (phase == SP_RESOLVE && !linked) {
+                linked = true;
+                if (valid && !triv && sk + 1u < S && link_i == 0xffffffffu) {
+                    const unsigned* a = my_off; const unsigned* b = OFF_OF(threadIdx.x + 1u);
+                    const unsigned Ma = M, Mb = COLD_OF(threadIdx.x + 1u, K_M);
+                    unsigned i = 0u, j = 0u;
+                    const unsigned b0 = b[0];
+                    { unsigned lo_i = 0u, hi_i = Ma + 1u; while (lo_i < hi_i) { const unsigned mid = (lo_i + hi_i) >> 1; if (a[mid] < b0) lo_i = mid + 1u; else hi_i = mid; } i = lo_i; }
+                    unsigned av = i <= Ma ? a[i] : 0u, bv = b0;
+                    while (i <= Ma && j <= Mb) {
+                        if (av == bv) { link_i = i; link_j = j; break; }
+                        if (av < bv) { i++; if (i <= Ma) av = a[i]; } else { j++; if (j <= Mb) bv = b[j]; }
+                    }
+                }
+            }
+        }
 
         RL_ST1(1)
-        // ---- C. thread the chain through the tracks: owners that can finish at once do so back to back
-        if (__ballot(phase == SP_RESOLVE && own < G) != 0ull) {
+        // ---- C. thread the chain through the tracks: pixels whose chain never leaves the tracks are done back to back
+        if (__ballot(phase == SP_RESOLVE && own < NP) != 0ull) {
             for (;;) {
                 bool fin = false;
-                if (phase == SP_RESOLVE && own < G && gl == own && mode == SM_IDLE && !resolved) {
-                    // where the chain stands: after the predecessor's pixel (its parked res_off / res_st), or at the anchor
+                if (phase == SP_RESOLVE && own < NP && sk == 0u && pl == own && mode == SM_IDLE && !resolved) {
+                    // where the chain stands: after the predecessor's pixel (its leader's parked res_off / res_st), or at the anchor
                     unsigned b_off = 0u; Rng b_st;
                     if (own == 0u) b_st = load_anc();
-                    else { b_off = cold[K_RES_OFF * 256 - 1]; b_st = load_res_st(threadIdx.x - 1u); }
+                    else { b_off = COLD_OF(threadIdx.x - S, K_RES_OFF); b_st = load_res_st(threadIdx.x - S); }
                     start_off = b_off;
                     if (!valid) { res_off = b_off; store_res_st(b_st); resolved = true; copied = true; fin = true; }       // past the block's end: hand the chain on
                     else if (triv) {
@@ -326,15 +413,26 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
                         Rng r = b_st; rng_advance(r, 2u * spp);
                         res_off = b_off + 2u * spp; store_res_st(r); resolved = true; fin = true;
                     } else {
-                        unsigned lo = 0u, hi_e = M + 1u;            // entries 0 .. M
-                        while (lo < hi_e) { const unsigned mid = (lo + hi_e) >> 1; if (my_off[mid] < b_off) lo = mid + 1u; else hi_e = mid; }
-                        res_j = lo;
-                        if (lo <= M && my_off[lo] == b_off) { fast_forward(rc, sc, 0u, lo); fin = resolved; }
+                        // the first of the pixel's tracks that reaches the start (a track runs on past its own segment until it has fallen in with the next
+                        // one, and the longer a walk has been going the likelier it is the chain); the next track too where the two overlap
+                        unsigned k0 = 0u;
+                        while (k0 < S && OFF_OF(lt + k0)[COLD_OF(lt + k0, K_M)] < b_off) k0++;
+                        bool on_track = false; unsigned j0 = 0u;
+                        for (unsigned k = k0; k < S && k < k0 + 2u && !on_track; k++) {
+                            const unsigned* offs = OFF_OF(lt + k);
+                            const unsigned Mk = COLD_OF(lt + k, K_M);
+                            if (k > k0 && offs[0] > b_off) break;
+                            unsigned lo = 0u, hi_e = Mk + 1u;            // entries 0 .. M
+                            while (lo < hi_e) { const unsigned mid = (lo + hi_e) >> 1; if (offs[mid] < b_off) lo = mid + 1u; else hi_e = mid; }
+                            if (k == k0) j0 = lo;
+                            if (lo <= Mk && offs[lo] == b_off) { on_track = true; k0 = k; j0 = lo; }
+                        }
+                        if (on_track) { follow(rc, sc, 0u, k0, j0); fin = resolved; }
                         else {
-                            // not on the track: walk from the true start until the track is met (or the pixel ends)
-                            res_i = 0u; cur_off = b_off; mode = SM_TRUTH;
-                            store_sample_state(rc, 0u, pix, b_st);
-                            begin_sample(rc, sc, b_st);
+#ifdef RL_SPEC_TIMERS
+                            if (spc.stats) atomicAdd(&spc.stats[12], 1ull);
+#endif
+                            slow_walk(rc, sc, b_off, b_st, 0u, k0, j0);      // not on a track: walk from the true start until one is met (or the pixel ends)
                         }
                     }
                 }
@@ -346,26 +444,27 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
 
         RL_ST1(2)
         // ---- D. the batch is threaded: copy the track entries the chain ran over into sample_states, then the next batch
-        if (__ballot(phase == SP_RESOLVE && own >= G) != 0ull) {
-            if (phase == SP_RESOLVE && own >= G) {
+        if (__ballot(phase == SP_RESOLVE && own >= NP) != 0ull) {
+            if (phase == SP_RESOLVE && own >= NP) {
                 if (valid && !copied) {
                     if (triv) {
-                        Rng r = load_entry_state(0u);
-                        for (unsigned s = 0; s < spp; s++) { store_sample_state(rc, s, pix, r); rng_next_u64(r); rng_next_u64(r); }
+                        if (sk == 0u) {
+                            Rng r = entry_state(threadIdx.x, 0u);
+                            for (unsigned s = 0; s < spp; s++) { store_sample_state(rc, s, pix, r); rng_next_u64(r); rng_next_u64(r); }
+                        }
                     } else {
-                        for (unsigned t = 0; t < cp_k0; t++) {
-                            const ulonglong2 a = my_st[2u * (cp_j0 + t)], b = my_st[2u * (cp_j0 + t) + 1u];
-                            ulonglong2* q = reinterpret_cast<ulonglong2*>(rc.sample_states + 4 * ((size_t)(cp_i0 + t) * rc.n_state_pixels + pix));
+                        const unsigned i0 = cp_i0, j0 = cp_j0, n = cp_k0;
+                        for (unsigned t = 0; t < n; t++) {
+                            const ulonglong2 a = my_st[2u * (j0 + t)], b = my_st[2u * (j0 + t) + 1u];
+                            ulonglong2* q = reinterpret_cast<ulonglong2*>(rc.sample_states + 4 * ((size_t)(i0 + t) * rc.n_state_pixels + pix));
                             q[0] = a; q[1] = b;
                         }
                     }
                     copied = true;
                 }
-            }
-            if (phase == SP_RESOLVE && own >= G) {
-                const Rng last = load_res_st(threadIdx.x - gl + G - 1u);      // the chain after the group's last pixel = the next batch's anchor
+                const Rng last = load_res_st(threadIdx.x - gl + (NP - 1u) * S);      // the chain after the group's last pixel = the next batch's anchor
                 store_anc(last);
-                q0 += G;
+                q0 += NP;
                 planned = false;
                 own = 0u;
                 if (q0 >= c_end) {
@@ -379,30 +478,33 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
 
         // ---- E. one vertex of every walking lane
 #ifdef RL_SPEC_TIMERS
-        { const unsigned long long rm = __ballot((PU(U_FLAGS) & ST_RAY) != 0u); it_traced = rm != 0ull; it_serial = __ballot(mode == SM_WALK || mode == SM_PROBE) == 0ull; if (rm) { e_iters++; e_lanes += __popcll(rm); if (__ballot(mode == SM_WALK || mode == SM_PROBE) == 0ull) e_slow_iters++; } }
+        { const unsigned long long rm = __ballot((PU(U_FLAGS) & ST_RAY) != 0u); it_traced = rm != 0ull; it_serial = __ballot(mode == SM_WALK || mode == SM_PROBE) == 0ull; if (rm) { e_iters++; e_lanes += __popcll(rm); if (it_serial) e_slow_iters++; } }
 #endif
         if (PU(U_FLAGS) & ST_RAY) {
             extend_slot(sc, recs, stack, ps);
             shade_slot<MAT, MEDIUM, LIGHTS_AREA_ONLY, true>(rc, sc, ps, PU(U_FLAGS), dummy, nd, dummy, dummy);
         }
 #ifdef RL_SPEC_TIMERS
-        { const unsigned long long rm = __ballot(true); (void)rm; }
         RL_ST1(4)
+        ser_prev = it_serial && it_traced;
 #endif
     }
 #undef RL_SPEC_KERNARGS
-#undef my_off
-#undef my_st
-#undef COLD
 #ifdef RL_SPEC_TIMERS
-    if (spc.stats && lane == 0u) { { unsigned long long* w = spc.stats + 16 + 8 * (tid >> 6); w[0] = wave_t0; w[1] = wall_clock64(); w[2] = n_full; w[3] = n_serial; w[4] = cyc_full; w[5] = cyc_serial; w[6] = n_idle; w[7] = st_slow; }
-        for (int k = 0; k < 5; k++) atomicAdd(&spc.stats[4 + k], tmr[k]); atomicAdd(&spc.stats[9], e_lanes); atomicAdd(&spc.stats[10], e_iters); atomicAdd(&spc.stats[11], e_slow_iters); }
+    if (spc.stats && lane == 0u) { { unsigned long long* w = spc.stats + 32 + 8 * (tid >> 6); w[0] = wave_t0; w[1] = wall_clock64(); w[2] = n_full; w[3] = n_serial; w[4] = cyc_full; w[5] = cyc_serial; w[6] = n_idle; w[7] = st_slow; }
+        for (int k = 0; k < 5; k++) { atomicAdd(&spc.stats[4 + k], tmr[k]); atomicAdd(&spc.stats[16 + k], tms[k]); } atomicAdd(&spc.stats[9], e_lanes); atomicAdd(&spc.stats[10], e_iters); atomicAdd(&spc.stats[11], e_slow_iters); }
 #endif
     if (spc.stats) {
         unsigned a = st_spec, b = st_slow, p = st_probe;
         for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); p += __shfl_down(p, off, 64); }
         if (lane == 0u) { atomicAdd(&spc.stats[0], (unsigned long long)a); atomicAdd(&spc.stats[1], (unsigned long long)b); atomicAdd(&spc.stats[2], (unsigned long long)p); atomicAdd(&spc.stats[3], (unsigned long long)st_iter); }
     }
+#undef my_off
+#undef my_st
+#undef OFF_OF
+#undef ST_OF
+#undef COLD
+#undef COLD_OF
 }
 
 template <bool LDS_SCENE, int MAT>

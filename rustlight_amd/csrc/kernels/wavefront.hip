@@ -277,6 +277,7 @@ struct rl_context {
     unsigned* d_trk_off = nullptr; size_t trk_off_capacity = 0;
     ulonglong2* d_trk_st = nullptr; size_t trk_st_capacity = 0;
     unsigned* d_trivial = nullptr; size_t trivial_capacity = 0;
+    double draws_per_sample = 0.0;         // measured by the last path render of this context (0: none yet): k_stream_spec only pays when a pixel's samples are short next to spp
     uint64_t trivial_key = ~0ull;         // (shard index, shard count, sensor expanded?) the masks on the device were computed for
     unsigned long long* d_spec_stats = nullptr; size_t spec_stats_capacity = 0;
     std::vector<hipEvent_t> events;
@@ -810,15 +811,30 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
                                  : (stc_c.pre_group ? (size_t)(256 / stc_c.pre_group) * ((size_t)ctx->ds.n_nodes * 32 + (size_t)ctx->ds.n_prims * 8) : 0));
         // ---- k_stream_spec (spec.hip.h): the chains with every lane busy — exact build; RL_CHAIN_SERIAL=1 keeps the one-lane-per-block walk (the cross-check)
         bool spec = !fast_math && !getenv("RL_CHAIN_SERIAL");
+        // Two walks of a pixel fall in with each other after about as many samples as a sample takes draws, so the speculative pass only pays when a
+        // pixel has several times that many samples (spec.hip.h): decided from the draws per sample the context's last render measured, else from
+        // what the scene is (a participating medium: ~150 draws per sample on the Cornell box — 1080p x 128 spp: 3085 vs 2837 ms; without one ~10).
+        // RL_SPEC_FORCE=1 (tests): always, also inside the kernel.
+        const bool spec_force = getenv("RL_SPEC_FORCE") != nullptr;
+        if (spec && !spec_force) {
+            const double nbar = ctx->draws_per_sample > 0.0 ? ctx->draws_per_sample : (medium ? 150.0 : 12.0);
+            if ((double)params->spp < 4.0 * nbar) spec = false;
+        }
         SpecConf spc{};
         unsigned spec_threads = 0;
-        unsigned long long spec_totals[16] = {0};
+        unsigned long long spec_totals[32] = {0};
         if (spec) {
             // lanes per block: the fewest that still give every SIMD about two waves (a wider batch looks further ahead, so its windows are wider)
             unsigned group = 16u;
             while (group < 64u && (size_t)owned.size() * group < (size_t)cus * 4u * 2u * 64u) group <<= 1;
+            // scenes that stream their BVH are bound by the latency of a wave's dependent fetches: one block per wave, four lanes per pixel
+            // (508 k triangles, 1080p x 128 spp: 32 x 1 / 64 x 4 = 4377 / 2667 ms; the serial chain 5689 ms); LDS-staged ones: two lanes per pixel from 32 lanes per block on
+            if (!ctx->lds_scene) group = 64u;
             if (getenv("RL_SPEC_GROUP")) { const int g = atoi(getenv("RL_SPEC_GROUP")); if (g == 16 || g == 32 || g == 64) group = (unsigned)g; }
             spc.group = group;
+            spc.sub = !ctx->lds_scene ? 4u : (group >= 32u ? 2u : 1u);
+            spc.serial_ratio = spec_force ? 0.0f : (getenv("RL_SPEC_SERIAL_RATIO") ? (float)atof(getenv("RL_SPEC_SERIAL_RATIO")) : 3.0f);
+            if (getenv("RL_SPEC_SUB")) { const int v = atoi(getenv("RL_SPEC_SUB")); if ((v == 1 || v == 2 || v == 4 || v == 8) && (unsigned)v <= group) spc.sub = (unsigned)v; }
             spc.cap = std::max(96u, std::min(3u * params->spp + 64u, 1u << 20));
             if (getenv("RL_SPEC_CAP")) spc.cap = std::max(4u, (unsigned)atoi(getenv("RL_SPEC_CAP")));
             spc.probe = getenv("RL_SPEC_PROBE") ? (unsigned)atoi(getenv("RL_SPEC_PROBE")) : std::min(32u, std::max(4u, params->spp));
@@ -847,8 +863,8 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
                 HIP_OK(hipStreamSynchronize(st));        // (`masks` is a local)
                 ctx->trivial_key = getenv("RL_SPEC_NO_TRIVIAL") ? ~0ull : key;
             }
-            if ((rcode = ensure(&ctx->d_spec_stats, &ctx->spec_stats_capacity, 16 + 8 * (size_t)(spec_threads / 64u))) != RL_OK) return rcode;
-            HIP_OK(hipMemsetAsync(ctx->d_spec_stats, 0, 16 * sizeof(unsigned long long), st));
+            if ((rcode = ensure(&ctx->d_spec_stats, &ctx->spec_stats_capacity, 32 + 8 * (size_t)(spec_threads / 64u))) != RL_OK) return rcode;
+            HIP_OK(hipMemsetAsync(ctx->d_spec_stats, 0, 32 * sizeof(unsigned long long), st));
             spc.trk_off = ctx->d_trk_off; spc.trk_st = ctx->d_trk_st; spc.trivial = ctx->d_trivial;
             spc.stats = (stats || getenv("RL_SPEC_STATS")) ? ctx->d_spec_stats : nullptr;
         }
@@ -895,12 +911,12 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         if (spec && spc.stats) {
             HIP_OK(hipMemcpy(spec_totals, ctx->d_spec_stats, sizeof(spec_totals), hipMemcpyDeviceToHost));
             spec_group = spc.group; spec_stat[0] = spec_totals[0]; spec_stat[1] = spec_totals[1]; spec_stat[2] = spec_totals[2];
-            if (getenv("RL_SPEC_STATS")) std::fprintf(stderr, "[spec] group %u cap %u: %llu speculative + %llu serial + %llu probe samples for %llu camera samples (%.2f x, %.2f serial per pixel), %llu wave iterations\n",
-                spc.group, spc.cap, spec_totals[0], spec_totals[1], spec_totals[2], (unsigned long long)n_pixels * params->spp,
+            if (getenv("RL_SPEC_STATS")) std::fprintf(stderr, "[spec] group %u x sub %u cap %u: %llu speculative + %llu serial + %llu probe samples for %llu camera samples (%.2f x, %.2f serial per pixel), %llu wave iterations\n",
+                spc.group, spc.sub, spc.cap, spec_totals[0], spec_totals[1], spec_totals[2], (unsigned long long)n_pixels * params->spp,
                 (double)(spec_totals[0] + spec_totals[1] + spec_totals[2]) / std::max(1.0, (double)n_pixels * params->spp), (double)spec_totals[1] / std::max(1u, n_pixels), spec_totals[3]);
             if (getenv("RL_SPEC_WAVE_TIMES") && spec_totals[8]) {     // dev build: lifetime of every wave (100 MHz clock)
                 std::vector<unsigned long long> wt(8 * (size_t)(spec_threads / 64u));
-                HIP_OK(hipMemcpy(wt.data(), ctx->d_spec_stats + 16, wt.size() * 8, hipMemcpyDeviceToHost));
+                HIP_OK(hipMemcpy(wt.data(), ctx->d_spec_stats + 32, wt.size() * 8, hipMemcpyDeviceToHost));
                 FILE* f = std::fopen(getenv("RL_SPEC_WAVE_TIMES"), "w");
                 if (f) { unsigned long long t0 = ~0ull; for (size_t w = 0; w < wt.size() / 8; w++) if (wt[8 * w]) t0 = std::min(t0, wt[8 * w]);
                          for (size_t w = 0; w < wt.size() / 8; w++) std::fprintf(f, "%zu %.3f %.3f %llu %llu %.3f %.3f %llu %llu\n", w, (wt[8 * w] - t0) * 1e-5, (wt[8 * w + 1] - t0) * 1e-5, wt[8 * w + 2], wt[8 * w + 3], wt[8 * w + 4] * 1e-5, wt[8 * w + 5] * 1e-5, wt[8 * w + 6], wt[8 * w + 7]); std::fclose(f); }
@@ -910,6 +926,10 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
                 std::fprintf(stderr, "[spec] cycles: bookkeeping %.1f %%, plan %.1f %%, thread %.1f %%, copy-out %.1f %%, extend+shade %.1f %%; %.1f lanes per traced iteration, %.1f %% of the traced iterations serial only, %.0f cycles per wave iteration\n",
                     100.0 * spec_totals[4] / tot, 100.0 * spec_totals[5] / tot, 100.0 * spec_totals[6] / tot, 100.0 * spec_totals[7] / tot, 100.0 * spec_totals[8] / tot,
                     (double)spec_totals[9] / std::max<double>(1.0, (double)spec_totals[10]), 100.0 * spec_totals[11] / std::max<double>(1.0, (double)spec_totals[10]), tot / std::max<double>(1.0, (double)spec_totals[3]));
+                { const double ts = (double)(spec_totals[16] + spec_totals[17] + spec_totals[18] + spec_totals[19] + spec_totals[20]);
+                  std::fprintf(stderr, "[spec] iterations after a serial-only one (%.1f %% of all cycles): bookkeeping %.1f %%, plan %.1f %%, thread %.1f %%, copy-out %.1f %%, extend+shade %.1f %%\n", 100.0 * ts / tot,
+                    100.0 * spec_totals[16] / ts, 100.0 * spec_totals[17] / ts, 100.0 * spec_totals[18] / ts, 100.0 * spec_totals[19] / ts, 100.0 * spec_totals[20] / ts); }
+                std::fprintf(stderr, "[spec] slow walks: %llu from a pixel's start, %llu across a missing link, %llu past the last track\n", spec_totals[12], spec_totals[13], spec_totals[14]);
             }
         }
         iterations = chunks.size();
@@ -972,6 +992,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     for (size_t r = 0; r < n_partial_rows; r++) for (int k = 0; k < STAT_COUNT; k++) totals[k] += partials[r * STAT_COUNT + k];
     HIP_OK(hipGetLastError());
     auto t_end = std::chrono::steady_clock::now();
+    if (totals[STAT_SAMPLES]) ctx->draws_per_sample = (double)totals[STAT_DRAWS] / (double)totals[STAT_SAMPLES];
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         stats->camera_samples = totals[STAT_SAMPLES];

@@ -98,8 +98,23 @@ def run(budget=20.0, seed=0, verbose=True, fast=False):
                     bad += 1
                     print("MISMATCH (ao/direct)", n, dict(size=(sd.width, sd.height), tris=sd.n_triangles, streaming=streaming, seed=seed, **mk), "max abs diff", float(np.nanmax(np.abs(img - ref))), flush=True)
                 continue
-            img, st = ctx.render(api.IndependentSampler(seed, kw["seed_variant"]).block_seeds(sd.width, sd.height), api.path_params(pipeline=pipe, sample_split=split, pool_slots=pool, **kw))
-            ref, ost = osc.render(master_seed=seed, eval_order=1, **kw)
+            # reference-order streams through the persistent kernel: half of the cases through the speculative chain pass (k_stream_spec, forced — these
+            # renders are far too small for it to be chosen) with random lanes per block / per pixel, track capacities, window margins and lead-ins
+            spec_env = {}
+            if kw["stream_mode"] == api.STREAM_REFERENCE_ORDER and pipe != 1 and pool == 0 and rng.random() < 0.5:
+                g = int(rng.choice([16, 32, 64]))
+                spec_env = dict(RL_SPEC_FORCE="1", RL_SPEC_GROUP=str(g), RL_SPEC_SUB=str(int(rng.choice([s for s in (1, 2, 4, 8) if s <= g]))),
+                                RL_SPEC_CAP=str(int(rng.choice([4, 9, 40, 400]))), RL_SPEC_LEAD=str(int(rng.choice([0, 2, 24]))),
+                                RL_SPEC_KS=str(float(rng.choice([0.0, 1.65, 4.0]))), RL_SPEC_KE=str(float(rng.choice([0.0, 1.65, 4.0]))), RL_SPEC_PROBE=str(int(rng.choice([0, 3, 32]))))
+                if rng.random() < 0.2: spec_env["RL_SPEC_NO_TRIVIAL"] = "1"
+                if rng.random() < 0.2: spec_env["RL_STATE_BUDGET_MB"] = "1"
+            os.environ.update(spec_env)
+            try:
+                img, st = ctx.render(api.IndependentSampler(seed, kw["seed_variant"]).block_seeds(sd.width, sd.height), api.path_params(pipeline=pipe, sample_split=split, pool_slots=pool, **kw))
+            finally:
+                for k in spec_env: os.environ.pop(k, None)
+            if spec_env: kw = dict(kw, _spec=spec_env)
+            ref, ost = osc.render(master_seed=seed, eval_order=1, **{k: v for k, v in kw.items() if k != "_spec"})
             ok = np.array_equal(img, ref) and all(st[k] == ost[k] for k in ("camera_samples", "vertices", "extension_rays", "rng_draws", "shadow_rays"))
             n += 1
             if ok and fast and pipe != 1 and pool == 0 and kw["stream_mode"] == api.STREAM_PER_SAMPLE:
@@ -110,7 +125,7 @@ def run(budget=20.0, seed=0, verbose=True, fast=False):
                 # moved it by more than 2 % in a 6-minute run, none by more than 40 %, all with vertex counts within 0.6 %) only to a coarse bound
                 # (a handful of flipped paths can also be hundreds of vertices long — glass, min_depth — and move the census of a tiny render by several percent
                 # while the image stays put: 2 of 4230 cases, per-pixel L2 1e-16; those pass on the image)
-                kf = dict(kw, spp=max(32, 8 * kw["spp"]))
+                kf = dict({k: v for k, v in kw.items() if k != "_spec"}, spp=max(32, 8 * kw["spp"]))
                 seeds = api.IndependentSampler(seed, kw["seed_variant"]).block_seeds(sd.width, sd.height)
                 ex, sx = ctx.render(seeds, api.path_params(pipeline=pipe, sample_split=split, **kf))
                 fa, sf = ctx.render(seeds, api.path_params(pipeline=pipe, sample_split=split, numerics=api.NUMERICS_FAST, **kf))

@@ -783,6 +783,99 @@ def test_reference_order_two_pass_equals_single_pass(built, monkeypatch):
     np.testing.assert_array_equal(parts[0] + parts[1] + parts[2], whole[0])
 
 
+def test_rng_advance_equals_stepping(built):
+    """rng_advance (csrc/kernels/rngjump.h: the jump polynomials x^(2^b) mod P of Xoshiro256's state transition, derived by scratch/r4/xoshiro_jump.py and
+    checked there against the generator's published JUMP / LONG_JUMP constants) against plain stepping of the oracle's sampler, on the device."""
+    import ctypes as C
+    L = api.lib()
+    n = 192
+    rng = np.random.default_rng(5)
+    states = rng.integers(1, 2**63, size=(n, 4), dtype=np.uint64)
+    counts = np.concatenate([[0, 1, 2, 255, 256, 257, 511, 512, 1023, 65536, 65537, 1000003], rng.integers(0, 200000, size=n - 12)]).astype(np.uint32)
+    out = np.zeros_like(states)
+    L.rl_debug_rng_advance.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.rl_debug_rng_advance(0, n, states.ctypes.data, counts.ctypes.data, out.ctypes.data) == 0
+    for i in range(n):
+        r = orc.Rng.from_state([int(x) for x in states[i]])
+        for _ in range(int(counts[i])):
+            orc.lib().orc_rng_next_u64(r.state)
+        assert list(r.state) == [int(x) for x in out[i]], (i, int(counts[i]))
+
+
+def test_reference_order_speculative_chain(built, monkeypatch):
+    """k_stream_spec (csrc/kernels/spec.hip.h), the first pass of reference-order streams with every lane busy: per-pixel windows of the block stream are
+    walked speculatively and the true chain is threaded through the tracks.  Whatever the windows, group shapes, capacities and estimates are, the recorded
+    sampler states — hence the image and every counter — must be those of the one-lane-per-block walk (RL_CHAIN_SERIAL: k_stream_chain) and of the oracle:
+    on every feature that changes a draw count, on ragged frames, with tiny track capacities (the slow path does the work), no lead-in, no margins, no
+    probes, without the trivial-pixel shortcut, in several chunks, on shards and through the streaming kernels.  These frames are far too small for the
+    pass to be chosen by itself (RL_SPEC_FORCE)."""
+    ref_mode = api.STREAM_REFERENCE_ORDER
+    cases = [(scenes.cbox(70, 41), dict(spp=24)),
+             (scenes.cbox(48, 48), dict(spp=9, strategy=api.STRATEGY_BSDF, max_depth=6)),
+             (scenes.cbox(48, 48), dict(spp=7, rr_depth=None, max_depth=5)),
+             (scenes.cbox(32, 32), dict(spp=5, max_depth=1)),
+             (scenes.cbox_medium(40, 40, 0.8, 0.2, g=0.6), dict(spp=6)),
+             (scenes.living_room(64, 48, n_spheres=27, tess=10), dict(spp=12, max_depth=10)),          # glass / mirror / phong / substrate
+             (scenes.sky_scene(48, 48), dict(spp=8, min_depth=1)),
+             (scenes.many_lights(48, 48, n=5, use_ats=True), dict(spp=6, max_depth=4))]
+    shapes = [dict(RL_SPEC_GROUP="16", RL_SPEC_SUB="1"), dict(RL_SPEC_GROUP="32", RL_SPEC_SUB="2"), dict(RL_SPEC_GROUP="64", RL_SPEC_SUB="4"), dict(RL_SPEC_GROUP="64", RL_SPEC_SUB="8"),
+              dict(RL_SPEC_GROUP="32", RL_SPEC_SUB="1", RL_SPEC_CAP="5"), dict(RL_SPEC_GROUP="64", RL_SPEC_SUB="2", RL_SPEC_LEAD="0", RL_SPEC_KS="0", RL_SPEC_KE="0", RL_SPEC_PROBE="0"),
+              dict(RL_SPEC_GROUP="16", RL_SPEC_SUB="4", RL_SPEC_NO_TRIVIAL="1", RL_SPEC_KS="5", RL_SPEC_KE="5")]
+    keys = ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws")
+    for n_case, (sd, kw) in enumerate(cases):
+        ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+        seeds = api.IndependentSampler(7).block_seeds(sd.width, sd.height)
+        monkeypatch.setenv("RL_CHAIN_SERIAL", "1")
+        base = _render_pair(sd, ctx, osc, seed=7, stream_mode=ref_mode, **kw)
+        _assert_parity(*base)
+        assert base[1]["spec_group"] == 0
+        monkeypatch.delenv("RL_CHAIN_SERIAL")
+        monkeypatch.setenv("RL_SPEC_FORCE", "1")
+        for env in (shapes if n_case < 2 else shapes[n_case % 3::3]):
+            for k, v in env.items(): monkeypatch.setenv(k, v)
+            img, st = ctx.render(seeds, api.path_params(stream_mode=ref_mode, **kw))
+            for k in env: monkeypatch.delenv(k)
+            assert st["spec_group"] == int(env["RL_SPEC_GROUP"]), env
+            np.testing.assert_array_equal(img, base[0], err_msg=f"case {n_case} {env}")
+            assert all(st[k] == base[1][k] for k in keys), (n_case, env)
+        monkeypatch.delenv("RL_SPEC_FORCE")
+    # chunks (the chain is parked between them), shards, and the kernels that stream the BVH
+    sd = scenes.cbox(160, 200)
+    ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+    seeds = api.IndependentSampler(1).block_seeds(160, 200)
+    monkeypatch.setenv("RL_CHAIN_SERIAL", "1")
+    whole = _render_pair(sd, ctx, osc, seed=1, stream_mode=ref_mode, spp=40)
+    _assert_parity(*whole)
+    monkeypatch.delenv("RL_CHAIN_SERIAL")
+    monkeypatch.setenv("RL_SPEC_FORCE", "1")
+    img, st = ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=40))
+    assert st["spec_group"] > 0 and st["spec_samples"] > 0
+    np.testing.assert_array_equal(img, whole[0])
+    monkeypatch.setenv("RL_STATE_BUDGET_MB", "2")
+    img, st = ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=40))
+    assert st["iterations"] > 5 and st["spec_group"] > 0
+    np.testing.assert_array_equal(img, whole[0])
+    monkeypatch.delenv("RL_STATE_BUDGET_MB")
+    parts = [ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=40, shard_index=r, shard_count=3))[0] for r in range(3)]
+    np.testing.assert_array_equal(parts[0] + parts[1] + parts[2], whole[0])
+    monkeypatch.setenv("RL_FORCE_STREAMING", "1")
+    sctx = api.Context(api.Scene(sd), 0)
+    monkeypatch.delenv("RL_FORCE_STREAMING")
+    assert not sctx.debug_sizes()["lds_scene"]
+    for env in (dict(RL_SPEC_GROUP="64", RL_SPEC_SUB="4"), dict(RL_SPEC_GROUP="32", RL_SPEC_SUB="1")):
+        for k, v in env.items(): monkeypatch.setenv(k, v)
+        img, st = sctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=40))
+        for k in env: monkeypatch.delenv(k)
+        assert st["spec_group"] == int(env["RL_SPEC_GROUP"])
+        np.testing.assert_array_equal(img, whole[0], err_msg=str(env))
+    # the policy: a frame this small at 40 spp is left to the serial chain unless forced; with the ~17 draws per sample the last render measured, 96 spp is enough
+    monkeypatch.delenv("RL_SPEC_FORCE")
+    img, st = ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=8))
+    assert st["spec_group"] == 0
+    img, st = ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=96))
+    assert st["spec_group"] > 0
+
+
 def test_full_size_reference_order(built):
     """BASELINE cfg 2's frame in the drop-in default mode, RL_STREAM_REFERENCE_ORDER (rustlight's own stream assignment,
     src/integrators/mod.rs:420-435), 1920x1080 x 8 spp through the two-pass form: 8 blocks (the four busiest + fixed ones inside and outside
