@@ -111,6 +111,17 @@ class _Watchdog:
         return False
 
 
+def oracle_crc(workload, width, height, spp, stream_mode, seed):
+    """CRC-32 the parity build of the CPU oracle gave for this frame (tests/golden/bench_crcs.json, made by tests/golden/make_bench_golden.py in the build
+    container) — a table lookup: the timed program neither imports nor runs the oracle for this.  None when the frame is not in the table."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_crcs.json")))
+    except (OSError, ValueError):
+        return None
+    e = table.get(f"{workload}:{width}x{height}x{spp}:{stream_mode}:seed{seed}")
+    return e["crc32"] if e else None
+
+
 def pipeline_bytes(stats_sum, pixels, steps):
     """SURVEY.md §8(d) / DESIGN.md §4: algorithmic bytes of the whole pipeline = 248 B / camera sample + 352 B / expanded vertex + 12 B / pixel."""
     return 248 * stats_sum["camera_samples"] + 352 * stats_sum["vertices"] + 12 * pixels * steps
@@ -187,11 +198,17 @@ def main():
                                    stream_mode=api.STREAM_PER_SAMPLE if stream_mode == "per_sample" else api.STREAM_REFERENCE_ORDER,
                                    numerics={"exact": 0, "fast": 1}[numerics])
 
+        reduce_events = []
+
         def step(seed):
             seeds = api.IndependentSampler(seed).block_seeds(width, height)              # same master stream on every rank
             _, st = ctx.render(seeds, params(*shard), out_device_ptr=fb.data_ptr(), stream=stream)
             if shard[1] > 1:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(work_stream)
                 rd.reduce_framebuffer(fb)                                                 # one RCCL reduce over xGMI
+                e1.record(work_stream)
+                reduce_events.append((e0, e1))
             if rank == 0:
                 host_fb.copy_(fb, non_blocking=True)                                      # framebuffer download (inside the timed region, §8(d))
             return st
@@ -208,7 +225,11 @@ def main():
         agg = {k: sum(s[k] for s in stats) for k in STAT_KEYS}
         ms = {k: sum(s[k] for s in stats) for k in MS_KEYS}
         host_img = host_fb.numpy().copy() if rank == 0 else None
-        return {"dt": dt, "agg": agg, "ms": ms, "host_img": host_img, "params": params, "steps": steps, "samples_per_step": width * height * spp_total}
+        # (this rank's wait for the slowest shard is part of its reduce time: the collective cannot start before every rank has arrived)
+        reduce_ms = sum(a.elapsed_time(b) for a, b in reduce_events[-steps:]) / steps if reduce_events else 0.0
+        return {"reduce_ms": reduce_ms, "dt": dt, "agg": agg, "ms": ms, "host_img": host_img, "params": params, "steps": steps, "samples_per_step": width * height * spp_total,
+                "last_seed": steps - 1, "spp": spp_total, "stream_mode": stream_mode,
+                "spec": {k: stats[-1][k] for k in ("spec_group", "spec_samples", "spec_serial_samples", "spec_probe_samples")}}
 
     # ---- the headline workload
     sd, what = build_scene(args.scene, args.width, args.height, args.tris)
@@ -223,7 +244,19 @@ def main():
     value = main_rec["samples_per_step"] * args.steps / dt / 1e6
     agg_all = rd.sum_over_ranks(agg)
     ranks = rd.gather_objects({"rank": rank, "device": device_index, "name": torch.cuda.get_device_name(device_index), "pid": os.getpid(),
-                               "kernel_ms_per_step": ((ms["ms_other"] + ms["ms_prepass"]) or sum(ms.values())) / max(1, args.steps)})
+                               "kernel_ms_per_step": ((ms["ms_other"] + ms["ms_prepass"]) or sum(ms.values())) / max(1, args.steps),
+                               "reduce_ms_per_step": main_rec["reduce_ms"]})
+    # ---- N > 1: the same shards once more in rustlight's own reference-order streams (the drop-in default), so that one multi-GPU run answers for both
+    # stream modes: per rank the chain pass (k_stream_spec), the evaluation pass (k_path_fused) and the reduce
+    ref_multi = None
+    if world > 1 and args.scene == "cbox" and args.stream_mode == "per_sample" and args.numerics == "exact" and not args.no_also:
+        rrec = time_workload(ctx, args.width, args.height, spp_total, "reference", "exact", 2, 1, shard=(rank, world))
+        per_rank = rd.gather_objects({"rank": rank, "chain_ms": rrec["ms"]["ms_prepass"] / 2, "kernel_ms": rrec["ms"]["ms_other"] / 2, "reduce_ms": rrec["reduce_ms"],
+                                      "chain_pass": rrec["spec"]})
+        if rank == 0:
+            ref_multi = {"workload": f"cbox {args.width}x{args.height}x{spp_total}spp in RL_STREAM_REFERENCE_ORDER on {world} shards", "steps": 2, "ms_per_step": rrec["dt"] / 2 * 1e3,
+                         "value": rrec["samples_per_step"] * 2 / rrec["dt"] / 1e6, "unit": "Msamples/s", "ranks": per_rank,
+                         "image_crc32": f"{zlib.crc32(rrec['host_img'].tobytes()):08x}"}
 
     if rank == 0:
         # ---- the N-GPU image must be the 1-GPU image, bit for bit (sums with zeros are exact): re-render the last step's
@@ -262,7 +295,7 @@ def main():
         if ms["ms_prepass"] > 0.0:
             avg = ms["ms_prepass"] / args.steps
             gbs = (32 * agg["camera_samples"] + 44 * agg["extension_rays"]) / args.steps / (avg * 1e-3) / 1e9
-            kernels["k_stream_chain"] = {"avg_launch_ms": avg, "launches": args.steps, "algorithmic_bytes_per_unit": "32/sample + 44/extension ray",
+            kernels["k_stream_spec" if main_rec["spec"]["spec_group"] else "k_stream_chain"] = {"avg_launch_ms": avg, "launches": args.steps, "algorithmic_bytes_per_unit": "32/sample + 44/extension ray",
                                          "achieved_GBps": gbs, "frac": gbs / PEAK_HBM_GBPS}
         dominant = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches"])
         # PMC numbers are NOT collected in this run (rocprofv3 --pmc needs its own passes: scratch/pmc_collect.sh).  They are quoted
@@ -294,10 +327,11 @@ def main():
         if is_default_workload(args) and world == 1:
             also = []
 
-            def sub(tag, rec, what, extra=None):
+            def sub(tag, rec, what, extra=None, scene_name="cbox"):
                 a, m = rec["agg"], rec["ms"]
                 width, height = rec["host_img"].shape[1], rec["host_img"].shape[0]
-                kernel_ms = {k: v / rec["steps"] for k, v in (("k_path_fused", m["ms_other"]), ("k_stream_chain", m["ms_prepass"])) if v > 0}
+                chain_kernel = "k_stream_spec" if rec["spec"]["spec_group"] else "k_stream_chain"
+                kernel_ms = {k: v / rec["steps"] for k, v in (("k_path_fused", m["ms_other"]), (chain_kernel, m["ms_prepass"])) if v > 0}
                 kms = sum(kernel_ms.values())
                 r = {"workload": tag, "what": what, "steps": rec["steps"], "ms_per_step": rec["dt"] / rec["steps"] * 1e3,
                      "value": rec["samples_per_step"] * rec["steps"] / rec["dt"] / 1e6, "unit": "Msamples/s",
@@ -306,13 +340,18 @@ def main():
                      "rays_per_s": (a["extension_rays"] + a["shadow_rays"]) / rec["dt"],
                      "frac": pipeline_bytes(a, width * height, rec["steps"]) / rec["steps"] / (kms * 1e-3) / 1e9 / PEAK_HBM_GBPS if kms else None,
                      "image_crc32": f"{zlib.crc32(rec['host_img'].tobytes()):08x}", "image_mean": float(rec["host_img"].mean())}
+                want = oracle_crc(scene_name, width, height, rec["spp"], rec["stream_mode"], rec["last_seed"])
+                r["oracle_crc32"] = want
+                r["oracle_crc_match"] = None if want is None else want == r["image_crc32"]        # the last timed frame against the CPU oracle's render of it
+                if rec["spec"]["spec_group"]:
+                    r["chain_pass"] = dict(rec["spec"], note="k_stream_spec: lanes per block, samples walked speculatively / serially / by the estimate probes in the last step")
                 r.update(extra or {})
                 also.append(r)
                 return r
 
-            r = time_workload(ctx, 1920, 1080, 128, "reference", "exact", 1, 1)
+            r = time_workload(ctx, 1920, 1080, 128, "reference", "exact", 3, 1)
             rr = sub("cbox_1080p_128spp_reference_order", r, "BASELINE configs[1] in RL_STREAM_REFERENCE_ORDER: rustlight's own stream assignment (one sampler per 16x16 block, "
-                     "src/integrators/mod.rs:420-435), the plugin / CLI default; two passes: k_stream_chain + k_path_fused")
+                     "src/integrators/mod.rs:420-435), the plugin / CLI default; two passes: k_stream_spec (the block chains, speculative windows) + k_path_fused")
             reference_order_value = rr["value"]
             ctx.close()
             for tag, name, w, h, steps, what in (
@@ -324,7 +363,7 @@ def main():
                 ctx2 = api.Context(api.Scene(sd2), device_index)
                 t_build = time.perf_counter() - t_build
                 r = time_workload(ctx2, w, h, 128, "per_sample", "exact", steps, 1)
-                sub(tag, r, what, {"context_build_s": round(t_build, 2), "triangles": int(sd2.n_triangles)})
+                sub(tag, r, what, {"context_build_s": round(t_build, 2), "triangles": int(sd2.n_triangles)}, scene_name=name)
                 ctx2.close()
 
         cpu = None
@@ -360,7 +399,7 @@ def main():
                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": workload, "spp_total": spp_total, "stream_mode": args.stream_mode, "numerics": args.numerics,
-                          "pipeline": ("two passes: k_stream_chain + k_path_fused" if ms["ms_prepass"] > 0 else "fused (k_path_fused)") if fused else "wavefront (raygen/extend/shade/shadow)",
+                          "pipeline": (f"two passes: {'k_stream_spec' if main_rec['spec']['spec_group'] else 'k_stream_chain'} + k_path_fused" if ms["ms_prepass"] > 0 else "fused (k_path_fused)") if fused else "wavefront (raygen/extend/shade/shadow)",
                           "parallelism": f"tile-shard x{world} + 1 RCCL reduce",
                           "timed_region": "rl_render_path + framebuffer reduce (N > 1) + framebuffer download to pinned host memory (SURVEY §8(d))",
                           "mean_vertices_per_sample": agg_all["vertices"] / max(1, agg_all["camera_samples"]),
@@ -369,8 +408,15 @@ def main():
                                "ranks": ranks, "image_crc32": f"{crc:08x}", "single_gpu_image_crc32": None if crc_single is None else f"{crc_single:08x}",
                                "crc_match": None if crc_single is None else crc_single == crc},
                "roofline": roofline, "cpu_baseline": cpu}
+        want = oracle_crc(args.scene, args.width, args.height, spp_total, args.stream_mode, args.steps - 1) if world == 1 and args.numerics == "exact" and args.tris == 0 else None
+        out["oracle_crc32"] = want
+        out["oracle_crc_match"] = None if want is None else want == f"{crc:08x}"        # the last timed frame == the CPU oracle's render of the same frame (tests/golden/bench_crcs.json)
+        if ref_multi is not None:
+            out["reference_order_value"] = ref_multi["value"]
+            out["reference_order"] = ref_multi
         if also is not None:
             out["reference_order_value"] = reference_order_value
+            out["reference_order_oracle_crc_match"] = rr["oracle_crc_match"]
             out["also"] = also
         print(json.dumps(out))
         sys.stdout.flush()

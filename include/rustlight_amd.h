@@ -118,6 +118,16 @@ void rl_scene_destroy(rl_scene* scene);
 int rl_scene_set_camera(rl_scene* scene, uint32_t width, uint32_t height, float fov_degrees,
                         int fov_axis, const float to_world[16], int flip);
 
+/* The camera as rustlight ALREADY HOLDS it (SURVEY.md 8(b) SceneDesc: `sample_to_camera[16], to_world[16]`): the two matrices Camera::generate reads
+ * (src/camera.rs:81-91: `sample_to_camera.transform_point(px / img)`, `to_world.transform_vector(d)`, position = to_world * origin, camera.rs:140-142),
+ * column-major as cgmath stores them (`let m: &[f32; 16] = camera.sample_to_camera.as_ref()`).  This is the entry a Rust host should use: nothing of
+ * Camera::new (cgmath's `perspective`, `inverse_transform`, the Fov::Y x aspect rule — camera.rs:31-67) is re-derived on this side, so the rays are
+ * rustlight's own by construction.  The two fields are private in rustlight: the host-side patch adds two accessors.
+ * rl_scene_set_camera (below, fov / flip: what the scene FILES carry) stays for the loaders and derives the same two matrices itself. */
+int rl_scene_set_camera_matrices(rl_scene* scene, uint32_t width, uint32_t height, const float sample_to_camera[16], const float to_world[16]);
+/* The matrices the scene's camera uses (whichever call set it): sample_to_camera, to_world (column-major), and Camera::position. */
+int rl_scene_get_camera_matrices(const rl_scene* scene, float sample_to_camera[16], float to_world[16], float position[3]);
+
 /* Camera::scale_image (src/camera.rs:73-78), the CLI's -s flag. */
 int rl_scene_scale_image(rl_scene* scene, float scale);
 
@@ -294,7 +304,7 @@ int rl_render_path(rl_context* ctx, const rl_path_params* params, const uint64_t
 
 /* ---- the whole scene as ONE plain-old-data description ("SceneDesc POD: counts + pointers") ------------------
  * What a Rust host fills from `&Scene` (src/scene.rs:16-30) in one go instead of the builder calls above; the arrays are only read during
- * the call.  Equivalent to: rl_scene_create, rl_scene_set_camera, rl_scene_add_bitmap (in order: their ids are 0, 1, ...), rl_scene_add_mesh
+ * the call.  Equivalent to: rl_scene_create, rl_scene_set_camera_matrices (has_camera_matrices) or rl_scene_set_camera, rl_scene_add_bitmap (in order: their ids are 0, 1, ...), rl_scene_add_mesh
  * (in order), rl_scene_set_medium, rl_scene_add_point_light / _directional_light (in order), rl_scene_set_environment[_map],
  * rl_scene_enable_ats, rl_scene_build_emitters — with the same checks and error codes. */
 typedef struct rl_mesh_desc {          /* struct Mesh (src/geometry.rs:107-119) */
@@ -317,6 +327,9 @@ typedef struct rl_scene_desc {
     uint32_t env_map_width, env_map_height; const float* env_map_rgb;   /* EnvironmentLightColor::Texture (0 x 0 / NULL: none) */
     int32_t has_medium; float sigma_a[3], sigma_s[3]; int32_t phase_type; float g;   /* HomogenousVolume */
     int32_t build_ats;                                             /* Scene::build_emitters(build_ats) */
+    /* != 0: the camera is (width, height, sample_to_camera, to_world) as rl_scene_set_camera_matrices takes it — rustlight's own matrices; fov_degrees,
+     * fov_axis and flip are ignored.  0: Camera::new from fov / flip (what scene files carry). */
+    int32_t has_camera_matrices; float sample_to_camera[16];
 } rl_scene_desc;
 int rl_scene_create_from_desc(const rl_scene_desc* desc, rl_scene** out);
 

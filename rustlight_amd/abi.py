@@ -41,7 +41,7 @@ class SceneDesc(C.Structure):
                 ("n_bitmaps", C.c_size_t), ("lights", C.POINTER(LightDesc)), ("n_lights", C.c_size_t), ("has_environment", C.c_int32),
                 ("environment_rgb", C.c_float * 3), ("env_map_width", C.c_uint32), ("env_map_height", C.c_uint32),
                 ("env_map_rgb", C.POINTER(C.c_float)), ("has_medium", C.c_int32), ("sigma_a", C.c_float * 3), ("sigma_s", C.c_float * 3),
-                ("phase_type", C.c_int32), ("g", C.c_float), ("build_ats", C.c_int32)]
+                ("phase_type", C.c_int32), ("g", C.c_float), ("build_ats", C.c_int32), ("has_camera_matrices", C.c_int32), ("sample_to_camera", C.c_float * 16)]
 
 
 class Sampler(C.Structure):

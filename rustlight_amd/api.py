@@ -28,7 +28,7 @@ NUMERICS_EXACT, NUMERICS_FAST = 0, 1
 
 # every symbol include/rustlight_amd.h declares (tests check the .so exports all of them)
 PUBLIC_SYMBOLS = [
-    "rl_scene_create", "rl_scene_create_from_desc", "rl_scene_destroy", "rl_scene_set_camera", "rl_scene_scale_image", "rl_scene_add_mesh",
+    "rl_scene_create", "rl_scene_create_from_desc", "rl_scene_destroy", "rl_scene_set_camera", "rl_scene_set_camera_matrices", "rl_scene_get_camera_matrices", "rl_scene_scale_image", "rl_scene_add_mesh",
     "rl_scene_add_bitmap", "rl_scene_set_medium", "rl_scene_add_point_light", "rl_scene_add_directional_light",
     "rl_scene_set_environment", "rl_scene_set_environment_map", "rl_scene_build_emitters", "rl_scene_enable_ats", "rl_scene_load_pbrt", "rl_scene_load_mitsuba", "rl_scene_load",
     "rl_scene_image_size", "rl_scene_counts", "rl_sampler_seed", "rl_sampler_next_u64", "rl_sampler_next_f32",
@@ -64,6 +64,8 @@ def lib():
     L.rl_scene_destroy.argtypes = [vp]
     L.rl_scene_destroy.restype = None
     L.rl_scene_set_camera.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_float, C.c_int, f32p, C.c_int]
+    L.rl_scene_set_camera_matrices.argtypes = [vp, C.c_uint32, C.c_uint32, f32p, f32p]
+    L.rl_scene_get_camera_matrices.argtypes = [vp, f32p, f32p, f32p]
     L.rl_scene_scale_image.argtypes = [vp, C.c_float]
     L.rl_scene_add_mesh.argtypes = [vp, f32p, C.c_size_t, u32p, C.c_size_t, f32p, f32p, C.POINTER(abi.BsdfDesc), f32p]
     L.rl_scene_add_bitmap.argtypes = [vp, C.c_uint32, C.c_uint32, f32p]
@@ -149,7 +151,9 @@ class IndependentSampler:
 class Scene:
     """Host-side flattened `Scene` (src/scene.rs:16-30)."""
 
-    def __init__(self, sd: Optional[S.SceneData] = None, handle=None):
+    def __init__(self, sd: Optional[S.SceneData] = None, handle=None, camera_matrices=None):
+        """camera_matrices = (sample_to_camera, to_world), column-major 16-vectors: the camera as rustlight's `Camera` holds it
+        (rl_scene_set_camera_matrices) instead of Camera::new's arguments."""
         L = lib()
         self.sd = sd
         if handle is not None:
@@ -159,7 +163,11 @@ class Scene:
             _check(L.rl_scene_create(C.byref(h)))
             self.h = h
             tw = np.ascontiguousarray(sd.to_world, dtype=np.float32)
-            _check(L.rl_scene_set_camera(self.h, sd.width, sd.height, sd.fov, sd.fov_axis, abi.fptr(tw), int(sd.flip)))
+            if camera_matrices is not None:
+                stc, twm = (np.ascontiguousarray(m, dtype=np.float32).ravel() for m in camera_matrices)
+                _check(L.rl_scene_set_camera_matrices(self.h, sd.width, sd.height, abi.fptr(stc), abi.fptr(twm)))
+            else:
+                _check(L.rl_scene_set_camera(self.h, sd.width, sd.height, sd.fov, sd.fov_axis, abi.fptr(tw), int(sd.flip)))
             for (w, hgt, rgb) in sd.bitmaps:
                 a = np.ascontiguousarray(rgb, dtype=np.float32)
                 _check(L.rl_scene_add_bitmap(self.h, w, hgt, abi.fptr(a)))
@@ -187,9 +195,15 @@ class Scene:
             _check(L.rl_scene_enable_ats(self.h, 1))
         _check(L.rl_scene_build_emitters(self.h))
 
+    def camera_matrices(self):
+        """(sample_to_camera[16], to_world[16], position[3]) the scene's camera uses, column-major."""
+        a, b, c = np.zeros(16, np.float32), np.zeros(16, np.float32), np.zeros(3, np.float32)
+        _check(lib().rl_scene_get_camera_matrices(self.h, abi.fptr(a), abi.fptr(b), abi.fptr(c)))
+        return a, b, c
+
     @classmethod
-    def from_desc(cls, sd: S.SceneData) -> "Scene":
-        """The same scene through the one-call POD entry (rl_scene_create_from_desc, SURVEY §8(b) "SceneDesc")."""
+    def from_desc(cls, sd: S.SceneData, camera_matrices=None) -> "Scene":
+        """The same scene through the one-call POD entry (rl_scene_create_from_desc, SURVEY §8(b) "SceneDesc"); camera_matrices as in __init__."""
         keep = []                                  # numpy arrays must outlive the call
         def fp(a):
             if a is None:
@@ -199,6 +213,11 @@ class Scene:
         d = abi.SceneDesc()
         d.width, d.height, d.fov_degrees, d.fov_axis, d.flip = sd.width, sd.height, sd.fov, sd.fov_axis, int(sd.flip)
         d.to_world = (C.c_float * 16)(*np.asarray(sd.to_world, np.float32).ravel())
+        if camera_matrices is not None:
+            d.has_camera_matrices = 1
+            d.sample_to_camera = (C.c_float * 16)(*np.asarray(camera_matrices[0], np.float32).ravel())
+            d.to_world = (C.c_float * 16)(*np.asarray(camera_matrices[1], np.float32).ravel())
+            d.fov_degrees, d.fov_axis, d.flip = 0.0, 0, 0
         meshes = (abi.MeshDesc * max(1, len(sd.meshes)))()
         for k, m in enumerate(sd.meshes):
             v, i, n, uv, e = abi.mesh_arrays(m)

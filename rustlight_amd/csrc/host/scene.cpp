@@ -148,6 +148,27 @@ int rl_scene_set_camera(rl_scene* scene, uint32_t width, uint32_t height, float 
     return scene->rebuild_camera() ? RL_OK : RL_ERR_INVALID_ARGUMENT;
 }
 
+// the camera from the two matrices rustlight's Camera holds (camera.rs:5-15): nothing of Camera::new is re-derived
+int rl_scene_set_camera_matrices(rl_scene* scene, uint32_t width, uint32_t height, const float sample_to_camera[16], const float to_world[16]) {
+    if (!scene || !sample_to_camera || !to_world || width == 0 || height == 0) return RL_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < 16; i++)
+        if (!std::isfinite(sample_to_camera[i]) || !std::isfinite(to_world[i])) { rl_set_error("camera matrices must be finite"); return RL_ERR_INVALID_ARGUMENT; }
+    scene->width = width; scene->height = height;
+    scene->fov_degrees = 0.0f; scene->fov_axis = 0; scene->flip = false;       // (not derived from: the matrices are authoritative)
+    scene->to_world = Mat4::from_cols(to_world);
+    scene->sample_to_camera = Mat4::from_cols(sample_to_camera);
+    scene->cam_pos = scene->to_world.xform_point({0.0f, 0.0f, 0.0f});   // Camera::position (camera.rs:140-142)
+    scene->has_camera = true;
+    return RL_OK;
+}
+int rl_scene_get_camera_matrices(const rl_scene* scene, float sample_to_camera[16], float to_world[16], float position[3]) {
+    if (!scene || !scene->has_camera || !sample_to_camera || !to_world || !position) return RL_ERR_INVALID_ARGUMENT;
+    scene->sample_to_camera.to_cols(sample_to_camera);
+    scene->to_world.to_cols(to_world);
+    position[0] = scene->cam_pos.x; position[1] = scene->cam_pos.y; position[2] = scene->cam_pos.z;
+    return RL_OK;
+}
+
 int rl_scene_scale_image(rl_scene* scene, float s) {
     if (!scene || !scene->has_camera) return RL_ERR_INVALID_ARGUMENT;
     // the scale is caller input: a negative, NaN or infinite value must be refused before it reaches the float -> unsigned conversion
@@ -444,7 +465,8 @@ int rl_scene_create_from_desc(const rl_scene_desc* d, rl_scene** out) {
     int rc = rl_scene_create(&s);
     if (rc != RL_OK) return rc;
     auto fail = [&](int code) { rl_scene_destroy(s); return code < 0 ? code : RL_ERR_INVALID_ARGUMENT; };
-    if ((rc = rl_scene_set_camera(s, d->width, d->height, d->fov_degrees, d->fov_axis, d->to_world, d->flip)) != RL_OK) return fail(rc);
+    if ((rc = d->has_camera_matrices ? rl_scene_set_camera_matrices(s, d->width, d->height, d->sample_to_camera, d->to_world)
+                                     : rl_scene_set_camera(s, d->width, d->height, d->fov_degrees, d->fov_axis, d->to_world, d->flip)) != RL_OK) return fail(rc);
     for (size_t i = 0; i < d->n_bitmaps; i++)
         if ((rc = rl_scene_add_bitmap(s, d->bitmaps[i].width, d->bitmaps[i].height, d->bitmaps[i].rgb)) < 0) return fail(rc);
     for (size_t i = 0; i < d->n_meshes; i++) {

@@ -10,7 +10,7 @@
 #include <string.h>
 
 #include "rustlight_amd.h"
-#include "scene_data.h"   /* SCENE_WIDTH, SCENE_HEIGHT, SCENE_SPP, SCENE_SEED, SCENE_STREAM_MODE, scene_meshes[], SCENE_N_MESHES, scene_fov, scene_to_world[16], scene_flip */
+#include "scene_data.h"   /* SCENE_WIDTH, SCENE_HEIGHT, SCENE_SPP, SCENE_SEED, SCENE_STREAM_MODE, scene_meshes[], SCENE_N_MESHES, scene_sample_to_camera[16], scene_to_world[16] (and scene_fov / scene_fov_axis / scene_flip for -DSCENE_CAMERA_FROM_FOV) */
 
 static int fail(const char* what, int rc) {
     fprintf(stderr, "%s failed: %d (%s)\n", what, rc, rl_last_error());
@@ -32,9 +32,15 @@ int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: render_desc out.raw\n"); return 2; }
     if (rl_device_count(&n_dev) != RL_OK || n_dev < 1) { fprintf(stderr, "no HIP device: the MI355X path has no CPU fallback\n"); return 3; }
 
+    (void)scene_fov; (void)scene_fov_axis; (void)scene_flip; (void)scene_sample_to_camera;   /* (one of the two camera forms stays unused) */
     memset(&desc, 0, sizeof(desc));
     desc.width = SCENE_WIDTH; desc.height = SCENE_HEIGHT;
-    desc.fov_degrees = scene_fov; desc.fov_axis = scene_fov_axis; desc.flip = scene_flip;
+#ifdef SCENE_CAMERA_FROM_FOV
+    desc.fov_degrees = scene_fov; desc.fov_axis = scene_fov_axis; desc.flip = scene_flip;          /* Camera::new's arguments (what scene files carry) */
+#else
+    desc.has_camera_matrices = 1;                                                                    /* the two matrices rustlight's Camera holds (camera.rs:5-15) */
+    memcpy(desc.sample_to_camera, scene_sample_to_camera, sizeof(desc.sample_to_camera));
+#endif
     memcpy(desc.to_world, scene_to_world, sizeof(desc.to_world));
     desc.meshes = scene_meshes; desc.n_meshes = SCENE_N_MESHES;
     if ((rc = rl_scene_create_from_desc(&desc, &scene)) != RL_OK) return fail("rl_scene_create_from_desc", rc);

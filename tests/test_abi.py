@@ -96,6 +96,28 @@ def test_host_bvh_and_camera_equal_oracle(built, maker):
     assert ps.counts()["emitters"] == os_.info()["emitters"]
 
 
+def test_camera_from_matrices_is_the_same_camera(built):
+    """rl_scene_set_camera_matrices / rl_scene_desc.has_camera_matrices (SURVEY 8(b) SceneDesc: `sample_to_camera[16], to_world[16]`): the camera handed over as
+    the two matrices rustlight's Camera holds (camera.rs:5-15) generates the rays Camera::new's arguments give, bit for bit — through the builder call
+    and through the one-call POD; non-finite matrices are refused."""
+    for sd in (scenes.cbox(48, 32), scenes.living_room(40, 24, n_spheres=1, tess=4)):
+        base = api.Scene(sd)
+        stc, tw, pos = base.camera_matrices()
+        assert np.isfinite(stc).all() and np.isfinite(tw).all()
+        np.testing.assert_array_equal(tw, np.asarray(sd.to_world, np.float32).ravel())
+        for other in (api.Scene(sd, camera_matrices=(stc, tw)), api.Scene.from_desc(sd, camera_matrices=(stc, tw))):
+            for a, b in zip(other.camera_matrices(), (stc, tw, pos)):
+                np.testing.assert_array_equal(a, b)
+            for px, py in [(0.0, 0.0), (10.25, 3.5), (sd.width - 0.001, sd.height - 0.5)]:
+                for a, b in zip(other.camera_ray(px, py), base.camera_ray(px, py)):
+                    np.testing.assert_array_equal(a, b)
+            for a, b in zip(other.debug_bvh(), base.debug_bvh()):
+                np.testing.assert_array_equal(a, b)
+    bad = stc.copy(); bad[5] = np.nan
+    with pytest.raises(api.RustlightError):
+        api.Scene(sd, camera_matrices=(bad, tw))
+
+
 @pytest.mark.parametrize("maker", [lambda: scenes.many_lights(32, 32, 4, glowing_spheres=3), lambda: scenes.many_lights(16, 16, 1), lambda: scenes.cbox(16, 16)])
 def test_light_tree_build_matches_the_oracle(built, maker):
     """`rl_scene_enable_ats`: the host builds LightSamplerATS (cone unions, bucketed split, itertools::partition order)

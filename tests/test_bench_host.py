@@ -71,3 +71,16 @@ def test_also_records_only_on_the_default_single_gpu_run():
 def test_pipeline_bytes_is_the_survey_formula():
     """algorithmic bytes = 248 B per camera sample + 352 B per expanded vertex + 12 B per pixel per pass."""
     assert bench.pipeline_bytes({"camera_samples": 10, "vertices": 7}, pixels=5, steps=2) == 248 * 10 + 352 * 7 + 12 * 5 * 2
+
+
+def test_bench_golden_table_covers_the_timed_frames():
+    """tests/golden/bench_crcs.json (oracle CRCs of the frames bench.py times; tests/golden/make_bench_golden.py): every frame of the default run is in it,
+    keyed the way bench.oracle_crc looks it up — the headline at the driver's step count (--steps 20: seed 19) and at the default (seed 2), the `also` records
+    at their three steps (seed 2), BASELINE configs[0]."""
+    import bench
+    for wl, w, h, spp, mode, seed in (("cbox", 1920, 1080, 128, "per_sample", 19), ("cbox", 1920, 1080, 128, "per_sample", 2), ("cbox", 1920, 1080, 128, "reference", 2),
+                                      ("cbox", 1080, 1080, 128, "per_sample", 2), ("cbox_medium", 1920, 1080, 128, "per_sample", 2), ("living_room", 1920, 1080, 128, "per_sample", 2),
+                                      ("cbox", 256, 256, 16, "reference", 0)):
+        crc = bench.oracle_crc(wl, w, h, spp, mode, seed)
+        assert crc is not None and len(crc) == 8, (wl, w, h, spp, mode, seed)
+    assert bench.oracle_crc("cbox", 1920, 1080, 128, "per_sample", 7) is None        # a frame nobody rendered on the CPU: no claim

@@ -636,13 +636,13 @@ def test_full_size_properties(built):
         np.testing.assert_array_equal(a[y0:y0 + 16, x0:x0 + 16], ref[y0:y0 + 16, x0:x0 + 16])
 
 
-def _oracle_blocks_match(sd, osc, img, seeds, blocks, **okw):
+def _oracle_blocks_match(sd, osc, img, seeds, blocks, stream_mode=1, **okw):
     """`blocks`: indices b = (x/16) * ceil(H/16) + y/16 — each is rendered alone by the oracle (a shard of one block) and compared bit for bit."""
     nby = (sd.height + 15) // 16
     nb = ((sd.width + 15) // 16) * nby
     verts = 0
     for b in blocks:
-        ref, ost = osc.render(seeds=seeds, stream_mode=1, eval_order=1, shard_index=int(b), shard_count=nb, **okw)
+        ref, ost = osc.render(seeds=seeds, stream_mode=stream_mode, eval_order=1, shard_index=int(b), shard_count=nb, **okw)
         x0, y0 = (b // nby) * 16, (b % nby) * 16
         np.testing.assert_array_equal(img[y0:y0 + 16, x0:x0 + 16], ref[y0:y0 + 16, x0:x0 + 16], err_msg=f"block {b} at ({x0}, {y0})")
         verts += ost["vertices"]
@@ -681,6 +681,29 @@ def test_full_size_mixed_materials(built):
     osc = orc.Scene(sd)
     blocks = _busiest_blocks(a, 4) + [60 * 68 + 34, 30 * 68 + 50]
     assert _oracle_blocks_match(sd, osc, a, seeds, blocks, spp=4) > 4000
+    _full_size_default_mode(sd, ctx, osc, seeds, blocks, spp=8, min_verts=8000)
+
+
+def _full_size_default_mode(sd, ctx, osc, seeds, blocks, spp, min_verts):
+    """The same full-size frame in the drop-in default, RL_STREAM_REFERENCE_ORDER (rustlight's own stream assignment, integrators/mod.rs:403-450), in two
+    passes: the blocks equal the oracle's walk of the same block streams bit for bit, and the two forms of the chain pass — the speculative one
+    (k_stream_spec, forced: `spp` is too small for it to be chosen) and the one-lane-per-block walk (k_stream_chain) — give the same frame and counters."""
+    keys = ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws")
+    os.environ["RL_SPEC_FORCE"] = "1"
+    try:
+        r, st = ctx.render(seeds, api.path_params(spp=spp, stream_mode=api.STREAM_REFERENCE_ORDER))
+    finally:
+        del os.environ["RL_SPEC_FORCE"]
+    assert st["ms_prepass"] > 0.0 and st["spec_group"] > 0 and st["camera_samples"] == sd.width * sd.height * spp and np.isfinite(r).all()
+    assert _oracle_blocks_match(sd, osc, r, seeds, blocks, stream_mode=0, spp=spp) > min_verts
+    os.environ["RL_CHAIN_SERIAL"] = "1"
+    try:
+        r2, st2 = ctx.render(seeds, api.path_params(spp=spp, stream_mode=api.STREAM_REFERENCE_ORDER))
+    finally:
+        del os.environ["RL_CHAIN_SERIAL"]
+    assert st2["spec_group"] == 0
+    np.testing.assert_array_equal(r, r2)
+    assert all(st[k] == st2[k] for k in keys)
 
 
 def test_full_size_medium(built):
@@ -697,6 +720,7 @@ def test_full_size_medium(built):
     osc = orc.Scene(sd)
     blocks = _busiest_blocks(a, 4) + [60 * 68 + 34, 10 * 68 + 5]
     assert _oracle_blocks_match(sd, osc, a, seeds, blocks, spp=2) > 20000
+    _full_size_default_mode(sd, ctx, osc, seeds, blocks[:4], spp=8, min_verts=40000)
 
 
 def test_cfg1_reference_order_whole_frame(built):
@@ -900,6 +924,23 @@ def test_full_size_reference_order(built):
         del os.environ["RL_REF_SINGLE_PASS"]
     np.testing.assert_array_equal(a, b1)
     assert all(st[k] == st1[k] for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws"))
+    _full_size_default_mode(sd, ctx, osc, seeds, [60 * 68 + 34, 66 * 68 + 46, 66 * 68 + 6, 26 * 68 + 34], spp=8, min_verts=4000)
+
+
+def test_bench_frames_equal_the_oracle(built):
+    """tests/golden/bench_crcs.json (made by tests/golden/make_bench_golden.py in the build container: the parity build of the CPU oracle renders the very
+    frames bench.py times) against the GPU: BASELINE configs[0] whole (256 x 256 x 16 spp, reference-order streams) and configs[1] at full size in
+    rustlight's own reference-order streams (1920 x 1080 x 128 spp, master seed 2 = the last of bench.py's three timed steps) — the CRC-32 of the float32
+    image.  bench.py prints the same comparison as `oracle_crc_match` / `reference_order_oracle_crc_match` for every frame in the table."""
+    import json
+    import zlib
+    table = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_crcs.json")))
+    for w, h, spp, seed in ((256, 256, 16, 0), (1920, 1080, 128, 2)):
+        e = table[f"cbox:{w}x{h}x{spp}:reference:seed{seed}"]
+        img, st = api.Context(api.Scene(scenes.cbox(w, h)), 0).render(api.IndependentSampler(seed).block_seeds(w, h), api.path_params(spp=spp, stream_mode=api.STREAM_REFERENCE_ORDER))
+        assert f"{zlib.crc32(img.tobytes()):08x}" == e["crc32"], (w, h, spp)
+        assert (st["camera_samples"], st["vertices"], st["rng_draws"]) == (e["camera_samples"], e["vertices"], e["rng_draws"])
+        assert (st["spec_group"] > 0) == (spp == 128)          # the large frame goes through k_stream_spec, the small one through k_stream_chain
 
 
 def test_multi_context_rccl_reduce(built, cbox64, ctx_cbox):
@@ -1041,6 +1082,21 @@ def _c_initializer(v):
     return str(int(v))
 
 
+def test_verbatim_reference_scene_renders_like_the_fixture(built):
+    """examples/web/index.html:9-43 verbatim (tests/golden/web_cbox_verbatim.pbrt) through rl_scene_load_pbrt renders the image of the in-memory
+    fixture — and of the oracle — bit for bit, in rustlight's own reference-order streams."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "web_cbox_verbatim.pbrt")
+    sd = scenes.cbox(512, 512)
+    seeds = api.IndependentSampler(4).block_seeds(512, 512)
+    pp = api.path_params(spp=2, stream_mode=api.STREAM_REFERENCE_ORDER)
+    img, st = api.Context(api.Scene.load_pbrt(path), 0).render(seeds, pp)
+    ref, st2 = api.Context(api.Scene(sd), 0).render(seeds, pp)
+    np.testing.assert_array_equal(img, ref)
+    oimg, ost = orc.Scene(sd).render(master_seed=4, spp=2, stream_mode=0, eval_order=1)
+    np.testing.assert_array_equal(img, oimg)
+    assert all(st[k] == st2[k] == ost[k] for k in ("camera_samples", "vertices", "extension_rays", "rng_draws"))
+
+
 def test_c99_consumer_renders_the_same_image(built, tmp_path):
     """The drop-in boundary from plain C (gcc -std=c99 -pedantic, nothing but include/rustlight_amd.h + the shared library) — what a Rust FFI
     caller does, minus Rust: rl_scene_create_from_desc -> rl_context_create -> rl_generate_block_seeds -> rl_render_path with the CLI's
@@ -1053,7 +1109,9 @@ def test_c99_consumer_renders_the_same_image(built, tmp_path):
     lines = ["#include <stdint.h>", f"#define SCENE_WIDTH {W}", f"#define SCENE_HEIGHT {H}", f"#define SCENE_SPP {spp}", f"#define SCENE_SEED {seed}ull",
              "#define SCENE_STREAM_MODE RL_STREAM_REFERENCE_ORDER", f"#define SCENE_N_MESHES {len(sd.meshes)}",
              f"static const float scene_fov = {float(np.float32(sd.fov)).hex()}f;", f"static const int scene_fov_axis = {int(sd.fov_axis)};", f"static const int scene_flip = {int(sd.flip)};",
-             "static const float scene_to_world[16] = {" + ", ".join(float(x).hex() + "f" for x in np.asarray(sd.to_world, np.float32).ravel()) + "};"]
+             "static const float scene_to_world[16] = {" + ", ".join(float(x).hex() + "f" for x in np.asarray(sd.to_world, np.float32).ravel()) + "};",
+             # the camera as rustlight's Camera holds it (camera.rs:5-15): what the consumer passes (rl_scene_desc.has_camera_matrices)
+             "static const float scene_sample_to_camera[16] = {" + ", ".join(float(x).hex() + "f" for x in api.Scene(sd).camera_matrices()[0]) + "};"]
     for i, m in enumerate(sd.meshes):
         v, idx, n, uv, e = abi.mesh_arrays(m)
         lines.append(f"static const float mesh{i}_v[] = {{" + ", ".join(float(x).hex() + "f" for x in v.ravel()) + "};")
@@ -1075,6 +1133,13 @@ def test_c99_consumer_renders_the_same_image(built, tmp_path):
     out = subprocess.run([str(exe), str(tmp_path / "img.raw")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     img = np.fromfile(tmp_path / "img.raw", dtype=np.float32).reshape(H, W, 3)
+    # the same consumer with Camera::new's arguments instead of the matrices (-DSCENE_CAMERA_FROM_FOV): the same image
+    exe2 = tmp_path / "render_desc_fov"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-DSCENE_CAMERA_FROM_FOV", "-I", os.path.join(root, "include"), "-I", str(tmp_path),
+                           os.path.join(root, "tests", "c_consumer", "render_desc.c"), "-o", str(exe2), "-L", libdir, "-lrustlight_amd", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out2 = subprocess.run([str(exe2), str(tmp_path / "img2.raw")], capture_output=True, text=True, timeout=300)
+    assert out2.returncode == 0, out2.stderr
+    np.testing.assert_array_equal(np.fromfile(tmp_path / "img2.raw", dtype=np.float32).reshape(H, W, 3), img)
     counters = dict(zip(out.stdout.split()[0::2], (int(x) for x in out.stdout.split()[1::2])))
     ref, st = api.Context(api.Scene(sd), 0).render(api.IndependentSampler(seed).block_seeds(W, H), api.path_params(spp=spp, stream_mode=api.STREAM_REFERENCE_ORDER))
     np.testing.assert_array_equal(img, ref)

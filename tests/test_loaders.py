@@ -20,6 +20,22 @@ def _same_scene(loaded, direct):
         np.testing.assert_array_equal(loaded.camera_ray(*px)[1], direct.camera_ray(*px)[1])
 
 
+def test_verbatim_reference_scene_text_loads_as_the_fixture(built):
+    """The one scene text in the reference tree written by someone else — the textarea of examples/web/index.html:9-43, copied verbatim by
+    tests/golden/extract_web_scene.py (pbrt-v3 exporter formatting: `Integrator`, `Sampler "sobol"`, `PixelFilter`, `"string filename"`, trailing blanks,
+    `1.74846e-007` exponents, `-0`; materials declared in another order than the shapes use them) — through rl_scene_load_pbrt must be the in-memory
+    fixture rustlight_amd/scenes.py builds from SURVEY App. C: same BVH (boxes, topology, primitive order), camera matrices and rays, emitter table.
+    (A `-m gpu` test renders both: tests/test_gpu_parity.py::test_verbatim_reference_scene_renders_like_the_fixture.)"""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "web_cbox_verbatim.pbrt")
+    text = open(path, encoding="utf-8").read()
+    assert text.startswith('Integrator "path" "integer maxdepth" [ 65 ] \n') and 'Sampler "sobol"' in text and text.rstrip().endswith("WorldEnd")     # the verbatim text, not a regeneration
+    loaded = api.Scene.load_pbrt(path)
+    direct = api.Scene(scenes.cbox(512, 512))
+    _same_scene(loaded, direct)
+    for a, b in zip(loaded.camera_matrices(), direct.camera_matrices()):
+        np.testing.assert_array_equal(a, b)
+
+
 def _mts_cbox(w=96, h=64):
     sd = scenes.cbox(w, h)
     sd.flip = True                     # MTSSceneLoader: Camera::new(.., flip = true) (scene_loader.rs:337)
