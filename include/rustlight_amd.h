@@ -128,6 +128,16 @@ int rl_scene_set_camera_matrices(rl_scene* scene, uint32_t width, uint32_t heigh
 /* The matrices the scene's camera uses (whichever call set it): sample_to_camera, to_world (column-major), and Camera::position. */
 int rl_scene_get_camera_matrices(const rl_scene* scene, float sample_to_camera[16], float to_world[16], float position[3]);
 
+/* EmissionType (src/geometry.rs:99-104) of a light mesh: the constant colour rl_scene_add_mesh gave it, or one of the two uv-dependent kinds
+ * Mesh::emit evaluates (geometry.rs:184-206): HSV { scale } = scale * (x, 1 - x, 0) with x = |uv.x| % 1, Texture { scale, img } = scale * img.pixel_uv(uv).
+ * The mesh must be a light and — for the two uv-dependent kinds — carry uv coordinates (the reference's `uv.unwrap()` panics otherwise).
+ * Emitter::flux takes Color::value(scale) for them (emitter.rs:591-599).  Call before rl_scene_build_emitters. */
+typedef enum rl_emission_type { RL_EMISSION_COLOR = 0, RL_EMISSION_HSV = 1, RL_EMISSION_TEXTURE = 2 } rl_emission_type;
+int rl_scene_set_mesh_emission(rl_scene* scene, uint32_t mesh, int type, float scale, int bitmap_id);
+/* The CLI's `-x hvs-light` / `-x texture-light` (examples/cli.rs:410-429): EVERY light mesh becomes HSV { scale } / Texture { scale, img = bitmap_id } with
+ * scale = Color::luminance of its colour (1 if it already was uv-dependent).  `type`: RL_EMISSION_HSV or RL_EMISSION_TEXTURE. */
+int rl_scene_override_light_emission(rl_scene* scene, int type, int bitmap_id);
+
 /* Camera::scale_image (src/camera.rs:73-78), the CLI's -s flag. */
 int rl_scene_scale_image(rl_scene* scene, float scale);
 
@@ -314,6 +324,7 @@ typedef struct rl_mesh_desc {          /* struct Mesh (src/geometry.rs:107-119) 
     const float* uv;                               /* uv per vertex or NULL */
     rl_bsdf_desc bsdf;
     int32_t has_emission; float emission_rgb[3];   /* EmissionType::Color */
+    int32_t emission_type; float emission_scale; int32_t emission_bitmap_id;   /* rl_emission_type; != RL_EMISSION_COLOR: as rl_scene_set_mesh_emission (needs has_emission and uv) */
 } rl_mesh_desc;
 typedef struct rl_bitmap_desc { uint32_t width, height; const float* rgb; } rl_bitmap_desc;
 typedef struct rl_light_desc { int32_t kind;       /* 0 = PointEmitter { position = a }, 1 = DirectionalLight { direction = a } */

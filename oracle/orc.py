@@ -75,6 +75,7 @@ def lib():
                                          C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                          C.POINTER(abi.BsdfDesc), C.POINTER(C.c_float)]
         L.orc_scene_set_medium.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_float]
+        L.orc_scene_set_mesh_emission.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int]
         L.orc_scene_build.argtypes = [C.c_void_p]
         L.orc_scene_add_point_light.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_scene_add_directional_light.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -175,6 +176,9 @@ class Scene:
             rc = L.orc_scene_add_mesh(self.h, abi.fptr(v), v.shape[0], abi.u32ptr(i), i.shape[0], abi.fptr(n),
                                       abi.fptr(uv), C.byref(bd), abi.fptr(e))
             assert rc >= 0
+            if getattr(m, "emission_kind", None):          # EmissionType::HSV / Texture (geometry.rs:99-104)
+                ek = m.emission_kind
+                assert L.orc_scene_set_mesh_emission(self.h, rc, 1 if ek[0] == "hsv" else 2, float(ek[1]), int(ek[2]) if len(ek) > 2 else -1) == 0
         if sd.medium is not None:
             sa = np.asarray(sd.medium.sigma_a, dtype=np.float32)
             ss = np.asarray(sd.medium.sigma_s, dtype=np.float32)

@@ -769,8 +769,11 @@ struct Mesh {
     std::vector<V3> normals;
     std::vector<V2> uv;
     BSDF bsdf;
-    bool is_light = false;   // EmissionType::Color
+    bool is_light = false;   // EmissionType::{Color, HSV, Texture}: anything but Zero
     Color emission = Color::zero();
+    int emission_type = 0;           // 0: EmissionType::Color { v = emission }; 1: HSV { scale }; 2: Texture { scale, img } (geometry.rs:99-104)
+    float emission_scale = 1.0f;
+    const Bitmap* emission_img = nullptr;
     Distribution1D cdf;
     size_t n_tris() const { return indices.size() / 3; }
 
@@ -795,7 +798,28 @@ struct Mesh {
         cdf = Distribution1D::normalize(areas);
         return true;
     }
-    Color emit() const { return is_light ? emission : Color::zero(); }  // geometry.rs:184-206 (Zero | Color)
+    // Mesh::emit (geometry.rs:184-206).  HSV / Texture `uv.unwrap()`: a light mesh without uv panics in the reference — the API refuses to put such an
+    // emission on a mesh without uv, so has_uv is true whenever it matters.
+    Color emit(bool huv, V2 uv) const {
+        if (!is_light) return Color::zero();
+        if (emission_type == 1) {
+            const Color c1{1.0f, 0.0f, 0.0f}, c2{0.0f, 1.0f, 0.0f};
+            float x = std::fmod(std::fabs(uv.x), 1.0f);                 // uv.x.abs() % 1.0
+            Color c = x * c1 + (1.0f - x) * c2;
+            return c * emission_scale;                                  // Color * f32: guarded (structure.rs:278-292)
+        }
+        if (emission_type == 2) {
+            if (!huv || !emission_img) return Color::zero();
+            float ux = modulo1(uv.x), uy = modulo1(uv.y);               // Bitmap::pixel_uv (structure.rs:434-453)
+            size_t x = as_usize(ux * (float)emission_img->w), y = as_usize(uy * (float)emission_img->h);
+            size_t i = (size_t)emission_img->w * y + x;
+            Color c = i >= emission_img->colors.size() ? Color::zero() : emission_img->colors[i];
+            return c * emission_scale;
+        }
+        return emission;
+    }
+    // the colour Emitter::flux uses (emitter.rs:591-599): the constant emission, or Color::value(scale) for the uv-dependent kinds ("TODO" there)
+    Color flux_emission() const { return !is_light ? Color::zero() : (emission_type == 0 ? emission : Color{emission_scale, emission_scale, emission_scale}); }
     float pdf() const { return 1.0f / cdf.total(); }
 
     // geometry.rs:358-410
@@ -879,7 +903,7 @@ struct Mesh {
 
 // ------------------------------------------------------------------------------------------
 // LightSampling & the mesh area emitter (src/emitter.rs:10-44, 570-688)
-struct LightSampling { int emitter; PDF pdf; V3 p, n, d; Color weight; bool is_valid() const { return !pdf.is_zero(); } };
+struct LightSampling { int emitter; PDF pdf; V3 p, n, d; Color weight; bool has_uv = false; V2 uv{0, 0}; bool is_valid() const { return !pdf.is_zero(); } };
 struct LightSamplingPDF { V3 o, p, n, dir; };
 
 static PDF mesh_direct_pdf(const Mesh& m, const LightSamplingPDF& ls) {  // emitter.rs:571-579
@@ -896,10 +920,10 @@ static LightSampling mesh_direct_sample(const Mesh& m, V3 p, float r, V2 uv) {  
     float geom = dist != 0.0f ? rmax(dot(sp.n, -d), 0.0f) / (dist * dist) : 0.0f;
     float pdf_area = sp.pdf.value();
     PDF pdf = sp.pdf.as_solid_angle_geom(geom);
-    Color weight = pdf.is_zero() ? Color::zero() : m.emit() * geom / pdf_area;
-    return {-1, pdf, sp.p, sp.n, d, weight};
+    Color weight = pdf.is_zero() ? Color::zero() : m.emit(sp.has_uv, sp.uv) * geom / pdf_area;
+    return {-1, pdf, sp.p, sp.n, d, weight, sp.has_uv, sp.uv};
 }
-static Color mesh_flux(const Mesh& m) { return m.cdf.total() * m.emit() * PI_F; }  // emitter.rs:591-599
+static Color mesh_flux(const Mesh& m) { return m.cdf.total() * m.flux_emission() * PI_F; }  // emitter.rs:591-599
 
 // solve_quadratic (src/math.rs:324-352) and BoundingSphere::intersect (src/structure.rs:894-917)
 static bool solve_quadratic(float a, float b, float c, float* x0, float* x1) {
@@ -1353,7 +1377,9 @@ struct Scene {
                 LightBounds& b = lp.bounds;
                 b.w = normalize(n);
                 b.theta_o = 0.0f; b.theta_e = 1.57079632679489661923f;
-                b.phi = m.emit().channel_max() * magnitude(n) * 0.5f;
+                V2 uvc{0, 0};                                           // "For now we interpolate at the middle" (emitter.rs:741-750)
+                if (m.has_uv) { V2 a0 = m.uv[m.indices[3 * i]], a1 = m.uv[m.indices[3 * i + 1]], a2 = m.uv[m.indices[3 * i + 2]]; uvc = {((a0.x + a1.x) + a2.x) / 3.0f, ((a0.y + a1.y) + a2.y) / 3.0f}; }
+                b.phi = m.emit(m.has_uv, uvc).channel_max() * magnitude(n) * 0.5f;
                 b.aabb = AABB().union_vec(v0).union_vec(v1).union_vec(v2);
                 b.cos_theta_o = detmath::cosf_det(b.theta_o); b.cos_theta_e = detmath::cosf_det(b.theta_e);
                 b.two_sided = false; b.number_lights = 1; b.phi_sqr = powi(b.phi, 2);
@@ -1395,8 +1421,8 @@ struct Scene {
             float geom = dist != 0.0f ? rmax(dot(sp.n, -d), 0.0f) / (dist * dist) : 0.0f;
             float pdf_area = sp.pdf.value();
             PDF pdf = sp.pdf.as_solid_angle_geom(geom);
-            Color weight = pdf.is_zero() ? Color::zero() : m.emit() * geom / pdf_area;
-            LightSampling res = {(int)lp.emitter_id, pdf, sp.p, sp.n, d, weight};
+            Color weight = pdf.is_zero() ? Color::zero() : m.emit(sp.has_uv, sp.uv) * geom / pdf_area;
+            LightSampling res = {(int)lp.emitter_id, pdf, sp.p, sp.n, d, weight, sp.has_uv, sp.uv};
             div_assign(res.weight, pdf_sel);
             res.pdf = res.pdf.mul(pdf_sel);
             return res;
@@ -1627,10 +1653,10 @@ struct PathTracer {
     Color vertex_contribution(int v, const Edge& e) const {  // vertex.rs:69-82
         const Vertex& vx = path.vertices[v];
         if (vx.kind == Vertex::Surface) {
-            if (dot(vx.its.n_s, -e.d) >= 0.0f) return scene.meshes[vx.its.mesh].emit();
+            if (dot(vx.its.n_s, -e.d) >= 0.0f) return scene.meshes[vx.its.mesh].emit(vx.its.has_uv, vx.its.uv);
             return Color::zero();
         }
-        if (vx.kind == Vertex::Light) { const EmitterRec& em = scene.emitters[vx.emitter]; return em.kind == EM_MESH ? scene.meshes[em.mesh].emit() : em.c; }  // emitter.eval(-d, uv)
+        if (vx.kind == Vertex::Light) { const EmitterRec& em = scene.emitters[vx.emitter]; return em.kind == EM_MESH ? scene.meshes[em.mesh].emit(vx.its.has_uv, vx.its.uv) : em.c; }  // emitter.eval(-d, uv): the sampled point's uv, kept in its.uv of the light vertex
         return Color::zero();
     }
     bool next_on_light_source(const Edge& e) const { return e.v1 >= 0 ? on_light_source(e.v1) : scene.has_env; }  // edge.rs:191-197
@@ -1780,7 +1806,7 @@ struct PathTracer {
             float tfar = dot(dd, lr.d);
             mul_assign(weight, scene.volume.transmittance(tfar));
         }
-        Vertex lv; lv.kind = Vertex::Light; lv.pos = lr.p; lv.n = lr.n; lv.emitter = lr.emitter;
+        Vertex lv; lv.kind = Vertex::Light; lv.pos = lr.p; lv.n = lr.n; lv.emitter = lr.emitter; lv.its.has_uv = lr.has_uv; lv.its.uv = lr.uv;
         int lvid = (int)path.vertices.size();
         path.vertices.push_back(lv);
         // Edge::from_vertex (edge.rs:27-63)
@@ -1986,7 +2012,7 @@ static Color direct_compute_pixel(const Scene& scene, const DirectParams& dp, ui
     if (!scene.trace(ray, &its)) return scene.environment_luminance(ray.d);
     if (its.wi.z <= 0.0f) return l_i;
     const Mesh& mesh = scene.meshes[its.mesh];
-    add_assign(l_i, mesh.emit());
+    add_assign(l_i, mesh.emit(its.has_uv, its.uv));
     float w_nb_bsdf = dp.nb_bsdf_samples == 0 ? 0.0f : 1.0f / (float)dp.nb_bsdf_samples;
     float w_nb_light = dp.nb_light_samples == 0 ? 0.0f : 1.0f / (float)dp.nb_light_samples;
     cnt.vertices++;
@@ -2022,7 +2048,7 @@ static Color direct_compute_pixel(const Scene& scene, const DirectParams& dp, ui
                     float light_pdf = scene.direct_pdf(nx.mesh, {r2.o, nx.p, nx.n_g, r2.d}, &its.n_s, nx.primitive_id).value();   // direct.rs:156-164
                     weight_bsdf = mis_weight(sd.pdf.v * w_nb_bsdf, light_pdf * w_nb_light);
                 } else weight_bsdf = 1.0f;
-                add_assign(l_i, weight_bsdf * sd.weight * nm.emit() * w_nb_bsdf);
+                add_assign(l_i, weight_bsdf * sd.weight * nm.emit(nx.has_uv, nx.uv) * w_nb_bsdf);
             }
         } else if (scene.has_env) {
             float weight_bsdf;
@@ -2097,6 +2123,18 @@ int orc_scene_add_mesh(orc_scene* sc, const float* vertices, size_t nv, const ui
     if (!m.finish()) return -1;
     sc->s.meshes.push_back(std::move(m));
     return (int)sc->s.meshes.size() - 1;
+}
+
+// examples/cli.rs:410-429 (`-x hvs-light`, `-x texture-light`): the emission of a light mesh becomes EmissionType::HSV { scale } or Texture { scale, img }
+int orc_scene_set_mesh_emission(orc_scene* sc, int mesh, int type, float scale, int bitmap_id) {
+    if (mesh < 0 || (size_t)mesh >= sc->s.meshes.size() || type < 0 || type > 2) return -1;
+    Mesh& m = sc->s.meshes[mesh];
+    if (!m.is_light) return -1;
+    if (type != 0 && !m.has_uv) return -1;                        // `uv.unwrap()` would panic
+    if (type == 2 && (bitmap_id < 0 || (size_t)bitmap_id >= sc->s.bitmaps.size())) return -1;
+    m.emission_type = type; m.emission_scale = scale;
+    m.emission_img = type == 2 ? sc->s.bitmaps[bitmap_id].get() : nullptr;
+    return 0;
 }
 
 int orc_scene_set_medium(orc_scene* sc, const float* sigma_a, const float* sigma_s, int phase, float g) {

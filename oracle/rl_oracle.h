@@ -42,6 +42,7 @@ int orc_scene_set_camera(orc_scene* sc, uint32_t w, uint32_t h, float fov, int f
 int orc_scene_add_bitmap(orc_scene* sc, uint32_t w, uint32_t h, const float* rgb);
 int orc_scene_add_mesh(orc_scene* sc, const float* vertices, size_t nv, const uint32_t* indices, size_t ntri,
                        const float* normals, const float* uv, const rl_bsdf_desc* bsdf, const float* emission);
+int orc_scene_set_mesh_emission(orc_scene* sc, int mesh, int type, float scale, int bitmap_id);   /* 1 = EmissionType::HSV { scale }, 2 = Texture { scale, img } (geometry.rs:99-104, cli.rs:410-429) */
 int orc_scene_set_medium(orc_scene* sc, const float* sigma_a, const float* sigma_s, int phase, float g);
 int orc_scene_add_point_light(orc_scene* sc, const float* position, const float* intensity);
 int orc_scene_add_directional_light(orc_scene* sc, const float* direction, const float* intensity);

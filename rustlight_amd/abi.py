@@ -24,7 +24,7 @@ class BsdfDesc(C.Structure):
 class MeshDesc(C.Structure):
     _fields_ = [("vertices", C.POINTER(C.c_float)), ("n_vertices", C.c_size_t), ("indices", C.POINTER(C.c_uint32)), ("n_triangles", C.c_size_t),
                 ("normals", C.POINTER(C.c_float)), ("uv", C.POINTER(C.c_float)), ("bsdf", BsdfDesc), ("has_emission", C.c_int32),
-                ("emission_rgb", C.c_float * 3)]
+                ("emission_rgb", C.c_float * 3), ("emission_type", C.c_int32), ("emission_scale", C.c_float), ("emission_bitmap_id", C.c_int32)]
 
 
 class BitmapDesc(C.Structure):

@@ -28,7 +28,7 @@ NUMERICS_EXACT, NUMERICS_FAST = 0, 1
 
 # every symbol include/rustlight_amd.h declares (tests check the .so exports all of them)
 PUBLIC_SYMBOLS = [
-    "rl_scene_create", "rl_scene_create_from_desc", "rl_scene_destroy", "rl_scene_set_camera", "rl_scene_set_camera_matrices", "rl_scene_get_camera_matrices", "rl_scene_scale_image", "rl_scene_add_mesh",
+    "rl_scene_create", "rl_scene_create_from_desc", "rl_scene_destroy", "rl_scene_set_camera", "rl_scene_set_camera_matrices", "rl_scene_get_camera_matrices", "rl_scene_set_mesh_emission", "rl_scene_override_light_emission", "rl_scene_scale_image", "rl_scene_add_mesh",
     "rl_scene_add_bitmap", "rl_scene_set_medium", "rl_scene_add_point_light", "rl_scene_add_directional_light",
     "rl_scene_set_environment", "rl_scene_set_environment_map", "rl_scene_build_emitters", "rl_scene_enable_ats", "rl_scene_load_pbrt", "rl_scene_load_mitsuba", "rl_scene_load",
     "rl_scene_image_size", "rl_scene_counts", "rl_sampler_seed", "rl_sampler_next_u64", "rl_sampler_next_f32",
@@ -66,6 +66,8 @@ def lib():
     L.rl_scene_set_camera.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_float, C.c_int, f32p, C.c_int]
     L.rl_scene_set_camera_matrices.argtypes = [vp, C.c_uint32, C.c_uint32, f32p, f32p]
     L.rl_scene_get_camera_matrices.argtypes = [vp, f32p, f32p, f32p]
+    L.rl_scene_set_mesh_emission.argtypes = [vp, C.c_uint32, C.c_int, C.c_float, C.c_int]
+    L.rl_scene_override_light_emission.argtypes = [vp, C.c_int, C.c_int]
     L.rl_scene_scale_image.argtypes = [vp, C.c_float]
     L.rl_scene_add_mesh.argtypes = [vp, f32p, C.c_size_t, u32p, C.c_size_t, f32p, f32p, C.POINTER(abi.BsdfDesc), f32p]
     L.rl_scene_add_bitmap.argtypes = [vp, C.c_uint32, C.c_uint32, f32p]
@@ -171,11 +173,14 @@ class Scene:
             for (w, hgt, rgb) in sd.bitmaps:
                 a = np.ascontiguousarray(rgb, dtype=np.float32)
                 _check(L.rl_scene_add_bitmap(self.h, w, hgt, abi.fptr(a)))
-            for m in sd.meshes:
+            for k, m in enumerate(sd.meshes):
                 v, i, n, uv, e = abi.mesh_arrays(m)
                 bd = abi.bsdf_desc(m.bsdf)
                 _check(L.rl_scene_add_mesh(self.h, abi.fptr(v), v.shape[0], abi.u32ptr(i), i.shape[0], abi.fptr(n),
                                            abi.fptr(uv), C.byref(bd), abi.fptr(e)))
+                if getattr(m, "emission_kind", None):          # EmissionType::HSV / Texture
+                    ek = m.emission_kind
+                    _check(L.rl_scene_set_mesh_emission(self.h, k, 1 if ek[0] == "hsv" else 2, float(ek[1]), int(ek[2]) if len(ek) > 2 else -1))
             if sd.medium is not None:
                 sa = np.asarray(sd.medium.sigma_a, dtype=np.float32)
                 ss = np.asarray(sd.medium.sigma_s, dtype=np.float32)
@@ -229,6 +234,9 @@ class Scene:
             if e is not None:
                 meshes[k].has_emission = 1
                 meshes[k].emission_rgb = (C.c_float * 3)(*e)
+            if getattr(m, "emission_kind", None):
+                ek = m.emission_kind
+                meshes[k].emission_type, meshes[k].emission_scale, meshes[k].emission_bitmap_id = (1 if ek[0] == "hsv" else 2), float(ek[1]), (int(ek[2]) if len(ek) > 2 else -1)
         d.meshes, d.n_meshes = meshes, len(sd.meshes)
         bitmaps = (abi.BitmapDesc * max(1, len(sd.bitmaps)))()
         for k, (w, h, rgb) in enumerate(sd.bitmaps):

@@ -89,6 +89,11 @@ struct MeshRecord {
     uint32_t n_tris;
     uint32_t cdf_base;       // first entry of this mesh's area cdf (n_tris + 1 entries)
     uint32_t ats_base;       // light tree: first entry of this mesh's triangles in ats_leaf_of (emissive meshes, when the tree is built)
+    // EmissionType (src/geometry.rs:99-104): 0 = Color { v = emission }, 1 = HSV { scale }, 2 = Texture { scale, img } — the two uv-dependent kinds of
+    // `-x hvs-light` / `-x texture-light` (examples/cli.rs:410-429); Mesh::emit (geometry.rs:184-206)
+    int32_t emission_type;
+    float emission_scale;
+    int32_t emission_bitmap;
 };
 enum { MESH_HAS_NORMALS = 1, MESH_HAS_UV = 2, MESH_IS_LIGHT = 4 };
 

@@ -259,12 +259,16 @@ void build_bvh4(const BvhBuild& bvh, Bvh4Build* out) {
         double step[3];
         for (int a = 0; a < 3; a++) {
             if (!(lo[a] <= hi[a]) || !std::isfinite(lo[a]) || !std::isfinite(hi[a])) { lo[a] = -3.0e38f; hi[a] = 3.0e38f; }   // non-finite geometry: a box that is always entered
-            nd.org[a] = lo[a];
             int e = 0;
-            const double ext = ((double)hi[a] - (double)lo[a]) * (1.0 + 1e-6) / 254.0;     // one step of slack for the conservative rounding below
+            // the child planes are widened by a whole grid step on each side (below), and the grid starts two steps below the box: the device evaluates a
+            // plane as (org - ray origin) / d + q * step / d in f32, whose rounding grows with the distance of the ray origin — a fraction of a step of
+            // slack is not conservative for a small node seen from far away, a whole step is for origins up to ~2^20 steps off
+            const double ext = ((double)hi[a] - (double)lo[a]) * (1.0 + 1e-6) / 250.0;
             if (ext > 0.0) { (void)std::frexp(ext, &e); } else e = -125;                    // ext <= 2^e
             e = std::max(-125, std::min(127, e));
             step[a] = std::ldexp(1.0, e);
+            const double o2 = (double)lo[a] - 2.0 * step[a];
+            nd.org[a] = std::isfinite(o2) && (double)(float)o2 <= (double)lo[a] - step[a] ? (float)o2 : lo[a];
             exps |= (uint32_t)(e + 127) << (8 * a);
         }
         nd.exps = exps;
@@ -273,8 +277,8 @@ void build_bvh4(const BvhBuild& bvh, Bvh4Build* out) {
             nd.child[k] = RL_CHILD_NONE;
             if (k < n) {
                 for (int a = 0; a < 3; a++) {
-                    double l = std::floor(((double)ch[k].lo[a] - (double)nd.org[a]) / step[a] - 1e-3);
-                    double h = std::ceil(((double)ch[k].hi[a] - (double)nd.org[a]) / step[a] + 1e-3);
+                    double l = std::floor(((double)ch[k].lo[a] - (double)nd.org[a]) / step[a] - 1e-3) - 1.0;
+                    double h = std::ceil(((double)ch[k].hi[a] - (double)nd.org[a]) / step[a] + 1e-3) + 1.0;
                     if (!(l == l)) l = 0.0;
                     if (!(h == h)) h = 255.0;
                     ql[a] = (uint32_t)std::max(0.0, std::min(255.0, l));

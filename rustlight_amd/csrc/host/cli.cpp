@@ -34,6 +34,7 @@ int main(int argc, char** argv) {
     float scale_image = 1.0f;
     int device = 0, gpus = 1;
     bool single_scattering = false, have_cmd = false, use_ats = false, shading_normals = true;
+    int light_override = RL_EMISSION_COLOR;      // -x hvs-light | texture-light
     std::string cmd, ao_distance = "1.0", average, equal_time;
     bool ao_normal_correction = false;
     size_t nb_bsdf = 1, nb_light = 1;
@@ -60,7 +61,9 @@ int main(int argc, char** argv) {
                 const std::string o = val();
                 if (o == "ats") use_ats = true;
                 else if (o == "no-shading") shading_normals = false;
-                else { std::fprintf(stderr, "extra option %s is not supported by this drop-in (ats, no-shading)\n", o.c_str()); return 2; }
+                else if (o == "hvs-light") light_override = RL_EMISSION_HSV;               // ExtraOptions::HVSLight (cli.rs:327, 410-429)
+                else if (o == "texture-light") light_override = RL_EMISSION_TEXTURE;       // ExtraOptions::TextureLight
+                else { std::fprintf(stderr, "extra option %s is not supported by this drop-in (ats, no-shading, hvs-light, texture-light)\n", o.c_str()); return 2; }
             }
             else if (a == "-l" || a == "--log") (void)val();   // log file: nothing is logged on this path
             else if (a[0] == '-') { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
@@ -105,6 +108,17 @@ int main(int argc, char** argv) {
             }
         }
         if (scale_image != 1.0f && rl_scene_scale_image(scene->handle, scale_image) != RL_OK) { std::fprintf(stderr, "invalid image scale: %s\n", rl_last_error()); return 2; }
+        if (light_override != RL_EMISSION_COLOR) {   // "Overide light is needed" (cli.rs:410-429): every light mesh becomes HSV { scale } / Texture { scale, butterfly.jpg }
+            int bitmap = -1;
+            if (light_override == RL_EMISSION_TEXTURE) {
+                uint32_t bw = 0, bh = 0;
+                if (rl_load_image("butterfly.jpg", &bw, &bh, nullptr, 0) != RL_OK) { std::fprintf(stderr, "texture-light: cannot read butterfly.jpg from the working directory (Bitmap::read(\"butterfly.jpg\"), cli.rs:423): %s\n", rl_last_error()); return 1; }
+                std::vector<float> px((size_t)3 * bw * bh);
+                if (rl_load_image("butterfly.jpg", &bw, &bh, px.data(), px.size()) != RL_OK) { std::fprintf(stderr, "texture-light: %s\n", rl_last_error()); return 1; }
+                bitmap = rl_scene_add_bitmap(scene->handle, bw, bh, px.data());
+            }
+            if (rl_scene_override_light_emission(scene->handle, light_override, bitmap) != RL_OK) { std::fprintf(stderr, "-x %s: %s\n", light_override == RL_EMISSION_HSV ? "hvs-light" : "texture-light", rl_last_error()); return 1; }
+        }
         scene->build_emitters(use_ats);      // scene.build_emitters(use_ats) (cli.rs:432)
         IntegratorPathTracing integrator;
         integrator.min_depth = match_infinity(min_depth);

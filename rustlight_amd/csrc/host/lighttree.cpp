@@ -176,9 +176,28 @@ int build_light_tree(rl_scene* scene, std::string* err) {
         if (scene->emitters[e].kind != EMITTER_MESH) { *err = "the ATS light tree needs surface emitters only (emitter.rs:1266-1268)"; return RL_ERR_UNSUPPORTED; }
         const HostMesh& m = scene->meshes[scene->emitters[e].mesh];
         scene->ats_emitter_base.push_back((uint32_t)lights.size());
-        const float le = std::fmax(m.emission[0], std::fmax(m.emission[1], m.emission[2]));   // emit().channel_max()
         for (size_t t = 0; t < m.n_tris(); t++) {   // Mesh::convert_light_proxy (emitter.rs:726-781)
             const Vec3 v0 = m.positions[m.indices[3 * t]], v1 = m.positions[m.indices[3 * t + 1]], v2 = m.positions[m.indices[3 * t + 2]];
+            // emit(&uv).channel_max() with uv "interpolated at the middle" of the triangle (emitter.rs:741-756); Mesh::emit: geometry.rs:184-206
+            float le = std::fmax(m.emission[0], std::fmax(m.emission[1], m.emission[2]));
+            if (m.emission_type != RL_EMISSION_COLOR && !m.uvs.empty()) {
+                const uint32_t i0 = m.indices[3 * t], i1 = m.indices[3 * t + 1], i2 = m.indices[3 * t + 2];
+                const float ux = ((m.uvs[2 * i0] + m.uvs[2 * i1]) + m.uvs[2 * i2]) / 3.0f, uy = ((m.uvs[2 * i0 + 1] + m.uvs[2 * i1 + 1]) + m.uvs[2 * i2 + 1]) / 3.0f;
+                float c[3] = {0.0f, 0.0f, 0.0f};
+                if (m.emission_type == RL_EMISSION_HSV) {
+                    const float x = std::fmod(std::fabs(ux), 1.0f);
+                    c[0] = x * 1.0f + (1.0f - x) * 0.0f; c[1] = x * 0.0f + (1.0f - x) * 1.0f; c[2] = x * 0.0f + (1.0f - x) * 0.0f;
+                } else if (m.emission_bitmap >= 0 && (size_t)m.emission_bitmap < scene->bitmaps.size()) {
+                    const HostBitmap& bm = scene->bitmaps[m.emission_bitmap];          // Bitmap::pixel_uv (structure.rs:434-453)
+                    auto mod1 = [](float a) { return std::fmod(std::fmod(a, 1.0f) + 1.0f, 1.0f); };
+                    auto as_usize = [](float f) -> unsigned long long { if (!(f > 0.0f)) return 0ull; if (f >= 1.8446744e19f) return ~0ull; return (unsigned long long)f; };
+                    const unsigned long long x = as_usize(mod1(ux) * (float)bm.w), y = as_usize(mod1(uy) * (float)bm.h), i = (unsigned long long)bm.w * y + x;
+                    if (i < (unsigned long long)bm.w * bm.h) { c[0] = bm.rgb[3 * i]; c[1] = bm.rgb[3 * i + 1]; c[2] = bm.rgb[3 * i + 2]; }
+                }
+                const float sc_ = m.emission_scale;
+                if (std::isfinite(sc_)) { c[0] *= sc_; c[1] *= sc_; c[2] *= sc_; } else { c[0] = c[1] = c[2] = 0.0f; }     // Color * f32 (guarded)
+                le = std::fmax(c[0], std::fmax(c[1], c[2]));
+            }
             const Vec3 n = vcross(vsub(v1, v0), vsub(v2, v0));
             Proxy p;
             p.emitter = (int32_t)e; p.prim = (int32_t)t;

@@ -71,6 +71,17 @@ struct rl_multi {
         if (r_ != ncclSuccess) { rl_set_error(std::string(#expr) + ": " + ncclGetErrorString(r_)); return RL_ERR_HIP; } \
     } while (0)
 
+// strings that go into rl_multi_describe's JSON (device names, RCCL / HIP error texts, environment text) are escaped
+static std::string json_escape(const std::string& in) {
+    std::string o;
+    for (unsigned char ch : in) {
+        if (ch == '"' || ch == '\\') { o += '\\'; o += (char)ch; }
+        else if (ch < 0x20) { char b[8]; std::snprintf(b, sizeof(b), "\\u%04x", ch); o += b; }
+        else o += (char)ch;
+    }
+    return o;
+}
+
 extern "C" void rl_multi_destroy(rl_multi* m) {
     if (!m) return;
     DeviceGuard guard;
@@ -147,14 +158,14 @@ extern "C" int rl_multi_describe(const rl_multi* m, char* buf, size_t capacity) 
     if (!m || !buf || capacity == 0) return RL_ERR_INVALID_ARGUMENT;
     DeviceGuard guard;
     std::string s = "{\"shards\": " + std::to_string(m->ctxs.size()) + ", \"rccl_version\": " + std::to_string(m->rccl_version) + ", \"comm_ranks\": " + std::to_string(m->comms.size()) +
-                    ", \"merge\": \"" + (m->host_merge ? "host sum (" + m->merge_note + ")" : std::string("ncclReduce(sum) onto device ") + std::to_string(m->comm_devices.empty() ? -1 : m->comm_devices[0])) + "\", \"devices\": [";
+                    ", \"merge\": \"" + (m->host_merge ? "host sum (" + json_escape(m->merge_note) + ")" : std::string("ncclReduce(sum) onto device ") + std::to_string(m->comm_devices.empty() ? -1 : m->comm_devices[0])) + "\", \"devices\": [";
     for (size_t r = 0; r < m->comm_devices.size(); r++) {
         hipDeviceProp_t prop{};
         const int d = m->comm_devices[r];
         (void)hipGetDeviceProperties(&prop, d);
         int shards_here = 0;
         for (int dv : m->device_of) shards_here += dv == d;
-        s += std::string(r ? ", " : "") + "{\"device\": " + std::to_string(d) + ", \"name\": \"" + prop.name + "\", \"arch\": \"" + prop.gcnArchName + "\", \"cus\": " + std::to_string(prop.multiProcessorCount) + ", \"shards\": " + std::to_string(shards_here) + ", \"peer_access\": [";
+        s += std::string(r ? ", " : "") + "{\"device\": " + std::to_string(d) + ", \"name\": \"" + json_escape(prop.name) + "\", \"arch\": \"" + json_escape(prop.gcnArchName) + "\", \"cus\": " + std::to_string(prop.multiProcessorCount) + ", \"shards\": " + std::to_string(shards_here) + ", \"peer_access\": [";
         for (size_t q = 0; q < m->comm_devices.size(); q++) {      // hipDeviceCanAccessPeer: what the xGMI ring of the reduce rides on
             int can = d == m->comm_devices[q] ? 1 : 0;
             if (d != m->comm_devices[q] && hipDeviceCanAccessPeer(&can, d, m->comm_devices[q]) != hipSuccess) { can = -1; (void)hipGetLastError(); }

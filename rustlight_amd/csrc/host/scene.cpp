@@ -77,6 +77,7 @@ void flatten_scene(const rl_scene& scene, FlatScene* out) {
         out->materials.push_back(convert_material(m.bsdf));
         r.flags = (m.normals.empty() ? 0 : MESH_HAS_NORMALS) | (m.uvs.empty() ? 0 : MESH_HAS_UV) | (m.is_light ? MESH_IS_LIGHT : 0);
         for (int i = 0; i < 3; i++) r.emission[i] = m.emission[i];
+        r.emission_type = m.emission_type; r.emission_scale = m.emission_scale; r.emission_bitmap = m.emission_bitmap;
         r.inv_area = 1.0f / m.area_total();
         r.emitter_pdf = 0.0f;
         r.vertex_base = vbase;
@@ -166,6 +167,30 @@ int rl_scene_get_camera_matrices(const rl_scene* scene, float sample_to_camera[1
     scene->sample_to_camera.to_cols(sample_to_camera);
     scene->to_world.to_cols(to_world);
     position[0] = scene->cam_pos.x; position[1] = scene->cam_pos.y; position[2] = scene->cam_pos.z;
+    return RL_OK;
+}
+
+// EmissionType::HSV / Texture on one light mesh (geometry.rs:99-104) — what examples/cli.rs:410-429 assigns under `-x hvs-light` / `-x texture-light`
+int rl_scene_set_mesh_emission(rl_scene* scene, uint32_t mesh, int type, float scale, int bitmap_id) {
+    if (!scene || mesh >= scene->meshes.size() || type < RL_EMISSION_COLOR || type > RL_EMISSION_TEXTURE) return RL_ERR_INVALID_ARGUMENT;
+    HostMesh& m = scene->meshes[mesh];
+    if (!m.is_light) { rl_set_error("mesh " + std::to_string(mesh) + " is not a light (EmissionType::Zero)"); return RL_ERR_INVALID_ARGUMENT; }
+    if (type != RL_EMISSION_COLOR && m.uvs.empty()) { rl_set_error("HSV / texture emission needs uv coordinates on the light mesh (Mesh::emit unwraps them: geometry.rs:200-203)"); return RL_ERR_INVALID_ARGUMENT; }
+    if (type == RL_EMISSION_TEXTURE && (bitmap_id < 0 || (size_t)bitmap_id >= scene->bitmaps.size())) { rl_set_error("texture emission without a valid bitmap id"); return RL_ERR_INVALID_ARGUMENT; }
+    m.emission_type = type; m.emission_scale = scale; m.emission_bitmap = type == RL_EMISSION_TEXTURE ? bitmap_id : -1;
+    scene->emitters_built = false;
+    return RL_OK;
+}
+// examples/cli.rs:410-429: every light mesh becomes HSV { scale } / Texture { scale, img } with scale = the luminance of its colour (1 if it had none)
+int rl_scene_override_light_emission(rl_scene* scene, int type, int bitmap_id) {
+    if (!scene || (type != RL_EMISSION_HSV && type != RL_EMISSION_TEXTURE)) return RL_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < scene->meshes.size(); i++) {
+        HostMesh& m = scene->meshes[i];
+        if (!m.is_light) continue;
+        const float scale = m.emission_type == RL_EMISSION_COLOR ? (m.emission[0] * 0.212671f + m.emission[1] * 0.715160f) + m.emission[2] * 0.072169f : 1.0f;   // Color::luminance (structure.rs:173-176)
+        const int rc = rl_scene_set_mesh_emission(scene, (uint32_t)i, type, scale, bitmap_id);
+        if (rc != RL_OK) return rc;
+    }
     return RL_OK;
 }
 
@@ -297,7 +322,8 @@ int rl_scene_build_emitters(rl_scene* scene) {
             return RL_ERR_INVALID_ARGUMENT;
         }
         float ch[3];
-        for (int k = 0; k < 3; k++) ch[k] = (m.emission[k] * total) * kPi;
+        // Emitter::flux (emitter.rs:591-599): the constant colour, or Color::value(scale) for the uv-dependent kinds ("TODO" there)
+        for (int k = 0; k < 3; k++) ch[k] = ((m.emission_type == 0 ? m.emission[k] : m.emission_scale) * total) * kPi;
         flux.push_back(channel_max(ch));
     }
     const float big_radius = scene->bsphere_radius * 1.1f;      // Emitter::preprocess: bsphere.radius *= 1.1
@@ -472,6 +498,7 @@ int rl_scene_create_from_desc(const rl_scene_desc* d, rl_scene** out) {
     for (size_t i = 0; i < d->n_meshes; i++) {
         const rl_mesh_desc& m = d->meshes[i];
         if ((rc = rl_scene_add_mesh(s, m.vertices, m.n_vertices, m.indices, m.n_triangles, m.normals, m.uv, &m.bsdf, m.has_emission ? m.emission_rgb : nullptr)) < 0) return fail(rc);
+        if (m.emission_type != RL_EMISSION_COLOR && (rc = rl_scene_set_mesh_emission(s, (uint32_t)i, m.emission_type, m.emission_scale, m.emission_bitmap_id)) != RL_OK) return fail(rc);
     }
     if (d->has_medium && (rc = rl_scene_set_medium(s, d->sigma_a, d->sigma_s, d->phase_type, d->g)) != RL_OK) return fail(rc);
     for (size_t i = 0; i < d->n_lights; i++) {

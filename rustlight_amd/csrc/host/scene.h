@@ -20,6 +20,9 @@ struct HostMesh {
     rl_bsdf_desc bsdf;
     bool is_light = false;
     float emission[3] = {0, 0, 0};
+    int emission_type = 0;           // EmissionType: 0 Color { v = emission }, 1 HSV { scale }, 2 Texture { scale, img } (geometry.rs:99-104)
+    float emission_scale = 1.0f;
+    int emission_bitmap = -1;
     // Distribution1D over triangle areas (src/math.rs:398-445)
     std::vector<float> cdf;
     float func_int = 0.0f;

@@ -24,7 +24,7 @@
 namespace rl {
 
 #ifdef RL_STAGE_TIMERS
-__device__ unsigned long long g_chain_timers[8];      // dev-only: cycles in raygen / extend / shade, wave-iterations, lane-iterations of each
+static __device__ unsigned long long g_chain_timers[8];      // dev-only (one copy per translation unit: read by that unit's own dump function): cycles in raygen / extend / shade, wave-iterations, lane-iterations of each
 #define RL_CT0 { ct0 = __builtin_readcyclecounter(); }
 #define RL_CT1(K, COND) { const unsigned long long t1 = __builtin_readcyclecounter(); ctm[K] += t1 - ct0; cln[K] += __popcll(__ballot(COND)); ct0 = t1; }
 #else

@@ -58,7 +58,7 @@ RL_DEV Col mc_compute_pixel(const DeviceScene& sc, const SceneRecs& recs, const 
     if (sp.wi.z <= 0.0f) return l_i;
     const MeshRecord mr = sc.meshes[sp.mesh];
     const Material& mat = sc.materials[mr.material];
-    l_i = l_i + ((mr.flags & MESH_IS_LIGHT) ? mkc(mr.emission[0], mr.emission[1], mr.emission[2]) : czero());
+    l_i = l_i + ((mr.flags & MESH_IS_LIGHT) ? mesh_emit(sc, mr, sp.has_uv, sp.uv) : czero());
     const float w_nb_bsdf = mp.nb_bsdf_samples == 0u ? 0.0f : div_rn(1.0f, (float)mp.nb_bsdf_samples);
     const float w_nb_light = mp.nb_light_samples == 0u ? 0.0f : div_rn(1.0f, (float)mp.nb_light_samples);
     n_vertices++;
@@ -94,7 +94,7 @@ RL_DEV Col mc_compute_pixel(const DeviceScene& sc, const SceneRecs& recs, const 
                     float light_pdf = light_direct_pdf(sc, nm, sc.tris[h2.prim].tri, sp.p, nx.p, nx.n_g, d_out_world, true, sp.n_s);   // direct.rs:156-164
                     weight_bsdf = mis_weight_power(bs.pdf * w_nb_bsdf, light_pdf * w_nb_light);
                 }
-                l_i = l_i + weight_bsdf * bs.weight * mkc(nm.emission[0], nm.emission[1], nm.emission[2]) * w_nb_bsdf;
+                l_i = l_i + weight_bsdf * bs.weight * mesh_emit(sc, nm, nx.has_uv, nx.uv) * w_nb_bsdf;
             }
         } else if (sc.env_emitter >= 0) {
             float weight_bsdf = bs.pdf_kind == PDF_SOLID_ANGLE ? mis_weight_power(bs.pdf * w_nb_bsdf, env_direct_pdf(sc, d_out_world) * w_nb_light) : 1.0f;

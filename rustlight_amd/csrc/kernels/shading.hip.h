@@ -61,6 +61,28 @@ RL_DEV Col tex_color(const DeviceScene& sc, const ColorTex& t, bool has_uv, V2 u
     return (fabsf(x) < t.line_width || fabsf(y) < t.line_width) ? mkc(t.c0[0], t.c0[1], t.c0[2]) : mkc(t.c1[0], t.c1[1], t.c1[2]);
 }
 
+// Mesh::emit(uv) (src/geometry.rs:184-206) of a mesh known to be a light: the constant colour, or one of the two uv-dependent kinds the CLI's
+// `-x hvs-light` / `-x texture-light` switch every light to (a light mesh of those kinds always has uv: the host refuses it otherwise, where the
+// reference's `uv.unwrap()` would panic)
+RL_DEV Col mesh_emit(const DeviceScene& sc, const MeshRecord& mr, bool has_uv, V2 uv) {
+    if (mr.emission_type == 1) {
+        const float x = fmodf(fabsf(uv.x), 1.0f);                              // uv.x.abs() % 1.0
+        const Col c = x * mkc(1.0f, 0.0f, 0.0f) + (1.0f - x) * mkc(0.0f, 1.0f, 0.0f);
+        return c * mr.emission_scale;                                          // Color * f32 (guarded)
+    }
+    if (mr.emission_type == 2) {
+        if (!has_uv || mr.emission_bitmap < 0) return czero();
+        BitmapDesc bd = sc.bitmaps[mr.emission_bitmap];                        // Bitmap::pixel_uv (src/structure.rs:434-453)
+        float ux = modulo1(uv.x), uy = modulo1(uv.y);
+        unsigned long long x = f32_as_usize(ux * (float)bd.w), y = f32_as_usize(uy * (float)bd.h);
+        unsigned long long i = (unsigned long long)bd.w * y + x;
+        Col c = czero();
+        if (i < (unsigned long long)bd.w * bd.h) { const float* px = sc.bitmap_texels + 3ull * (bd.offset + i); c = mkc(px[0], px[1], px[2]); }
+        return c * mr.emission_scale;
+    }
+    return mkc(mr.emission[0], mr.emission[1], mr.emission[2]);
+}
+
 // Intersection::fill_intersection
 RL_DEV SurfacePoint fill_intersection(const DeviceScene& sc, int prim, float hu, float hv, V3 ray_o, V3 ray_d, float t) {
     const float4* q = reinterpret_cast<const float4*>(sc.tris) + 4 * prim;
@@ -503,7 +525,19 @@ RL_DEV void mesh_sample_triangle(const DeviceScene& sc, const MeshRecord& mr, un
     if (dist != 0.0f) d = d / dist;
     float geom = dist != 0.0f ? div_rn(rmax(dot(n_g, -d), 0.0f), dist * dist) : 0.0f;
     float pdf = geom == 0.0f ? 0.0f : div_rn(pdf_area, geom);   // PDF::as_solid_angle_geom
-    Col emit = mkc(mr.emission[0], mr.emission[1], mr.emission[2]);
+    Col emit;
+    if (mr.emission_type == 0) emit = mkc(mr.emission[0], mr.emission[1], mr.emission[2]);
+    else {
+        // the sampled point's uv: interpolated, then `.normalize()`d as a 2-vector (sic, geometry.rs:316-325)
+        V2 suv; suv.x = 0.0f; suv.y = 0.0f;
+        const bool huv = (mr.flags & MESH_HAS_UV) != 0;
+        if (huv) {
+            const float tx = sc.uvs[2 * i0] * b.x + sc.uvs[2 * i1] * b.y + sc.uvs[2 * i2] * w2, ty = sc.uvs[2 * i0 + 1] * b.x + sc.uvs[2 * i1 + 1] * b.y + sc.uvs[2 * i2 + 1] * w2;
+            const float inv = div_rn(1.0f, sqrt_rn(tx * tx + ty * ty));
+            suv.x = tx * inv; suv.y = ty * inv;
+        }
+        emit = mesh_emit(sc, mr, huv, suv);
+    }
     ls->weight = pdf == 0.0f ? czero() : emit * geom / pdf_area;
     ls->pdf = pdf; ls->pdf_kind = PDF_SOLID_ANGLE;
     ls->p = pos; ls->n = n_g; ls->d = d;

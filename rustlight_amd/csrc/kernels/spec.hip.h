@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
                 triv = valid && ((triv_bits[(c >> 5) & 7u] >> (c & 31u)) & 1u) != 0u;
                 resolved = false; copied = false; linked = false; cp_k0 = 0u; M = 0u; link_i = 0xffffffffu;
                 cnt = 0u; sum_n = 0u; sum_n2 = 0.0f;
-                if (sk == 0u && valid && !triv && !have_est && spc.probe > 0u) {
+                if (sk == 0u && valid && !triv && (!have_est || spc.probe_every) && spc.probe > 0u) {
                     // nothing to predict this pixel's length from: a short walk somewhere in the stream nobody else probes
                     Rng r = load_anc(); rng_advance(r, (pl << 10) + 512u);
                     store_rng(ps, Q_R0, r);
@@ -305,11 +305,15 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
         const bool group_idle2 = (__ballot(mode != SM_IDLE) & gmask) == 0ull;
         if (group_idle2 && phase == SP_PROBE && planned) {
             // ---- the windows of the batch
-            if (sk == 0u && valid && !triv && !have_est) {
+            if (sk == 0u && valid && !triv && (!have_est || cnt > 0u)) {
                 const float m = cnt ? (float)sum_n / (float)cnt : 16.0f;
                 const float var = cnt ? fmaxf(sum_n2 / (float)cnt - m * m, 0.0f) : m * m;
-                estL = m * (float)spp;
-                estV = var * (float)spp * (1.0f + (float)spp / (float)(cnt ? cnt : 1u));      // spread of the pixel's length + error of this estimate of its mean
+                const float pL = m * (float)spp;
+                const float pV = var * (float)spp * (1.0f + (float)spp / (float)(cnt ? cnt : 1u));      // spread of the pixel's length + error of this estimate of its mean
+                // a pixel that has a length to go by (the pixel a batch earlier) keeps it unless the probe contradicts it: across a geometry edge the
+                // pixel a row or two up is a different kind of pixel
+                const float dl = pL - estL;
+                if (!have_est || dl * dl > 9.0f * (pV + estV)) { estL = pL; estV = pV; }
                 have_est = true;
             }
             cnt = 0u; sum_n = 0u; sum_n2 = 0.0f;
@@ -351,7 +355,11 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
                     const float nbar = fmaxf(Lp / (float)spp, 1.0f);
                     const unsigned nn = (unsigned)(nbar + 0.5f);
                     const unsigned t_ex = (unsigned)fminf(T_ex + 0.5f, 4.0e9f);
-                    const unsigned lead_d = (unsigned)fminf((float)spc.lead * nbar, 1.0e9f);
+                    // lead-in: two walks of a pixel whose samples nearly all take the same number of draws fall in with each other slowly (they only
+                    // change their relative position when one of them takes an unusual sample), so such pixels — whose samples are cheap — get a longer one
+                    float lead_s = (float)spc.lead;
+                    if (spc.lead_var > 0.0f) lead_s = fminf(fmaxf(lead_s, lead_s * spc.lead_var * (float)spp / fmaxf(eV, 1.0e-3f)), (float)spc.lead_max);
+                    const unsigned lead_d = (unsigned)fminf(lead_s * nbar, 1.0e9f);
                     unsigned margin = pl == 0u ? 0u : (unsigned)fminf(spc.ks * __builtin_sqrtf(S_ex), 1.0e9f) + lead_d;
                     margin = (margin + nn - 1u) / nn * nn;          // a pixel whose samples all take nn draws only meets the chain on its own residue
                     margin = min(margin, t_ex / nn * nn);

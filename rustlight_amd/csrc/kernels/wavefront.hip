@@ -660,9 +660,19 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     // (32 B per camera sample) fit their budget; one chunk unless the render is very large (1080p x 128 spp = 8.5 GB).
     struct Chunk { unsigned c0, c1, n_pix; std::vector<unsigned> base; };
     std::vector<Chunk> chunks;
-    if (two_pass) {
+    // The state buffer is sized by what the device has free, not only by the fixed budget (several contexts or shards on one device, a smaller GPU):
+    // the budget is cut to the buffer the context already holds + 60 % of the free memory, and if the allocation still fails it is halved until one
+    // cursor position of every block no longer fits — then the single-pass walk, which needs no such buffer, renders the frame.
+    if (two_pass && !getenv("RL_STATE_BUDGET_MB")) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) state_budget = std::min(state_budget, ctx->sample_states_capacity * sizeof(unsigned long long) + free_b / 10 * 6);
+        else (void)hipGetLastError();
+    }
+    for (bool planned_states = false; two_pass && !planned_states;) {
         const size_t budget = state_budget;
         const size_t per_cursor = (size_t)owned.size() * params->spp * 32;       // bytes of states one cursor position of every block takes (upper bound)
+        if (per_cursor > budget) { two_pass = false; chunks.clear(); break; }
+        chunks.clear();
         const unsigned cursors_per_chunk = (unsigned)std::max<size_t>(1, std::min<size_t>(256, budget / std::max<size_t>(1, per_cursor)));
         for (unsigned c0 = 0; c0 < 256u; c0 += cursors_per_chunk) {
             Chunk ch; ch.c0 = c0; ch.c1 = std::min(256u, c0 + cursors_per_chunk); ch.n_pix = 0;
@@ -673,6 +683,14 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
                 ch.n_pix += std::min(ch.c1, npx) - std::min(ch.c0, npx);
             }
             if (ch.n_pix) chunks.push_back(std::move(ch));
+        }
+        size_t need = 0;
+        for (const Chunk& ch : chunks) need = std::max(need, (size_t)ch.n_pix * params->spp * 4);
+        if (ctx->sample_states_capacity >= need && ctx->d_sample_states) planned_states = true;
+        else {
+            if (ctx->d_sample_states) { hipFree(ctx->d_sample_states); ctx->d_sample_states = nullptr; ctx->sample_states_capacity = 0; }
+            if (hipMalloc((void**)&ctx->d_sample_states, std::max<size_t>(need, 1) * sizeof(unsigned long long)) == hipSuccess) { ctx->sample_states_capacity = need; planned_states = true; }
+            else { (void)hipGetLastError(); ctx->d_sample_states = nullptr; state_budget /= 2; }      // fewer cursors per chunk
         }
     }
     unsigned max_chunk_pix = 0;
@@ -807,7 +825,14 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         // scenes that stream their BVH (exact build): the group fetches 16-node treelet blocks for its chain (traverse_treelet); 72 float4 of LDS per chain
         const bool treelets = !ctx->lds_scene && !fast_math && ctx->ds.nodes_t && ctx->ds.root_t >= 0 && plan_chain.item_shift >= 5u && ctx->ds.stack_depth <= 512u && !getenv("RL_CHAIN_NO_TREELETS");
         if (treelets) stc_c.pre_group = 1 << plan_chain.item_shift;
-        const size_t lds_chain = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + (treelets ? (size_t)(256 / stc_c.pre_group) * (72 + (ctx->ds.stack_depth + 1) / 2) * 16
+        // (both LDS-hungry forms are only taken when their workgroup fits: a very deep BVH or a large record set falls back to the plain per-node walk — ADVICE r3)
+        {
+            const size_t want = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + (treelets ? (size_t)(256 / stc_c.pre_group) * (72 + (ctx->ds.stack_depth + 1) / 2) * 16
+                                : (stc_c.pre_group ? (size_t)(256 / stc_c.pre_group) * ((size_t)ctx->ds.n_nodes * 32 + (size_t)ctx->ds.n_prims * 8) : 0));
+            if (want > (size_t)64 * 1024) stc_c.pre_group = 0;
+        }
+        const bool treelets_on = treelets && stc_c.pre_group != 0;
+        const size_t lds_chain = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + (treelets_on ? (size_t)(256 / stc_c.pre_group) * (72 + (ctx->ds.stack_depth + 1) / 2) * 16
                                  : (stc_c.pre_group ? (size_t)(256 / stc_c.pre_group) * ((size_t)ctx->ds.n_nodes * 32 + (size_t)ctx->ds.n_prims * 8) : 0));
         // ---- k_stream_spec (spec.hip.h): the chains with every lane busy — exact build; RL_CHAIN_SERIAL=1 keeps the one-lane-per-block walk (the cross-check)
         bool spec = !fast_math && !getenv("RL_CHAIN_SERIAL");
@@ -839,6 +864,9 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             if (getenv("RL_SPEC_CAP")) spc.cap = std::max(4u, (unsigned)atoi(getenv("RL_SPEC_CAP")));
             spc.probe = getenv("RL_SPEC_PROBE") ? (unsigned)atoi(getenv("RL_SPEC_PROBE")) : std::min(32u, std::max(4u, params->spp));
             spc.lead = getenv("RL_SPEC_LEAD") ? (unsigned)atoi(getenv("RL_SPEC_LEAD")) : 24u;
+            spc.lead_max = getenv("RL_SPEC_LEAD_MAX") ? (unsigned)atoi(getenv("RL_SPEC_LEAD_MAX")) : 128u;
+            spc.lead_var = getenv("RL_SPEC_LEAD_VAR") ? (float)atof(getenv("RL_SPEC_LEAD_VAR")) : 100.0f;      // (cbox 1080p x 128 spp: 265.5 -> 260.2 ms; probing every batch: 319.6 ms)
+            spc.probe_every = getenv("RL_SPEC_PROBE_EVERY") ? (unsigned)atoi(getenv("RL_SPEC_PROBE_EVERY")) : 0u;
             spc.ks = getenv("RL_SPEC_KS") ? (float)atof(getenv("RL_SPEC_KS")) : 1.65f;
             spc.ke = getenv("RL_SPEC_KE") ? (float)atof(getenv("RL_SPEC_KE")) : 1.65f;
             spec_threads = (unsigned)((((size_t)owned.size() * group) + 255u) / 256u * 256u);

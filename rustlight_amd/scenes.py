@@ -63,6 +63,7 @@ class MeshData:
     uv: Optional[np.ndarray]        # (n, 2) f32 or None
     bsdf: Bsdf
     emission: Optional[tuple] = None
+    emission_kind: Optional[tuple] = None      # None: EmissionType::Color; ('hsv', scale) | ('texture', scale, bitmap_id) (geometry.rs:99-104)
 
 
 @dataclass
@@ -416,3 +417,18 @@ def write_pbrt(scene: SceneData, path: str) -> None:
     lines.append("WorldEnd")
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")
+
+
+def luminance(rgb) -> np.float32:
+    """Color::luminance (src/structure.rs:173-176), in f32 like the reference."""
+    r, g, b = (np.float32(x) for x in rgb)
+    return np.float32(np.float32(r * np.float32(0.212671) + g * np.float32(0.715160)) + b * np.float32(0.072169))
+
+
+def override_light_emission(sd: "SceneData", kind: str, bitmap_id: int = -1) -> "SceneData":
+    """examples/cli.rs:410-429 (`-x hvs-light` / `-x texture-light`): every light mesh becomes EmissionType::HSV / Texture with scale = its colour's luminance."""
+    for m in sd.meshes:
+        if m.emission is not None:
+            scale = float(luminance(m.emission)) if m.emission_kind is None else 1.0
+            m.emission_kind = ("hsv", scale) if kind == "hsv" else ("texture", scale, bitmap_id)
+    return sd

@@ -44,6 +44,16 @@ def run(budget=20.0, seed=0, verbose=True, fast=False):
         if kind in (0, 1, 3) and rng.random() < 0.2:
             sd.medium = S.Medium(rand_color(0.0, 0.2), rand_color(0.1, 0.8), int(rng.choice([S.PHASE_ISOTROPIC, S.PHASE_HG])), float(rng.uniform(-0.6, 0.6)))
             sd.environment = None; sd.environment_map = None      # (no environment with a medium)
+        # `-x hvs-light` / `-x texture-light` (cli.rs:410-429): the light meshes' emission becomes uv-dependent (EmissionType::HSV / Texture) — when they all carry uv
+        lights = [m for m in sd.meshes if m.emission is not None]
+        if lights and all(m.uv is not None for m in lights) and rng.random() < 0.15:
+            kind_e = "hsv" if rng.random() < 0.5 else "texture"
+            bid = -1
+            if kind_e == "texture":
+                tw, th = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+                sd.bitmaps.append((tw, th, rng.uniform(0.0, 3.0, (tw * th, 3)).astype(np.float32)))
+                bid = len(sd.bitmaps) - 1
+            S.override_light_emission(sd, kind_e, bitmap_id=bid)
         return sd
 
     def rand_params(sd):

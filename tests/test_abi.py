@@ -61,7 +61,10 @@ def test_no_gpu_means_loud_failure_not_fallback(built, cbox64):
     for args in (["-n", "1", "-o", "/tmp/never.pfm", "path"], ["-x", "ats", "-n", "1", "-o", "/tmp/never.pfm", "direct", "-b", "1"]):
         r = subprocess.run([cli, os.path.join(ROOT, "data", "cbox.pbrt"), *args], capture_output=True, text=True)
         assert r.returncode != 0 and "no CPU fallback" in r.stderr and not os.path.exists("/tmp/never.pfm")
-    r = subprocess.run([cli, os.path.join(ROOT, "data", "cbox.pbrt"), "-x", "hvs-light", "path"], capture_output=True, text=True)
+    # `-x hvs-light` (EmissionType::HSV on every light mesh, cli.rs:410-429) is parsed and applied, then the same refusal; an unknown extra option is an error
+    r = subprocess.run([cli, os.path.join(ROOT, "data", "cbox.pbrt"), "-x", "hvs-light", "-n", "1", "-o", "/tmp/never.pfm", "path"], capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr and not os.path.exists("/tmp/never.pfm")
+    r = subprocess.run([cli, os.path.join(ROOT, "data", "cbox.pbrt"), "-x", "no-such-option", "-n", "1", "-o", "/tmp/never.pfm", "path"], capture_output=True, text=True)
     assert r.returncode == 2 and "not supported" in r.stderr
 
 

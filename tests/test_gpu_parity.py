@@ -1082,6 +1082,40 @@ def _c_initializer(v):
     return str(int(v))
 
 
+def test_uv_dependent_emission_parity(built):
+    """`-x hvs-light` / `-x texture-light` (examples/cli.rs:410-429): every light mesh's emission becomes EmissionType::HSV { scale } / Texture { scale, img }
+    (src/geometry.rs:99-104), evaluated by Mesh::emit at the hit's uv (vertex.rs:69-82) and at the sampled point's normalised uv (emitter.rs:609-688), with
+    Color::value(scale) as its flux and the triangle-centre emission in the light tree — image bits and counters of the oracle in both stream modes, both
+    pipelines, with the light tree, through `direct`, and on a many-light scene whose lights have uv."""
+    keys = ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws")
+    tex = (4, 3, np.random.default_rng(2).uniform(0.0, 2.0, (12, 3)).astype(np.float32))
+    for kind in ("hsv", "texture"):
+        for use_ats in (False, True):
+            sd = scenes.cbox(40, 32)
+            if kind == "texture": sd.bitmaps.append(tex)
+            scenes.override_light_emission(sd, kind, bitmap_id=0)
+            sd.use_ats = use_ats
+            ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+            for mode in (api.STREAM_PER_SAMPLE, api.STREAM_REFERENCE_ORDER):
+                for pipe in (api.PIPELINE_AUTO, api.PIPELINE_WAVEFRONT):
+                    got = _render_pair(sd, ctx, osc, seed=5, spp=6, stream_mode=mode, pipeline=pipe)
+                    _assert_parity(*got)
+            seeds = api.IndependentSampler(5).block_seeds(sd.width, sd.height)
+            img, st = ctx.render_direct(seeds, spp=4, nb_bsdf_samples=1, nb_light_samples=2)
+            ref, ost = osc.render_direct(seeds=seeds, spp=4, nb_bsdf_samples=1, nb_light_samples=2)
+            np.testing.assert_array_equal(img, ref)
+            assert all(st[k] == ost[k] for k in ("camera_samples", "extension_rays", "shadow_rays", "rng_draws"))
+            # the one-call POD carries the emission kind too
+            img2, st2 = api.Context(api.Scene.from_desc(sd), 0).render(seeds, api.path_params(spp=3))
+            np.testing.assert_array_equal(img2, ctx.render(seeds, api.path_params(spp=3))[0])
+    # a light mesh without uv cannot take a uv-dependent emission (the reference's `uv.unwrap()` would panic): refused
+    sd = scenes.cbox(16, 16)
+    sd.meshes[-1].uv = None
+    scenes.override_light_emission(sd, "hsv")
+    with pytest.raises(api.RustlightError):
+        api.Scene(sd)
+
+
 def test_verbatim_reference_scene_renders_like_the_fixture(built):
     """examples/web/index.html:9-43 verbatim (tests/golden/web_cbox_verbatim.pbrt) through rl_scene_load_pbrt renders the image of the in-memory
     fixture — and of the oracle — bit for bit, in rustlight's own reference-order streams."""

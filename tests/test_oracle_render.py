@@ -222,3 +222,32 @@ def test_ao_and_direct(built, orc_cbox64):
     dl, _ = orc_cbox64.render_direct(master_seed=4, spp=32, nb_bsdf_samples=0, nb_light_samples=2)
     db, _ = orc_cbox64.render_direct(master_seed=5, spp=128, nb_bsdf_samples=2, nb_light_samples=0)
     assert abs(dl.mean() - d.mean()) / d.mean() < 0.05 and abs(db.mean() - d.mean()) / d.mean() < 0.1
+
+
+def test_uv_dependent_emission_kinds():
+    """EmissionType::HSV / Texture (src/geometry.rs:99-104,184-206; `-x hvs-light` / `-x texture-light`, examples/cli.rs:410-429) in the oracle: Mesh::emit at the
+    sampled point's uv — interpolated and then `.normalize()`d as a 2-vector (sic, geometry.rs:316-325) — times geom / pdf_area is the light sample's weight;
+    Emitter::flux takes Color::value(scale); the image changes colour accordingly (no blue from an HSV light)."""
+    sd = scenes.cbox(24, 24)
+    scenes.override_light_emission(sd, "hsv")
+    scale = np.float32(scenes.luminance((17.0, 12.0, 4.0)))
+    assert sd.meshes[-1].emission_kind == ("hsv", float(scale))
+    sc = orc.Scene(sd)
+    p = np.array([0.1, 0.4, -0.2], np.float32)
+    for a, b, c in ((0.3, 0.2, 0.7), (0.9, 0.55, 0.05), (0.5, 0.99, 0.4)):
+        ls = sc.sample_light(p, 0.3, a, b, c)
+        plain = orc.Scene(scenes.cbox(24, 24)).sample_light(p, 0.3, a, b, c)
+        np.testing.assert_array_equal(ls["p"], plain["p"])                          # same point, same pdf: only the emitted colour differs
+        assert ls["pdf"] == plain["pdf"]
+        m = sd.meshes[-1]
+        # uv of the sampled point from its position: the light quad's uv are an affine map of (x, z); recompute through the barycentrics of the hit triangle instead
+        w = ls["weight"] / np.maximum(plain["weight"], 1e-30) * np.array([17.0, 12.0, 4.0], np.float32)     # = emit(uv)
+        assert w[2] == 0.0 and abs((w[0] + w[1]) / scale - 1.0) < 1e-5                                       # (x, 1 - x, 0) * scale
+    img, st = sc.render(master_seed=3, spp=8, stream_mode=1)
+    assert img[..., 2].max() == 0.0 and img[..., 0].mean() > 0.0 and img[..., 1].mean() > 0.0
+    # a texture light: a 2 x 2 bitmap, scale * img.pixel_uv(uv)
+    sd2 = scenes.cbox(24, 24)
+    sd2.bitmaps.append((2, 2, np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 1]], np.float32)))
+    scenes.override_light_emission(sd2, "texture", bitmap_id=0)
+    img2, _ = orc.Scene(sd2).render(master_seed=3, spp=8, stream_mode=1)
+    assert np.isfinite(img2).all() and img2.mean() > 0.0 and not np.array_equal(img2, img)
