@@ -71,6 +71,7 @@ struct SpecConf {
     unsigned probe;              // samples of the estimate probe (lanes that have no resolved pixel to go by: the first batch)
     unsigned lead;               // samples of lead-in before a window (a track needs a few samples to fall in with the chain)
     unsigned lead_max; float lead_var;   // pixels whose draws per sample vary less than lead_var get lead x lead_var / variance samples of it, at most lead_max
+    unsigned extra;              // != 0: a pixel's last lane walks on past its window while other lanes of the group still walk (it would idle; fewer serial samples past the track's end)
     unsigned probe_every;        // != 0: every batch probes (a pixel keeps the length of the pixel a batch earlier unless the probe contradicts it)
     float serial_ratio;          // a batch whose samples take more than spp / serial_ratio draws on average is walked serially (0: never)
     float ks, ke;                // window margins in standard deviations of the predicted start / end offset

@@ -61,26 +61,43 @@ RL_DEV Col tex_color(const DeviceScene& sc, const ColorTex& t, bool has_uv, V2 u
     return (fabsf(x) < t.line_width || fabsf(y) < t.line_width) ? mkc(t.c0[0], t.c0[1], t.c0[2]) : mkc(t.c1[0], t.c1[1], t.c1[2]);
 }
 
+// LIGHTS: what the scene's emitter set may contain, known when the kernel is picked (see sample_light): LIGHTS_AREA_ONLY = mesh area lights with a CONSTANT
+// emission only, no light tree — the code of everything else is compiled out of the caller.
+enum { LIGHTS_ANY = 0, LIGHTS_AREA_ONLY = 1 };
 // Mesh::emit(uv) (src/geometry.rs:184-206) of a mesh known to be a light: the constant colour, or one of the two uv-dependent kinds the CLI's
 // `-x hvs-light` / `-x texture-light` switch every light to (a light mesh of those kinds always has uv: the host refuses it otherwise, where the
-// reference's `uv.unwrap()` would panic)
-RL_DEV Col mesh_emit(const DeviceScene& sc, const MeshRecord& mr, bool has_uv, V2 uv) {
-    if (mr.emission_type == 1) {
-        const float x = fmodf(fabsf(uv.x), 1.0f);                              // uv.x.abs() % 1.0
+// reference's `uv.unwrap()` would panic).  The uv-dependent kinds live in a function of their own that is NOT inlined: inlined, their code raised the
+// register pressure of every kernel that shades (the headline kernel went from 6 to 16 spilled VGPRs for a branch it never takes).
+static __device__ __noinline__ Col mesh_emit_uv(const BitmapDesc* bitmaps, const float* texels, int type, float scale, int bitmap, bool has_uv, float ux_in, float uy_in) {
+    if (type == 1) {
+        const float x = fmodf(fabsf(ux_in), 1.0f);                              // uv.x.abs() % 1.0
         const Col c = x * mkc(1.0f, 0.0f, 0.0f) + (1.0f - x) * mkc(0.0f, 1.0f, 0.0f);
-        return c * mr.emission_scale;                                          // Color * f32 (guarded)
+        return c * scale;                                                       // Color * f32 (guarded)
     }
-    if (mr.emission_type == 2) {
-        if (!has_uv || mr.emission_bitmap < 0) return czero();
-        BitmapDesc bd = sc.bitmaps[mr.emission_bitmap];                        // Bitmap::pixel_uv (src/structure.rs:434-453)
-        float ux = modulo1(uv.x), uy = modulo1(uv.y);
-        unsigned long long x = f32_as_usize(ux * (float)bd.w), y = f32_as_usize(uy * (float)bd.h);
-        unsigned long long i = (unsigned long long)bd.w * y + x;
-        Col c = czero();
-        if (i < (unsigned long long)bd.w * bd.h) { const float* px = sc.bitmap_texels + 3ull * (bd.offset + i); c = mkc(px[0], px[1], px[2]); }
-        return c * mr.emission_scale;
+    if (!has_uv || bitmap < 0) return czero();
+    BitmapDesc bd = bitmaps[bitmap];                                            // Bitmap::pixel_uv (src/structure.rs:434-453)
+    float ux = modulo1(ux_in), uy = modulo1(uy_in);
+    unsigned long long x = f32_as_usize(ux * (float)bd.w), y = f32_as_usize(uy * (float)bd.h);
+    unsigned long long i = (unsigned long long)bd.w * y + x;
+    Col c = czero();
+    if (i < (unsigned long long)bd.w * bd.h) { const float* px = texels + 3ull * (bd.offset + i); c = mkc(px[0], px[1], px[2]); }
+    return c * scale;
+}
+template <int LIGHTS = LIGHTS_ANY>
+RL_DEV Col mesh_emit(const DeviceScene& sc, const MeshRecord& mr, bool has_uv, V2 uv) {
+    if (LIGHTS == LIGHTS_AREA_ONLY || __builtin_expect(mr.emission_type == 0, 1)) return mkc(mr.emission[0], mr.emission[1], mr.emission[2]);
+    return mesh_emit_uv(sc.bitmaps, sc.bitmap_texels, mr.emission_type, mr.emission_scale, mr.emission_bitmap, has_uv, uv.x, uv.y);
+}
+// the emission at a SAMPLED point of triangle (i0, i1, i2): its uv is interpolated and then `.normalize()`d as a 2-vector (sic, geometry.rs:316-325)
+static __device__ __noinline__ Col mesh_emit_sampled(const BitmapDesc* bitmaps, const float* texels, const float* uvs, int type, float scale, int bitmap, bool has_uv,
+                                                     unsigned i0, unsigned i1, unsigned i2, float bx, float by, float w2) {
+    float sx = 0.0f, sy = 0.0f;
+    if (has_uv) {
+        const float tx = uvs[2 * i0] * bx + uvs[2 * i1] * by + uvs[2 * i2] * w2, ty = uvs[2 * i0 + 1] * bx + uvs[2 * i1 + 1] * by + uvs[2 * i2 + 1] * w2;
+        const float inv = div_rn(1.0f, sqrt_rn(tx * tx + ty * ty));
+        sx = tx * inv; sy = ty * inv;
     }
-    return mkc(mr.emission[0], mr.emission[1], mr.emission[2]);
+    return mesh_emit_uv(bitmaps, texels, type, scale, bitmap, has_uv, sx, sy);
 }
 
 // Intersection::fill_intersection
@@ -499,6 +516,7 @@ RL_DEV bool bsphere_intersect(V3 center, float radius, V3 o, V3 d, float tnear, 
 
 // Mesh::sample_tri + the direct_sample tail shared by Mesh::direct_sample / direct_sample_tri (geometry.rs:261-337,
 // emitter.rs:609-688): point on triangle `prim` of the mesh, geometry term, solid-angle pdf from `pdf_area`.
+template <int LIGHTS = LIGHTS_ANY>
 RL_DEV void mesh_sample_triangle(const DeviceScene& sc, const MeshRecord& mr, unsigned int prim, float pdf_area, V3 p, V2 uv, LightSample* ls) {
     unsigned int gtri = mr.tri_base + prim;
     unsigned int i0 = sc.tri_indices[3 * gtri], i1 = sc.tri_indices[3 * gtri + 1], i2 = sc.tri_indices[3 * gtri + 2];
@@ -526,18 +544,8 @@ RL_DEV void mesh_sample_triangle(const DeviceScene& sc, const MeshRecord& mr, un
     float geom = dist != 0.0f ? div_rn(rmax(dot(n_g, -d), 0.0f), dist * dist) : 0.0f;
     float pdf = geom == 0.0f ? 0.0f : div_rn(pdf_area, geom);   // PDF::as_solid_angle_geom
     Col emit;
-    if (mr.emission_type == 0) emit = mkc(mr.emission[0], mr.emission[1], mr.emission[2]);
-    else {
-        // the sampled point's uv: interpolated, then `.normalize()`d as a 2-vector (sic, geometry.rs:316-325)
-        V2 suv; suv.x = 0.0f; suv.y = 0.0f;
-        const bool huv = (mr.flags & MESH_HAS_UV) != 0;
-        if (huv) {
-            const float tx = sc.uvs[2 * i0] * b.x + sc.uvs[2 * i1] * b.y + sc.uvs[2 * i2] * w2, ty = sc.uvs[2 * i0 + 1] * b.x + sc.uvs[2 * i1 + 1] * b.y + sc.uvs[2 * i2 + 1] * w2;
-            const float inv = div_rn(1.0f, sqrt_rn(tx * tx + ty * ty));
-            suv.x = tx * inv; suv.y = ty * inv;
-        }
-        emit = mesh_emit(sc, mr, huv, suv);
-    }
+    if (LIGHTS == LIGHTS_AREA_ONLY || __builtin_expect(mr.emission_type == 0, 1)) emit = mkc(mr.emission[0], mr.emission[1], mr.emission[2]);
+    else emit = mesh_emit_sampled(sc.bitmaps, sc.bitmap_texels, sc.uvs, mr.emission_type, mr.emission_scale, mr.emission_bitmap, (mr.flags & MESH_HAS_UV) != 0, i0, i1, i2, b.x, b.y, w2);
     ls->weight = pdf == 0.0f ? czero() : emit * geom / pdf_area;
     ls->pdf = pdf; ls->pdf_kind = PDF_SOLID_ANGLE;
     ls->p = pos; ls->n = n_g; ls->d = d;
@@ -614,7 +622,6 @@ RL_DEV float ats_pdf(const DeviceScene& sc, unsigned int leaf, V3 p, bool has_n,
 // or direct_sample_tri of the (emitter, triangle) picked by the light tree.  `n`: Some(&its.n_s) at surfaces, None in the medium.
 // LIGHTS: what the scene's emitter set may contain, known when the kernel is picked — LIGHTS_AREA_ONLY compiles the light tree, point,
 // directional and environment code out of the caller (the emitter kinds are then not even looked at); results are those of LIGHTS_ANY.
-enum { LIGHTS_ANY = 0, LIGHTS_AREA_ONLY = 1 };
 template <int LIGHTS = LIGHTS_ANY>
 RL_DEV LightSample sample_light(const DeviceScene& sc, V3 p, bool has_n, V3 n, float r_sel, float r, V2 uv) {
     if (LIGHTS != LIGHTS_AREA_ONLY && sc.ats_root >= 0) {
@@ -622,7 +629,7 @@ RL_DEV LightSample sample_light(const DeviceScene& sc, V3 p, bool has_n, V3 n, f
         int li = ats_sample(sc, r_sel, p, has_n, n, &pdf_sel);
         LightSample ls;
         ls.kind = EMITTER_MESH;
-        mesh_sample_triangle(sc, sc.meshes[sc.ats_light_mesh[li]], (unsigned int)sc.ats_light_prim[li], -1.0f, p, uv, &ls);
+        mesh_sample_triangle<LIGHTS>(sc, sc.meshes[sc.ats_light_mesh[li]], (unsigned int)sc.ats_light_prim[li], -1.0f, p, uv, &ls);
         ls.weight = div_unguarded(ls.weight, pdf_sel);
         ls.pdf = ls.pdf * pdf_sel;
         return ls;
@@ -636,7 +643,7 @@ RL_DEV LightSample sample_light(const DeviceScene& sc, V3 p, bool has_n, V3 n, f
         // Mesh::direct_sample -> Mesh::sample: triangle by area cdf, pdf = Area(1 / cdf.total()) (emitter.rs:652-688, geometry.rs:340-348)
         MeshRecord mr = sc.meshes[em.mesh];
         unsigned int prim = cdf_sample(sc.mesh_cdf + mr.cdf_base, mr.n_tris + 1, r);
-        mesh_sample_triangle(sc, mr, prim, mr.inv_area, p, uv, &ls);
+        mesh_sample_triangle<LIGHTS>(sc, mr, prim, mr.inv_area, p, uv, &ls);
     } else if (em.kind == EMITTER_POINT) {                 // PointEmitter::direct_sample (emitter.rs:194-213)
         V3 lp = mk3(em.v[0], em.v[1], em.v[2]);
         V3 d = lp - p;

@@ -38,7 +38,7 @@
 namespace rl {
 
 
-enum : unsigned { SM_IDLE = 0u, SM_PROBE, SM_WALK, SM_TRUTH, SM_EXT };
+enum : unsigned { SM_IDLE = 0u, SM_PROBE, SM_WALK, SM_TRUTH, SM_EXTRA };      // SM_EXTRA: a pixel's last lane walking on past its window while the rest of the group still walks (free filler: it would idle)
 enum : unsigned { SP_PROBE = 0u, SP_WALK, SP_RESOLVE, SP_DONE };
 
 RL_DEV Rng shfl_rng(const Rng& r, int src) {
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
                     if (!fresh) { cnt++; sum_n += nd; sum_n2 += (float)nd * (float)nd; st_probe++; }
                     if (cnt >= spc.probe) { mode = SM_IDLE; PU(U_FLAGS) = 0u; }
                     else begin_sample(rc, sc, rng);
-                } else if (mode == SM_WALK) {
+                } else if (mode == SM_WALK || mode == SM_EXTRA) {
                     if (!fresh) { cnt++; sum_n += nd; sum_n2 += (float)nd * (float)nd; cur_off += nd; st_spec++; }
                     my_off[M] = cur_off;
                     my_st[2u * M] = make_ulonglong2(rng.s0, rng.s1); my_st[2u * M + 1u] = make_ulonglong2(rng.s2, rng.s3);
@@ -258,7 +258,8 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
                         link_j = lj;
                         if (lj < Mb && bv == cur_off) { link_i = M; met = true; }
                     }
-                    if (met || cur_off >= stop || M + 1u >= spc.cap) { mode = SM_IDLE; PU(U_FLAGS) = 0u; }      // entry M is the frontier
+                    if (mode == SM_WALK && !met && cur_off >= stop && sk + 1u == S && M + 1u < spc.cap && spc.extra) mode = SM_EXTRA;      // the window is covered: walk on while others still walk
+                    if (met || M + 1u >= spc.cap || (mode == SM_WALK && cur_off >= stop)) { mode = SM_IDLE; PU(U_FLAGS) = 0u; }      // entry M is the frontier
                     else { M++; begin_sample(rc, sc, rng); }
                 } else {   // SM_TRUTH: the pixel's leader walks where no track carries the chain
                     res_i++; cur_off += nd; st_slow++;
@@ -281,7 +282,12 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
         RL_ST1(0)
 
         // ---- B. group transitions, taken when no lane of the group is walking
-        const bool group_idle = (__ballot(mode != SM_IDLE) & gmask) == 0ull;
+        const bool group_idle = (__ballot(mode != SM_IDLE && mode != SM_EXTRA) & gmask) == 0ull;
+        if (group_idle && mode == SM_EXTRA) {      // the group's windows are all walked: the extra walk stops where it stands (the sample in flight is dropped, its start stays the frontier)
+            if (!(PU(U_FLAGS) & ST_REGEN) || (PU(U_FLAGS) & ST_FRESH)) M--;
+            else { cur_off += nd; my_off[M] = cur_off; const Rng r2 = load_rng(ps, Q_R0); my_st[2u * M] = make_ulonglong2(r2.s0, r2.s1); my_st[2u * M + 1u] = make_ulonglong2(r2.s2, r2.s3); }
+            mode = SM_IDLE; PU(U_FLAGS) = 0u;
+        }
         if (group_idle && phase == SP_PROBE) {
             if (!planned) {
                 // a new batch: this lane's pixel
@@ -302,7 +308,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
                 }
             }
         }
-        const bool group_idle2 = (__ballot(mode != SM_IDLE) & gmask) == 0ull;
+        const bool group_idle2 = (__ballot(mode != SM_IDLE && mode != SM_EXTRA) & gmask) == 0ull;
         if (group_idle2 && phase == SP_PROBE && planned) {
             // ---- the windows of the batch
             if (sk == 0u && valid && !triv && (!have_est || cnt > 0u)) {

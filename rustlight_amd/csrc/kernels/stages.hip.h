@@ -326,7 +326,7 @@ RL_DEV void shade_slot(const RenderConst& rc, const DeviceScene& sc, PS& ps, uns
         // ---- contribution carried by the arriving edge (Edge::contribution -> Vertex::contribution)
         if constexpr (!DRAWS_ONLY) {
         Col emit = czero();
-        if (!is_volume && (mr.flags & MESH_IS_LIGHT) && dot(sp.n_s, -rd) >= 0.0f) emit = mesh_emit(sc, mr, sp.has_uv, sp.uv);      // its.mesh.emit(&its.uv) (vertex.rs:69-82)
+        if (!is_volume && (mr.flags & MESH_IS_LIGHT) && dot(sp.n_s, -rd) >= 0.0f) emit = mesh_emit<LIGHTS>(sc, mr, sp.has_uv, sp.uv);      // its.mesh.emit(&its.uv) (vertex.rs:69-82)
         Col contrib = W * emit;
         const unsigned cur = depth - 1u;          // evaluate()'s curr_depth of the origin vertex
         const bool add_contrib = rc.has_min ? cur >= rc.min_depth : true;

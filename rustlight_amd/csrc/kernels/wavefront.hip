@@ -387,6 +387,7 @@ extern "C" int rl_context_create(const rl_scene* scene, int device, rl_context**
         ds.medium = scene->medium;
         ctx->area_lights_only = scene->ats_root < 0 && !getenv("RL_GENERIC_LIGHTS");
         for (const EmitterRecord& e : scene->emitters) if (e.kind != EMITTER_MESH) ctx->area_lights_only = false;
+        for (const HostMesh& hm : scene->meshes) if (hm.is_light && hm.emission_type != RL_EMISSION_COLOR) ctx->area_lights_only = false;      // uv-dependent emission (`-x hvs-light | texture-light`): the generic instantiation
         ctx->single_bsdf = true;
         ctx->bsdf_type = flat.materials.empty() ? 0 : flat.materials[0].type;
         for (const Material& m : flat.materials) if (m.type != ctx->bsdf_type) ctx->single_bsdf = false;
@@ -866,6 +867,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             spc.lead = getenv("RL_SPEC_LEAD") ? (unsigned)atoi(getenv("RL_SPEC_LEAD")) : 24u;
             spc.lead_max = getenv("RL_SPEC_LEAD_MAX") ? (unsigned)atoi(getenv("RL_SPEC_LEAD_MAX")) : 128u;
             spc.lead_var = getenv("RL_SPEC_LEAD_VAR") ? (float)atof(getenv("RL_SPEC_LEAD_VAR")) : 100.0f;      // (cbox 1080p x 128 spp: 265.5 -> 260.2 ms; probing every batch: 319.6 ms)
+            spc.extra = getenv("RL_SPEC_EXTRA") ? (unsigned)atoi(getenv("RL_SPEC_EXTRA")) : 0u;      // (cbox 1080p x 128 spp: 2.84 M instead of 3.57 M serial samples, 383 M instead of 306 M walked: 261 vs 259 ms — a wash, off)
             spc.probe_every = getenv("RL_SPEC_PROBE_EVERY") ? (unsigned)atoi(getenv("RL_SPEC_PROBE_EVERY")) : 0u;
             spc.ks = getenv("RL_SPEC_KS") ? (float)atof(getenv("RL_SPEC_KS")) : 1.65f;
             spc.ke = getenv("RL_SPEC_KE") ? (float)atof(getenv("RL_SPEC_KE")) : 1.65f;
