@@ -75,9 +75,9 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
 
     // ---- the group: G lanes of one wave own one block; S of them share a pixel (lane sk walks segment sk of the pixel's window), so a batch is
     // NP = G / S consecutive pixels.  The pixel's first lane (sk = 0, the LEADER) keeps the pixel's state and threads the chain through it.
-    const unsigned G = spc.group, S = spc.sub, NP = G / S, lane = threadIdx.x & 63u, gl = lane & (G - 1u);
+    const unsigned G = spc.group, S = spc.sub, NP = G / S, lane = threadIdx.x & 63u, gl = threadIdx.x & (G - 1u);      // G = 256: the whole workgroup (4 waves) owns one block
     const unsigned pl = gl / S, sk = gl - pl * S, lt = threadIdx.x - sk;          // pixel slot, segment, the leader's thread index in the workgroup
-    const unsigned long long gmask = (G >= 64u ? ~0ull : ((1ull << G) - 1ull)) << (lane & ~(G - 1u));
+    const unsigned long long gmask = (G >= 64u ? ~0ull : ((1ull << G) - 1ull)) << (lane & ~(G - 1u) & 63u);
     const unsigned item = tid / G;
     const bool have_block = item < rc_arg.n_owned;
     const unsigned spp = rc_arg.spp;
@@ -130,6 +130,32 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
     auto load_anc = [&]() -> Rng { Rng r; r.s0 = ganc[0]; r.s1 = ganc[1]; r.s2 = ganc[2]; r.s3 = ganc[3]; return r; };
     auto store_anc = [&](const Rng& r) { ganc[0] = r.s0; ganc[1] = r.s1; ganc[2] = r.s2; ganc[3] = r.s3; };      // (every lane of the group writes the same value)
     store_anc(anc);
+    // group-wide votes and sums: within a wave by ballot / shuffles; a group that spans the workgroup (G = 256) through the barrier (every thread of the
+    // workgroup then belongs to the one group, so every call site is reached by all of them together)
+    float* const gscratch = reinterpret_cast<float*>(coldbase + K_COLD_COUNT * 256 + 8 * (256 / 16));
+    auto group_any = [&](bool p) -> bool { return G <= 64u ? (__ballot(p) & gmask) != 0ull : __syncthreads_or((int)p) != 0; };
+    auto group_scan2 = [&](float& a, float& b) {      // inclusive prefix sums over the lanes of the group
+        const unsigned w = G <= 64u ? G : 64u, li = G <= 64u ? gl : lane;
+        for (unsigned d = 1u; d < w; d <<= 1) { const float ta = __shfl_up(a, d, 64), tb = __shfl_up(b, d, 64); if (li >= d) { a += ta; b += tb; } }
+        if (G > 64u) {
+            const unsigned wv = threadIdx.x >> 6;
+            if (lane == 63u) { gscratch[wv] = a; gscratch[4u + wv] = b; }
+            __syncthreads();
+            for (unsigned k = 0; k < wv; k++) { a += gscratch[k]; b += gscratch[4u + k]; }
+            __syncthreads();
+        }
+    };
+    auto group_sum2 = [&](float& a, float& b) {
+        const unsigned w = G <= 64u ? G : 64u;
+        for (unsigned d = 1u; d < w; d <<= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+        if (G > 64u) {
+            const unsigned wv = threadIdx.x >> 6;
+            if (lane == 0u) { gscratch[8u + wv] = a; gscratch[12u + wv] = b; }
+            __syncthreads();
+            a = ((gscratch[8] + gscratch[9]) + gscratch[10]) + gscratch[11]; b = ((gscratch[12] + gscratch[13]) + gscratch[14]) + gscratch[15];
+            __syncthreads();
+        }
+    };
     auto load_res_st = [&](unsigned t) -> Rng {        // of workgroup thread t (a leader)
         const unsigned* q = coldbase + K_RES_ST * 256 + t;
         Rng r;
@@ -278,11 +304,11 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
                 }
             }
         }
-        if ((__ballot(fin_now) & gmask) != 0ull) own++;
+        if (group_any(fin_now)) own++;
         RL_ST1(0)
 
         // ---- B. group transitions, taken when no lane of the group is walking
-        const bool group_idle = (__ballot(mode != SM_IDLE && mode != SM_EXTRA) & gmask) == 0ull;
+        const bool group_idle = !group_any(mode != SM_IDLE && mode != SM_EXTRA);
         if (group_idle && mode == SM_EXTRA) {      // the group's windows are all walked: the extra walk stops where it stands (the sample in flight is dropped, its start stays the frontier)
             if (!(PU(U_FLAGS) & ST_REGEN) || (PU(U_FLAGS) & ST_FRESH)) M--;
             else { cur_off += nd; my_off[M] = cur_off; const Rng r2 = load_rng(ps, Q_R0); my_st[2u * M] = make_ulonglong2(r2.s0, r2.s1); my_st[2u * M + 1u] = make_ulonglong2(r2.s2, r2.s3); }
@@ -308,7 +334,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
                 }
             }
         }
-        const bool group_idle2 = (__ballot(mode != SM_IDLE && mode != SM_EXTRA) & gmask) == 0ull;
+        const bool group_idle2 = !group_any(mode != SM_IDLE && mode != SM_EXTRA);
         if (group_idle2 && phase == SP_PROBE && planned) {
             // ---- the windows of the batch
             if (sk == 0u && valid && !triv && (!have_est || cnt > 0u)) {
@@ -327,12 +353,9 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
             const float Lp = valid ? (triv ? 2.0f * (float)spp : eL) : 0.0f;
             const float Vp = (valid && !triv) ? 2.0f * eV : 0.0f;        // the length it is predicted from is itself one draw of the same spread
             float Ti = sk == 0u ? Lp : 0.0f, Si = sk == 0u ? Vp : 0.0f;      // sums over the pixels up to and including this lane's
-            for (unsigned d = 1u; d < G; d <<= 1) {
-                const float t = __shfl_up(Ti, d, 64), s = __shfl_up(Si, d, 64);
-                if (gl >= d) { Ti += t; Si += s; }
-            }
+            group_scan2(Ti, Si);
             const float T_ex = Ti - Lp, S_ex = Si - Vp;
-            const bool any_walk = (__ballot(valid && !triv) & gmask) != 0ull;
+            const bool any_walk = group_any(valid && !triv);
             // Two walks of a pixel meet after about as many samples as a sample takes draws (their sample starts are renewal processes of that density), so a
             // pixel of spp samples can only be threaded through a speculative track when its samples are short next to spp: a batch whose pixels take more
             // than spp / serial_ratio draws per sample on average (participating media, deep specular chains, few samples per pixel) is walked by its
@@ -340,7 +363,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
             bool serial_batch = false;
             if (any_walk && spc.serial_ratio > 0.0f) {
                 float sl = (sk == 0u && valid && !triv) ? Lp : 0.0f, sn = (sk == 0u && valid && !triv) ? 1.0f : 0.0f;
-                for (unsigned d = 1u; d < G; d <<= 1) { sl += __shfl_xor(sl, d, 64); sn += __shfl_xor(sn, d, 64); }
+                group_sum2(sl, sn);
                 serial_batch = sl * spc.serial_ratio > sn * (float)spp * (float)spp;       // mean draws per sample = sl / (sn spp)
             }
             if (any_walk && serial_batch) {
@@ -393,6 +416,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
         // the tracks were written by other lanes of this wave: their stores are made visible first.
         if (S > 1u && __ballot(phase == SP_RESOLVE && !linked && own < NP) != 0ull) {
             __threadfence();
+            if (G > 64u) __syncthreads();          // (the tracks of a pixel's lanes are in one wave, but the threading below reads across waves)
             if (phase == SP_RESOLVE && !linked) {
                 linked = true;
                 if (valid && !triv && sk + 1u < S && link_i == 0xffffffffu) {
@@ -450,9 +474,9 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
                         }
                     }
                 }
-                const unsigned long long fm = __ballot(fin);
-                if ((fm & gmask) != 0ull) own++;
-                if (fm == 0ull) break;
+                const bool gfin = group_any(fin);
+                if (gfin) own++;
+                if (G <= 64u ? __ballot(fin) == 0ull : !gfin) break;
             }
         }
 

@@ -856,11 +856,13 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             // scenes that stream their BVH are bound by the latency of a wave's dependent fetches: one block per wave, four lanes per pixel
             // (508 k triangles, 1080p x 128 spp: 32 x 1 / 64 x 4 = 4377 / 2667 ms; the serial chain 5689 ms); LDS-staged ones: two lanes per pixel from 32 lanes per block on
             if (!ctx->lds_scene) group = 64u;
-            if (getenv("RL_SPEC_GROUP")) { const int g = atoi(getenv("RL_SPEC_GROUP")); if (g == 16 || g == 32 || g == 64) group = (unsigned)g; }
+            if (getenv("RL_SPEC_GROUP")) { const int g = atoi(getenv("RL_SPEC_GROUP")); if (g == 16 || g == 32 || g == 64 || g == 256) group = (unsigned)g; }
             spc.group = group;
-            spc.sub = !ctx->lds_scene ? 4u : (group >= 32u ? 2u : 1u);
+            // sixteen pixels per batch whatever the group: a longer look-ahead widens every window and misses more often (shard 0 of 8 at 1024 spp, 64 lanes per block,
+            // 1 / 2 / 4 lanes per pixel: 2621 / 1235 / 731 ms; full frame at 128 spp, 32 lanes: 2 lanes per pixel 265, 4: 705)
+            spc.sub = std::max(1u, group / 16u);
             spc.serial_ratio = spec_force ? 0.0f : (getenv("RL_SPEC_SERIAL_RATIO") ? (float)atof(getenv("RL_SPEC_SERIAL_RATIO")) : 3.0f);
-            if (getenv("RL_SPEC_SUB")) { const int v = atoi(getenv("RL_SPEC_SUB")); if ((v == 1 || v == 2 || v == 4 || v == 8) && (unsigned)v <= group) spc.sub = (unsigned)v; }
+            if (getenv("RL_SPEC_SUB")) { const int v = atoi(getenv("RL_SPEC_SUB")); if ((v == 1 || v == 2 || v == 4 || v == 8 || v == 16) && (unsigned)v <= group) spc.sub = (unsigned)v; }
             spc.cap = std::max(96u, std::min(3u * params->spp + 64u, 1u << 20));
             if (getenv("RL_SPEC_CAP")) spc.cap = std::max(4u, (unsigned)atoi(getenv("RL_SPEC_CAP")));
             spc.probe = getenv("RL_SPEC_PROBE") ? (unsigned)atoi(getenv("RL_SPEC_PROBE")) : std::min(32u, std::max(4u, params->spp));
@@ -869,8 +871,10 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             spc.lead_var = getenv("RL_SPEC_LEAD_VAR") ? (float)atof(getenv("RL_SPEC_LEAD_VAR")) : 100.0f;      // (cbox 1080p x 128 spp: 265.5 -> 260.2 ms; probing every batch: 319.6 ms)
             spc.extra = getenv("RL_SPEC_EXTRA") ? (unsigned)atoi(getenv("RL_SPEC_EXTRA")) : 0u;      // (cbox 1080p x 128 spp: 2.84 M instead of 3.57 M serial samples, 383 M instead of 306 M walked: 261 vs 259 ms — a wash, off)
             spc.probe_every = getenv("RL_SPEC_PROBE_EVERY") ? (unsigned)atoi(getenv("RL_SPEC_PROBE_EVERY")) : 0u;
-            spc.ks = getenv("RL_SPEC_KS") ? (float)atof(getenv("RL_SPEC_KS")) : 1.65f;
-            spc.ke = getenv("RL_SPEC_KE") ? (float)atof(getenv("RL_SPEC_KE")) : 1.65f;
+            // window margins in standard deviations of the predicted offsets: with one block per wave a pixel the chain has to be walked through stalls the whole wave, so wider
+            // (shard 0 of 8, 1024 spp: 1.65 / 2.5 sigma = 714 / 688 ms; full frame, two blocks per wave: 281 / 292)
+            spc.ks = getenv("RL_SPEC_KS") ? (float)atof(getenv("RL_SPEC_KS")) : (group >= 64u ? 2.5f : 1.65f);
+            spc.ke = getenv("RL_SPEC_KE") ? (float)atof(getenv("RL_SPEC_KE")) : (group >= 64u ? 2.5f : 1.65f);
             spec_threads = (unsigned)((((size_t)owned.size() * group) + 255u) / 256u * 256u);
             // the tracks: 36 B per entry; when they do not fit what the device has free the serial walk runs instead
             const size_t need = (size_t)spec_threads * spc.cap * 36u;
@@ -910,7 +914,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             ra.n_state_pixels = ch.n_pix; ra.cursor_begin = ch.c0; ra.cursor_end = ch.c1;
             hipLaunchKernelGGL(k_chunk_pixels, dim3(((unsigned)owned.size() + 63) / 64), dim3(64), 0, st, ra);
             if (timing) hipEventRecord(ctx->events[0], st);
-            if (spec) (ctx->lds_scene ? launch_spec_lds : launch_spec_stream)(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, dim3(spec_threads / 256u), block, traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + (size_t)kSpecColdWords * 256 * 4 + (256 / 16) * 32, st, ra, ds, stc, spc);
+            if (spec) (ctx->lds_scene ? launch_spec_lds : launch_spec_stream)(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, dim3(spec_threads / 256u), block, traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + (size_t)kSpecColdWords * 256 * 4 + (256 / 16) * 32 + 64, st, ra, ds, stc, spc);
             else
             (ctx->lds_scene ? (fast_math ? launch_chain_lds_fast : launch_chain_lds) : (fast_math ? launch_chain_stream_fast : launch_chain_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, dim3((plan_chain.P + 255) / 256), block, lds_chain, st, ra, ds, stc_c);
             if (timing) hipEventRecord(ctx->events[1], st);

@@ -112,8 +112,8 @@ def run(budget=20.0, seed=0, verbose=True, fast=False):
             # renders are far too small for it to be chosen) with random lanes per block / per pixel, track capacities, window margins and lead-ins
             spec_env = {}
             if kw["stream_mode"] == api.STREAM_REFERENCE_ORDER and pipe != 1 and pool == 0 and rng.random() < 0.5:
-                g = int(rng.choice([16, 32, 64]))
-                spec_env = dict(RL_SPEC_FORCE="1", RL_SPEC_GROUP=str(g), RL_SPEC_SUB=str(int(rng.choice([s for s in (1, 2, 4, 8) if s <= g]))),
+                g = int(rng.choice([16, 32, 64, 256]))
+                spec_env = dict(RL_SPEC_FORCE="1", RL_SPEC_GROUP=str(g), RL_SPEC_SUB=str(int(rng.choice([s for s in (1, 2, 4, 8, 16) if s <= g]))), RL_SPEC_EXTRA=str(int(rng.integers(2))), RL_SPEC_PROBE_EVERY=str(int(rng.random() < 0.2)),
                                 RL_SPEC_CAP=str(int(rng.choice([4, 9, 40, 400]))), RL_SPEC_LEAD=str(int(rng.choice([0, 2, 24]))),
                                 RL_SPEC_KS=str(float(rng.choice([0.0, 1.65, 4.0]))), RL_SPEC_KE=str(float(rng.choice([0.0, 1.65, 4.0]))), RL_SPEC_PROBE=str(int(rng.choice([0, 3, 32]))))
                 if rng.random() < 0.2: spec_env["RL_SPEC_NO_TRIVIAL"] = "1"

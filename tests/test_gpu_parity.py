@@ -844,7 +844,8 @@ def test_reference_order_speculative_chain(built, monkeypatch):
              (scenes.many_lights(48, 48, n=5, use_ats=True), dict(spp=6, max_depth=4))]
     shapes = [dict(RL_SPEC_GROUP="16", RL_SPEC_SUB="1"), dict(RL_SPEC_GROUP="32", RL_SPEC_SUB="2"), dict(RL_SPEC_GROUP="64", RL_SPEC_SUB="4"), dict(RL_SPEC_GROUP="64", RL_SPEC_SUB="8"),
               dict(RL_SPEC_GROUP="32", RL_SPEC_SUB="1", RL_SPEC_CAP="5"), dict(RL_SPEC_GROUP="64", RL_SPEC_SUB="2", RL_SPEC_LEAD="0", RL_SPEC_KS="0", RL_SPEC_KE="0", RL_SPEC_PROBE="0"),
-              dict(RL_SPEC_GROUP="16", RL_SPEC_SUB="4", RL_SPEC_NO_TRIVIAL="1", RL_SPEC_KS="5", RL_SPEC_KE="5")]
+              dict(RL_SPEC_GROUP="16", RL_SPEC_SUB="4", RL_SPEC_NO_TRIVIAL="1", RL_SPEC_KS="5", RL_SPEC_KE="5"),
+              dict(RL_SPEC_GROUP="256", RL_SPEC_SUB="16"), dict(RL_SPEC_GROUP="256", RL_SPEC_SUB="1", RL_SPEC_EXTRA="1"), dict(RL_SPEC_GROUP="64", RL_SPEC_SUB="16", RL_SPEC_EXTRA="1", RL_SPEC_PROBE_EVERY="1")]   # 256: a whole workgroup per block (votes and sums through the barrier)
     keys = ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws")
     for n_case, (sd, kw) in enumerate(cases):
         ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
@@ -855,7 +856,7 @@ def test_reference_order_speculative_chain(built, monkeypatch):
         assert base[1]["spec_group"] == 0
         monkeypatch.delenv("RL_CHAIN_SERIAL")
         monkeypatch.setenv("RL_SPEC_FORCE", "1")
-        for env in (shapes if n_case < 2 else shapes[n_case % 3::3]):
+        for env in (shapes if n_case < 2 else shapes[n_case % 4::4]):
             for k, v in env.items(): monkeypatch.setenv(k, v)
             img, st = ctx.render(seeds, api.path_params(stream_mode=ref_mode, **kw))
             for k in env: monkeypatch.delenv(k)
@@ -997,6 +998,11 @@ def test_bench_two_ranks_on_one_gpu(built):
     assert out["n_gpus"] == 2 and out["distributed"]["world_size"] == 2 and len(out["distributed"]["ranks"]) == 2
     assert out["distributed"]["crc_match"] is True and out["config"]["spp_total"] == 8
     assert out["value"] > 0 and out["roofline"]["kernel"] == "k_path_fused"
+    # the same shards once more in rustlight's own reference-order streams (the drop-in default), per rank: chain pass, evaluation pass, reduce
+    ro = out["reference_order"]
+    assert out["reference_order_value"] == ro["value"] > 0 and len(ro["ranks"]) == 2
+    assert all(r["chain_ms"] > 0 and r["kernel_ms"] > 0 and r["reduce_ms"] >= 0 for r in ro["ranks"])
+    assert all("reduce_ms_per_step" in r for r in out["distributed"]["ranks"])
 
 
 def test_fast_numerics_tolerance_mode(built):
