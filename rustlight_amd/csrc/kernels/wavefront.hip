@@ -696,7 +696,10 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     }
     unsigned max_chunk_pix = 0;
     for (const Chunk& ch : chunks) max_chunk_pix = std::max(max_chunk_pix, ch.n_pix);
-    const Plan plan = two_pass ? plan_items(true, max_chunk_pix, 0) : plan_items(per_sample, n_pixels, (unsigned)owned.size());   // two-pass: the largest second pass
+    Plan plan = two_pass ? plan_items(true, max_chunk_pix, 0) : plan_items(per_sample, n_pixels, (unsigned)owned.size());   // two-pass: the largest second pass
+    // (a SMALLER chunk can ask for MORE lanes per pixel, hence more slots and statistics rows than the largest one: uneven chunks at 1080p — 131 + 125 cursors — lost
+    // 1 % of the counters and wrote past the rows; everything sized from `plan` below covers every chunk's own plan)
+    if (two_pass) for (const Chunk& ch : chunks) { const Plan pc = plan_items(true, ch.n_pix, 0); plan.P = std::max(plan.P, pc.P); plan.split = std::max(plan.split, pc.split); }
     const Plan plan_chain = two_pass ? plan_items(false, 0, (unsigned)owned.size()) : Plan{1u, 0u, 0u, 0u};
     const unsigned split = plan.split, n_items = plan.n_items, item_shift = plan.item_shift;
     const unsigned P = std::max(plan.P, plan_chain.P);

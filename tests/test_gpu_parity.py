@@ -805,6 +805,18 @@ def test_reference_order_two_pass_equals_single_pass(built, monkeypatch):
     # shards: the chains of a shard's blocks only
     parts = [ctx.render(api.IndependentSampler(1).block_seeds(160, 200), api.path_params(stream_mode=ref_mode, spp=24, shard_index=r, shard_count=3))[0] for r in range(3)]
     np.testing.assert_array_equal(parts[0] + parts[1] + parts[2], whole[0])
+    # two UNEVEN chunks (140 + 116 block cursors of a 1280 x 800 frame): the smaller chunk asks for more lanes per pixel (9 against 7), i.e. more slots and statistics rows than
+    # the larger one — the counters must not lose them (round 4: sized from the largest chunk only, 1 % of the draws of a 1080p render went missing)
+    sd = scenes.cbox(1280, 800)
+    ctx = api.Context(api.Scene(sd), 0)
+    seeds = api.IndependentSampler(2).block_seeds(1280, 800)
+    a, sa = ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=8))
+    monkeypatch.setenv("RL_STATE_BUDGET_MB", "143")
+    b, sb = ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=8))
+    monkeypatch.delenv("RL_STATE_BUDGET_MB")
+    assert sa["iterations"] == 1 and sb["iterations"] == 2
+    np.testing.assert_array_equal(a, b)
+    assert all(sa[k] == sb[k] for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws"))
 
 
 def test_rng_advance_equals_stepping(built):
