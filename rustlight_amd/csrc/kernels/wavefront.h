@@ -16,6 +16,8 @@ int rl_debug_numerics(int device, size_t n, const float* a, const float* b, floa
 int rl_debug_trace_batch_fast(rl_context* ctx, size_t n, const float* origins, const float* directions, float* t_out, int32_t* mesh_out, int32_t* tri_out, int32_t* steps_out);
 // rng_advance (kernels/rngjump.h) on the device: states_out[i] = sampler states_in[i] (4 x u64) after counts[i] more draws
 int rl_debug_rng_advance(int device, size_t n, const uint64_t* states_in, const uint32_t* counts, uint64_t* states_out);
+// host only: out[y * W + x] = 1 where every camera sample of the pixel takes exactly two draws (its rays cannot reach the scene's bounding box; k_stream_spec's shortcut)
+int rl_debug_trivial_pixels(const rl_scene* scene, int has_max_depth, uint32_t max_depth, uint8_t* out);
 int rl_debug_bvh_sizes(const rl_context* ctx, uint64_t* n_ref_nodes, uint64_t* n_prims, uint32_t* stack_depth, int* lds_scene);
 // host-only: builds the BVH of `scene` and returns it in the reference's node shape (no GPU needed)
 int rl_debug_bvh(const rl_scene* scene, uint64_t* n_nodes, uint64_t* n_prims, float* boxes, uint64_t* info, uint64_t* count,

@@ -487,8 +487,16 @@ static int stack_conf(rl_context* ctx, size_t n_threads, StackConf* out) {
 // corner rays; a box that lies wholly beyond ONE side plane of that cone touches none of them.  Evaluated in f64 on a footprint grown by a quarter
 // pixel and a box grown by 1e-3 of its size — orders of magnitude more than the f32 rounding of the device's ray generation and slab / triangle
 // tests — so a pixel flagged here cannot produce a hit on the device.  Bit c of words [8 b .. 8 b + 7]: block cursor c of owned block b.
-static void trivial_pixel_masks(const rl_context* ctx, const rl_path_params* params, const std::vector<unsigned>& owned, size_t nby, std::vector<unsigned>* out) {
-    const uint32_t W = ctx->width, H = ctx->height;
+struct TrivialInput { uint32_t W, H; bool medium, empty; float root_min[3], root_max[3]; CameraRecord camera; };
+static TrivialInput trivial_input(const rl_context* ctx) {
+    TrivialInput in{};
+    in.W = ctx->width; in.H = ctx->height; in.medium = ctx->ds.medium.enabled != 0; in.empty = ctx->ds.root == RL_CHILD_NONE || ctx->ds.n_prims == 0;
+    for (int k = 0; k < 3; k++) { in.root_min[k] = ctx->ds.root_min[k]; in.root_max[k] = ctx->ds.root_max[k]; }
+    in.camera = ctx->ds.camera;
+    return in;
+}
+static void trivial_pixel_masks(const TrivialInput& ti, const rl_path_params* params, const std::vector<unsigned>& owned, size_t nby, std::vector<unsigned>* out) {
+    const uint32_t W = ti.W, H = ti.H;
     out->assign(owned.size() * 8, 0u);
     const bool expand = !params->has_max_depth || 1u < params->max_depth;
     auto all_of_block = [&](size_t j, unsigned npx) { for (unsigned c = 0; c < npx; c++) (*out)[j * 8 + (c >> 5)] |= 1u << (c & 31u); };
@@ -499,18 +507,17 @@ static void trivial_pixel_masks(const rl_context* ctx, const rl_path_params* par
         }
         return;
     }
-    if (ctx->ds.medium.enabled || getenv("RL_SPEC_NO_TRIVIAL")) return;      // Edge::from_ray samples the medium on a miss too: no shortcut
-    const DeviceScene& ds = ctx->ds;
-    const bool empty = ds.root == RL_CHILD_NONE || ds.n_prims == 0;
+    if (ti.medium || getenv("RL_SPEC_NO_TRIVIAL")) return;      // Edge::from_ray samples the medium on a miss too: no shortcut
+    const bool empty = ti.empty;
     double lo[3], hi[3];
     for (int k = 0; k < 3; k++) {
-        lo[k] = ds.root_min[k]; hi[k] = ds.root_max[k];
+        lo[k] = ti.root_min[k]; hi[k] = ti.root_max[k];
         if (!empty && !(std::isfinite(lo[k]) && std::isfinite(hi[k]) && lo[k] <= hi[k])) return;      // hostile geometry: no shortcut
         const double grow = 1e-3 * (hi[k] - lo[k]) + 1e-4 * std::max(1.0, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
         lo[k] -= grow; hi[k] += grow;
     }
-    const float* m = ds.camera.sample_to_camera; const float* tw = ds.camera.to_world;
-    const double cam[3] = {ds.camera.position[0], ds.camera.position[1], ds.camera.position[2]};
+    const float* m = ti.camera.sample_to_camera; const float* tw = ti.camera.to_world;
+    const double cam[3] = {ti.camera.position[0], ti.camera.position[1], ti.camera.position[2]};
     // direction of the ray through raster position (u, v), not normalised; false when the projective map degenerates there
     auto ray_dir = [&](double u, double v, double* d) -> bool {
         const double sx = u / (double)W, sy = v / (double)H;
@@ -559,6 +566,33 @@ static void trivial_pixel_masks(const rl_context* ctx, const rl_path_params* par
             if (misses(x - 0.25, y - 0.25, x + 1.25, y + 1.25)) (*out)[j * 8 + (c >> 5)] |= 1u << (c & 31u);
         }
     }
+}
+
+// test hook, host only (no GPU): the pixels k_stream_spec would treat as taking two draws per sample — out[y * W + x] = 1 — for the scene's camera and the bounding box of
+// its BVH (built here as rl_context_create builds it).  tests/test_abi.py checks every flagged pixel against the oracle's camera rays and traversal.
+extern "C" int rl_debug_trivial_pixels(const rl_scene* scene, int has_max_depth, uint32_t max_depth, uint8_t* out) {
+    if (!scene || !out || !scene->has_camera) return RL_ERR_INVALID_ARGUMENT;
+    BvhBuild bvh;
+    build_bvh(*scene, &bvh);
+    TrivialInput ti{};
+    ti.W = scene->width; ti.H = scene->height; ti.medium = scene->medium.enabled != 0; ti.empty = bvh.root == RL_CHILD_NONE || bvh.tris.empty();
+    for (int k = 0; k < 3; k++) { ti.root_min[k] = bvh.root_min[k]; ti.root_max[k] = bvh.root_max[k]; }
+    scene->sample_to_camera.to_cols(ti.camera.sample_to_camera);
+    scene->to_world.to_cols(ti.camera.to_world);
+    ti.camera.position[0] = scene->cam_pos.x; ti.camera.position[1] = scene->cam_pos.y; ti.camera.position[2] = scene->cam_pos.z;
+    ti.camera.width = scene->width; ti.camera.height = scene->height;
+    rl_path_params pp{};
+    pp.has_max_depth = has_max_depth; pp.max_depth = max_depth;
+    const size_t nbx = (ti.W + 15) / 16, nby = (ti.H + 15) / 16;
+    std::vector<unsigned> owned(nbx * nby), masks;
+    for (size_t b = 0; b < owned.size(); b++) owned[b] = (unsigned)b;
+    trivial_pixel_masks(ti, &pp, owned, nby, &masks);
+    std::memset(out, 0, (size_t)ti.W * ti.H);
+    for (size_t b = 0; b < owned.size(); b++) {
+        const unsigned bx = (unsigned)(b / nby) * 16u, by = (unsigned)(b % nby) * 16u, bw = std::min(16u, ti.W - bx), bh = std::min(16u, ti.H - by);
+        for (unsigned c = 0; c < bw * bh; c++) if ((masks[b * 8 + (c >> 5)] >> (c & 31u)) & 1u) out[(size_t)(by + c / bw) * ti.W + bx + c % bw] = 1;
+    }
+    return RL_OK;
 }
 
 extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, const uint64_t* block_seeds, size_t n_blocks, float* out_rgb,
@@ -894,7 +928,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             const uint64_t key = ((uint64_t)params->shard_index << 33) | ((uint64_t)shard_count << 1) | (expand ? 1u : 0u);
             if (key != ctx->trivial_key || ctx->trivial_capacity < owned.size() * 8 || getenv("RL_SPEC_NO_TRIVIAL")) {
                 std::vector<unsigned> masks;
-                trivial_pixel_masks(ctx, params, owned, nby, &masks);
+                trivial_pixel_masks(trivial_input(ctx), params, owned, nby, &masks);
                 if ((rcode = ensure(&ctx->d_trivial, &ctx->trivial_capacity, masks.size())) != RL_OK) return rcode;
                 HIP_OK(hipMemcpyAsync(ctx->d_trivial, masks.data(), masks.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
                 HIP_OK(hipStreamSynchronize(st));        // (`masks` is a local)

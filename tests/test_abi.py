@@ -99,6 +99,46 @@ def test_host_bvh_and_camera_equal_oracle(built, maker):
     assert ps.counts()["emitters"] == os_.info()["emitters"]
 
 
+def test_pixels_flagged_as_two_draw_pixels_cannot_reach_the_scene(built):
+    """k_stream_spec's shortcut: a pixel whose camera rays cannot reach the scene's bounding box takes exactly two draws per sample (the jitter; without a medium a
+    missed camera ray ends its path, path.rs:152-166), so its sampler states are skip-aheads.  The host decides it conservatively (rl_debug_trivial_pixels: the same
+    function the render calls).  Here, host only: at 1920 x 1080 the flagged set is large (the reference's Fov::Y x aspect quirk) — and for every flagged pixel the
+    ORACLE's camera rays through its four corners, its centre and random jitters miss everything, while the pixels next to the flagged region's border that do hit
+    geometry are, of course, not flagged.  With a medium nothing is flagged; with max_depth <= 1 everything is."""
+    import ctypes as C
+    L = api.lib()
+    L.rl_debug_trivial_pixels.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
+    for sd in (scenes.cbox(1920, 1080), scenes.living_room(320, 180, n_spheres=8, tess=6), scenes.cbox(333, 77)):
+        ps, osc = api.Scene(sd), orc.Scene(sd)
+        flags = np.zeros((sd.height, sd.width), np.uint8)
+        assert L.rl_debug_trivial_pixels(ps.h, 0, 0, flags.ctypes.data) == 0
+        frac = flags.mean()
+        if sd.width == 1920: assert 0.35 < frac < 0.5, frac            # ~45 % of the 16:9 frame looks past the box
+        ys, xs = np.nonzero(flags)
+        rng = np.random.default_rng(3)
+        pick = rng.choice(len(ys), size=min(len(ys), 20000), replace=False) if len(ys) else np.zeros(0, int)
+        # the flagged pixels nearest to unflagged ones (the border of the region) are the critical ones: take all of them too
+        edge = np.zeros_like(flags, bool)
+        edge[:, 1:] |= (flags[:, 1:] == 1) & (flags[:, :-1] == 0); edge[:, :-1] |= (flags[:, :-1] == 1) & (flags[:, 1:] == 0)
+        edge[1:, :] |= (flags[1:, :] == 1) & (flags[:-1, :] == 0); edge[:-1, :] |= (flags[:-1, :] == 1) & (flags[1:, :] == 0)
+        ey, ex = np.nonzero(edge)
+        px = np.concatenate([xs[pick], ex]).astype(np.float64); py = np.concatenate([ys[pick], ey]).astype(np.float64)
+        o_all, d_all = [], []
+        for du, dv in ((0.0, 0.0), (0.999999, 0.0), (0.0, 0.999999), (0.999999, 0.999999), (0.5, 0.5), (float(rng.random()), float(rng.random()))):
+            for x, y in zip(px, py):
+                o, d = osc.camera_generate(float(x + du), float(y + dv))
+                o_all.append(o); d_all.append(d)
+        t, u, v, m, tr = osc.trace(np.array(o_all), np.array(d_all))
+        assert (m < 0).all(), f"{(m >= 0).sum()} camera rays of flagged pixels hit geometry"
+        # and the shortcut is not vacuous at the border: unflagged neighbours of flagged pixels mostly do see geometry within a few pixels
+        assert flags.sum() == 0 or len(ey) > 0
+    with_medium = api.Scene(scenes.cbox_medium(64, 36, 0.5))
+    f2 = np.zeros((36, 64), np.uint8)
+    assert L.rl_debug_trivial_pixels(with_medium.h, 0, 0, f2.ctypes.data) == 0 and f2.sum() == 0
+    f3 = np.zeros((36, 64), np.uint8)
+    assert L.rl_debug_trivial_pixels(api.Scene(scenes.cbox(64, 36)).h, 1, 1, f3.ctypes.data) == 0 and f3.all()
+
+
 def test_camera_from_matrices_is_the_same_camera(built):
     """rl_scene_set_camera_matrices / rl_scene_desc.has_camera_matrices (SURVEY 8(b) SceneDesc: `sample_to_camera[16], to_world[16]`): the camera handed over as
     the two matrices rustlight's Camera holds (camera.rs:5-15) generates the rays Camera::new's arguments give, bit for bit — through the builder call
