@@ -62,7 +62,8 @@ static constexpr size_t kSampleBufBudget = (size_t)16 << 30;   // bytes of HBM t
 // traversal stack configuration (see TravStack)
 struct StackConf { int lds_levels; int* overflow; size_t overflow_stride; int pre_group; };   // pre_group: k_stream_chain on tiny LDS scenes — lanes per chain that precompute its ray's records (0: off; trace.hip.h: precompute_records)
 
-static constexpr int kSpecColdWords = 33;      // k_stream_spec: words of per-thread state parked in LDS, + 4 u64 per group (host: LDS bytes of the launch)
+static constexpr int kSpecColdWords = 30;      // k_stream_spec: words of per-thread state parked in LDS, + 4 u64 + 16 words per group (host: LDS bytes of the launch)
+static constexpr size_t kSpecGroupLdsBytes = (256 / 16) * 32 + 64 + (256 / 16) * 64 + (256 / 16) * 16;      // per workgroup: the groups' anchors, the scan scratch, the groups' serial-walk heads, their counters
 // k_stream_spec (spec.hip.h): launch configuration and scratch of the speculative first pass of reference-order streams
 struct SpecConf {
     unsigned group;              // lanes per 16x16 block: 16, 32 or 64 (a batch = `group` consecutive pixels of the block, one per lane)
@@ -73,6 +74,8 @@ struct SpecConf {
     unsigned lead_max; float lead_var;   // pixels whose draws per sample vary less than lead_var get lead x lead_var / variance samples of it, at most lead_max
     unsigned extra;              // != 0: a pixel's last lane walks on past its window while other lanes of the group still walk (it would idle; fewer serial samples past the track's end)
     unsigned probe_every;        // != 0: every batch probes (a pixel keeps the length of the pixel a batch earlier unless the probe contradicts it)
+    unsigned dense; float dense_frac;    // serial walks of a pixel whose samples nearly all take the same number of draws c (at least dense_frac of its walked samples) are taken `dense` samples at a time: the group's idle
+                                 // lanes evaluate the samples that start c, 2c, ... draws on (0: off)
     float serial_ratio;          // a batch whose samples take more than spp / serial_ratio draws on average is walked serially (0: never)
     float ks, ke;                // window margins in standard deviations of the predicted start / end offset
     unsigned* trk_off;           // [thread][cap] stream offsets of the samples a lane walked, relative to the batch's anchor, ascending
@@ -129,6 +132,7 @@ enum : int { kStreamGivenStates = 2 };
 // their loops: the segment lays the arguments out like this struct (each at its natural alignment, in order); the kernels static_assert their
 // hand-computed offset against it, so a reordered or added argument fails to compile instead of reading garbage.
 struct PathKernargs { RenderConst rc; DeviceScene sc; StackConf stc; };
+struct SpecKernargs { RenderConst rc; DeviceScene sc; StackConf stc; SpecConf spec; };      // k_stream_spec
 
 // Path-state accessors.  The stage functions below are written once against `ps.f/u/q(field)`:
 //  * PoolState: the wavefront kernels — state lives in the HBM pool, one coalesced word per lane;

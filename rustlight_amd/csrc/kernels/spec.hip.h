@@ -28,17 +28,20 @@
 #pragma once
 #include "rngjump.h"
 
+// Waves per SIMD the register budget is set for.  What limits the kernel's occupancy is LDS (the lanes' parked state: 30 KB per workgroup, + stacks + scene:
+// three workgroups per CU on the Cornell box — which is what lets every heavy block of a 1080p frame start at once), so the budget is that of
+// three waves: 168 VGPRs, none spilled in any instantiation (at 128 the generic-material instantiations spilled 50-100).
 #ifndef RL_SPEC_WAVES
-#define RL_SPEC_WAVES 4
+#define RL_SPEC_WAVES 3
 #endif
 #ifndef RL_SPEC_WAVES_STREAMING
-#define RL_SPEC_WAVES_STREAMING 4
+#define RL_SPEC_WAVES_STREAMING 3
 #endif
 
 namespace rl {
 
 
-enum : unsigned { SM_IDLE = 0u, SM_PROBE, SM_WALK, SM_TRUTH, SM_EXTRA };      // SM_EXTRA: a pixel's last lane walking on past its window while the rest of the group still walks (free filler: it would idle)
+enum : unsigned { SM_IDLE = 0u, SM_PROBE, SM_WALK, SM_TRUTH, SM_EXTRA, SM_HELP };      // SM_EXTRA: a pixel's last lane walking on past its window while the rest of the group still walks (free filler: it would idle)
 enum : unsigned { SP_PROBE = 0u, SP_WALK, SP_RESOLVE, SP_DONE };
 
 RL_DEV Rng shfl_rng(const Rng& r, int src) {
@@ -48,8 +51,10 @@ RL_DEV Rng shfl_rng(const Rng& r, int src) {
 }
 
 template <int MAT, bool MEDIUM, bool LDS_SCENE, int NUM>
-__global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES_STREAMING) k_stream_spec(RenderConst rc_arg, DeviceScene sc_arg, StackConf stc, SpecConf spc) {
+__global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES_STREAMING) k_stream_spec(RenderConst rc_arg, DeviceScene sc_arg, StackConf stc, SpecConf spc_arg) {
     const DeviceScene& sc0 = sc_arg;
+    const SpecConf* spcp = &spc_arg;      // (inside the loop: re-read from the kernarg segment like rc and sc, so that none of its fields is kept in a register across the traversal)
+#define spc (*spcp)
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneRecs recs;
     float4* after_scene = smem;
@@ -103,8 +108,8 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
     // Fields of the second row are the pixel's: only its leader's copy is used (the owner of a pixel reads and writes the other lanes' rows).
     unsigned* const coldbase = reinterpret_cast<unsigned*>(after_scene) + 2 * 256 * stc.lds_levels;
     unsigned* const cold = coldbase + threadIdx.x;
-    enum { K_CUR_OFF, K_M, K_STOP, K_NB_LO, K_CNT, K_SUM_N, K_SUM_N2, K_LINK_I, K_LINK_J, K_CP_I0, K_CP_J0, K_CP_K0, K_PIX, K_C, K_Q0, K_ST_SPEC,
-           K_EST_L, K_EST_V, K_RES_I, K_RES_J, K_RES_K, K_START_OFF, K_RES_OFF, K_RES_ST, K_ST_SLOW = K_RES_ST + 8, K_ST_PROBE, K_COLD_COUNT };
+    enum { K_CUR_OFF, K_M, K_STOP, K_NB_LO, K_CNT, K_SUM_N, K_SUM_N2, K_LINK_I, K_LINK_J, K_CP_I0, K_CP_J0, K_CP_K0, K_Q0,
+           K_EST_L, K_EST_V, K_RES_I, K_RES_J, K_RES_K, K_RES_OFF, K_RES_ST, K_NMIN = K_RES_ST + 8, K_DN, K_DR, K_COLD_COUNT };
     static_assert(K_COLD_COUNT == kSpecColdWords, "LDS budget of k_stream_spec (host: wavefront.hip)");
 #define COLD(k) cold[(k) * 256]
 #define COLD_OF(t, k) coldbase[(k) * 256 + (t)]
@@ -115,14 +120,13 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
     unsigned& cnt = COLD(K_CNT); unsigned& sum_n = COLD(K_SUM_N); float& sum_n2 = reinterpret_cast<float&>(COLD(K_SUM_N2));     // draw statistics of this lane's walk
     unsigned& link_i = COLD(K_LINK_I); unsigned& link_j = COLD(K_LINK_J);     // entry link_i of this track = entry link_j of the next lane's (0xffffffff: no link)
     unsigned& cp_i0 = COLD(K_CP_I0); unsigned& cp_j0 = COLD(K_CP_J0); unsigned& cp_k0 = COLD(K_CP_K0);        // samples cp_i0 .. cp_i0 + cp_k0 - 1 of the pixel are this track's entries cp_j0 ..
-    unsigned& pix = COLD(K_PIX); unsigned& c = COLD(K_C);      // this lane's pixel in the batch: index into sample_states, block cursor
-    unsigned& q0 = COLD(K_Q0);                    // first block cursor of the current batch (group-uniform)
-    unsigned& st_spec = COLD(K_ST_SPEC);
+    unsigned& q0 = COLD(K_Q0);                    // first block cursor of the current batch (group-uniform); this lane's pixel is block cursor q0 + pl
+#define pix (pix_base + (q0 + pl - c_begin))      /* its index into sample_states */
     float& estL = reinterpret_cast<float&>(COLD(K_EST_L)); float& estV = reinterpret_cast<float&>(COLD(K_EST_V));   // leader: predicted length of the pixel in draws, its variance
     unsigned& res_i = COLD(K_RES_I); unsigned& res_j = COLD(K_RES_J); unsigned& res_k = COLD(K_RES_K);      // leader, slow walk: truth samples done, the sub-track ahead (segment, entry)
-    unsigned& start_off = COLD(K_START_OFF);      // leader: true start offset of the pixel
     unsigned& res_off = COLD(K_RES_OFF);          // leader: where the chain stands after the pixel (offset; the state: K_RES_ST, 8 words)
-    unsigned& st_slow = COLD(K_ST_SLOW); unsigned& st_probe = COLD(K_ST_PROBE);
+    unsigned& nmin_cnt = COLD(K_NMIN);            // fewest draws a sample of this lane's walk took (<< 16) | how many of its samples took exactly that
+    // K_DN / K_DR: helper of a serial walk (below): draws of the sample it evaluated (0: not yet), the round it belongs to; its sampler after the sample: the lane's K_RES_ST
     for (int k = 0; k < K_COLD_COUNT; k++) COLD(k) = 0u;
     q0 = c_begin;
     // the block sampler where the batch begins: one copy per group, after the per-thread planes
@@ -133,6 +137,29 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
     // group-wide votes and sums: within a wave by ballot / shuffles; a group that spans the workgroup (G = 256) through the barrier (every thread of the
     // workgroup then belongs to the one group, so every call site is reached by all of them together)
     float* const gscratch = reinterpret_cast<float*>(coldbase + K_COLD_COUNT * 256 + 8 * (256 / 16));
+    // ---- a serial walk taken several samples at a time (HELPERS).  Where the chain leaves the tracks inside a pixel whose samples nearly all take the same number of draws c,
+    // two walks of the pixel stay apart for long (they sit on different residues of c) and the serial walk is most of the pixel.  But then the chain's next positions are
+    // predictable: from the head at offset b they are b + c, b + 2c, ... until a sample takes another count.  The group's lanes — idle while a pixel is threaded — evaluate
+    // the samples that start there (lane h: state stepped h c draws on), and the pixel's leader consumes them in order for as long as the chain really stands on them:
+    // sample h is on the chain iff samples 0 .. h-1 all took c draws; its state is then the sampler lane h-1 was left with.  The first sample that takes another count ends
+    // the round; the next one starts from where it leaves the chain.  Nothing is used unless the chain provably stands on it.
+    const unsigned gshift = 31u - (unsigned)__builtin_clz(G);
+    // the group's head, 16 words: [0..7] sampler at the head, [8] its offset, [9] c, [10] round, [11] active, [12] the leader's lane in the group, [13] its pixel
+    // (addresses recomputed at every use: held in registers across the loop they push the traversal into scratch)
+#define ghead (reinterpret_cast<unsigned*>(gscratch + 16) + 16u * (threadIdx.x >> gshift))
+    enum { GH_B = 8, GH_C, GH_ROUND, GH_ACTIVE, GH_LGL, GH_PXY };
+    if (gl < 16u) ghead[gl] = 0u;
+    // the group's counters: samples walked, serial, probed
+#define gstat (reinterpret_cast<unsigned*>(gscratch + 16) + 16u * (256u / 16u) + 4u * (threadIdx.x >> gshift))
+    if (gl < 4u) gstat[gl] = 0u;
+#define st_spec_inc atomicAdd(&gstat[0], 1u)
+#define st_slow_inc atomicAdd(&gstat[1], 1u)
+#define st_probe_inc atomicAdd(&gstat[2], 1u)
+#ifdef RL_PROBE_NO_DENSE
+    const unsigned H = 0u;
+#else
+    const unsigned H = (G <= 64u && spc.dense > 1u) ? min(spc.dense, G) : 0u;
+#endif
     auto group_any = [&](bool p) -> bool { return G <= 64u ? (__ballot(p) & gmask) != 0ull : __syncthreads_or((int)p) != 0; };
     auto group_scan2 = [&](float& a, float& b) {      // inclusive prefix sums over the lanes of the group
         const unsigned w = G <= 64u ? G : 64u, li = G <= 64u ? gl : lane;
@@ -175,7 +202,14 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
     };
     unsigned mode = SM_IDLE;
     unsigned pxy = 0;                             // image position of this lane's pixel, x | y << 16
-    bool valid = false, triv = false, resolved = false, copied = false, have_est = false, planned = false, linked = false;
+    // the lane's flags, one register (as separate bools each is a lane mask in a pair of SGPRs, and the kernel is short of those too)
+    unsigned bits = 0u;
+    struct Bit {
+        unsigned& w; const unsigned m;
+        RL_DEV operator bool() const { return (w & m) != 0u; }
+        RL_DEV void operator=(bool b) { w = b ? (w | m) : (w & ~m); }
+    };
+    Bit valid{bits, 1u}, triv{bits, 2u}, resolved{bits, 4u}, copied{bits, 8u}, have_est{bits, 16u}, planned{bits, 32u}, linked{bits, 64u};
     unsigned nd = 0;                              // draws the sample being walked has taken so far
     unsigned own = 0;                             // resolve: the pixel slot the chain stands in (group-uniform)
     unsigned dummy = 0;
@@ -198,12 +232,14 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
         constexpr size_t sc_off = (sizeof(RenderConst) + alignof(DeviceScene) - 1) / alignof(DeviceScene) * alignof(DeviceScene); \
         static_assert(sc_off == offsetof(PathKernargs, sc), "kernarg layout of k_stream_spec"); \
         const DeviceScene& sc = *(const DeviceScene*)(ka + sc_off); \
+        static_assert(offsetof(SpecKernargs, sc) == offsetof(PathKernargs, sc), "kernarg layout of k_stream_spec"); \
+        spcp = (const SpecConf*)(ka + offsetof(SpecKernargs, spec)); \
         const RenderConst& rc = *(const RenderConst*)ka;
 
     // Path::from_sensor + Camera::generate for the sample that starts at `rng` (raygen_chain_slot without the cursor logic)
-    auto begin_sample = [&](const RenderConst& rc, const DeviceScene& sc, Rng rng) {
-        const float u = (float)(pxy & 0xffffu) + rng_next_f32(rng);
-        const float v = (float)(pxy >> 16) + rng_next_f32(rng);
+    auto begin_sample_at = [&](const RenderConst& rc, const DeviceScene& sc, Rng rng, unsigned pxy_) {
+        const float u = (float)(pxy_ & 0xffffu) + rng_next_f32(rng);
+        const float v = (float)(pxy_ >> 16) + rng_next_f32(rng);
         nd = 2u;
         const bool expand = (!rc.has_max || 1u < rc.max_depth);
         if (!expand) { store_rng(ps, Q_R0, rng); PU(U_FLAGS) = ST_REGEN; return; }
@@ -213,19 +249,42 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
         PU(U_DEPTH) = 1u;
         PU(U_FLAGS) = ST_RAY | (PREV_SENSOR << ST_PREV_SHIFT) | ST_PDF_SA;
     };
+    auto begin_sample = [&](const RenderConst& rc, const DeviceScene& sc, const Rng& rng) { begin_sample_at(rc, sc, rng, pxy); };
+    // (leader) a round of helpers from the chain's head (off, st)
+    auto dense_round = [&](unsigned off, const Rng& st) {
+        ghead[0] = (unsigned)st.s0; ghead[1] = (unsigned)(st.s0 >> 32); ghead[2] = (unsigned)st.s1; ghead[3] = (unsigned)(st.s1 >> 32);
+        ghead[4] = (unsigned)st.s2; ghead[5] = (unsigned)(st.s2 >> 32); ghead[6] = (unsigned)st.s3; ghead[7] = (unsigned)(st.s3 >> 32);
+#ifdef RL_SPEC_TIMERS
+        if (spc.stats) atomicAdd(&spc.stats[24], 1ull);
+#endif
+        ghead[GH_B] = off; ghead[GH_ROUND] = ghead[GH_ROUND] + 1u; ghead[GH_ACTIVE] = 1u; ghead[GH_LGL] = gl; ghead[GH_PXY] = pxy;
+    };
     // (leader) the chain has reached the end of this lane's pixel
     auto finish_pixel = [&](unsigned off, const Rng& st) {
         res_off = off; store_res_st(st);
         resolved = true; mode = SM_IDLE;
         PU(U_FLAGS) = 0u;
-        estL = (float)(off - start_off);
+        estL = (float)(off - (pl == 0u ? 0u : COLD_OF(threadIdx.x - S, K_RES_OFF)));      // (the pixel began where its predecessor ended)
         if (cnt >= 8u) { const float m = (float)sum_n / (float)cnt; estV = fmaxf(sum_n2 / (float)cnt - m * m, 0.0f) * (float)spp; }
         have_est = true;
     };
     // (leader) the pixel's chain leaves the tracks at (off, st) with i samples done: walk on, one lane, towards entry j of segment k's track
     auto slow_walk = [&](const RenderConst& rc, const DeviceScene& sc, unsigned off, const Rng& st, unsigned i, unsigned k, unsigned j) {
-        res_i = i; res_k = k; res_j = j; cur_off = off; mode = SM_TRUTH;
+        res_i = i; res_k = k; res_j = j; cur_off = off;
         store_sample_state(rc, i, pix, st);
+        if (H && cnt >= (spc.dense_frac > 0.0f ? 8u : 1u) && (float)(nmin_cnt & 0xffffu) >= spc.dense_frac * (float)cnt) {      // (dense_frac = 0, tests: every serial walk that has a draw count to go by)      // several samples at a time (the lanes start in section D2)
+#ifdef RL_SPEC_TIMERS
+            if (spc.stats) atomicAdd(&spc.stats[26], 1ull);
+#endif
+            mode = SM_IDLE; PU(U_FLAGS) = 0u;
+            ghead[GH_C] = nmin_cnt >> 16;
+            dense_round(off, st);
+            return;
+        }
+#ifdef RL_SPEC_TIMERS
+        if (spc.stats) atomicAdd(&spc.stats[27], 1ull);
+#endif
+        mode = SM_TRUTH;
         begin_sample(rc, sc, st);
     };
     // (leader) the chain stands on entry j of segment k's track with i samples of the pixel done: that track is the chain up to its link into the next
@@ -266,11 +325,15 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
                 const bool fresh = (flags & ST_FRESH) != 0u;
                 const Rng rng = load_rng(ps, Q_R0);            // the sampler after the sample (or where the walk starts)
                 if (mode == SM_PROBE) {
-                    if (!fresh) { cnt++; sum_n += nd; sum_n2 += (float)nd * (float)nd; st_probe++; }
+                    if (!fresh) { cnt++; sum_n += nd; sum_n2 += (float)nd * (float)nd; st_probe_inc; }
                     if (cnt >= spc.probe) { mode = SM_IDLE; PU(U_FLAGS) = 0u; }
                     else begin_sample(rc, sc, rng);
                 } else if (mode == SM_WALK || mode == SM_EXTRA) {
-                    if (!fresh) { cnt++; sum_n += nd; sum_n2 += (float)nd * (float)nd; cur_off += nd; st_spec++; }
+                    if (!fresh) {
+                        cnt++; sum_n += nd; sum_n2 += (float)nd * (float)nd; cur_off += nd; st_spec_inc;
+                        const unsigned nm = nmin_cnt >> 16, ndc = min(nd, 0xffffu);
+                        if (ndc < nm) nmin_cnt = (ndc << 16) | 1u; else if (ndc == nm && (nmin_cnt & 0xffffu) != 0xffffu) nmin_cnt++;
+                    }
                     my_off[M] = cur_off;
                     my_st[2u * M] = make_ulonglong2(rng.s0, rng.s1); my_st[2u * M + 1u] = make_ulonglong2(rng.s2, rng.s3);
                     // past its own segment the lane walks on until it stands on an entry of the next lane's walk (same pixel): from there the two are one walk.
@@ -287,8 +350,12 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
                     if (mode == SM_WALK && !met && cur_off >= stop && sk + 1u == S && M + 1u < spc.cap && spc.extra) mode = SM_EXTRA;      // the window is covered: walk on while others still walk
                     if (met || M + 1u >= spc.cap || (mode == SM_WALK && cur_off >= stop)) { mode = SM_IDLE; PU(U_FLAGS) = 0u; }      // entry M is the frontier
                     else { M++; begin_sample(rc, sc, rng); }
+                } else if (mode == SM_HELP) {      // a helper's sample is done: its draw count and the sampler after it, for the leader to pick up
+                    store_res_st(rng);
+                    COLD(K_DN) = nd; st_spec_inc;
+                    mode = SM_IDLE; PU(U_FLAGS) = 0u;
                 } else {   // SM_TRUTH: the pixel's leader walks where no track carries the chain
-                    res_i++; cur_off += nd; st_slow++;
+                    res_i++; cur_off += nd; st_slow_inc;
                     // the first entry at or beyond the chain in the tracks ahead (segment res_k, then the next ones)
                     for (;;) {
                         if (res_k >= S) break;
@@ -302,6 +369,34 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
                     else if (res_k < S && OFF_OF(lt + res_k)[res_j] == cur_off) { follow(rc, sc, res_i, res_k, res_j); fin_now = resolved; }
                     else { store_sample_state(rc, res_i, pix, rng); begin_sample(rc, sc, rng); }
                 }
+            }
+        }
+        if (H && ghead[GH_ACTIVE] && ghead[GH_LGL] == gl) {
+            // ---- A2. (leader) take the helpers' samples in chain order for as long as the chain stands on them
+            const unsigned hb = ghead[GH_B], hc = ghead[GH_C], hr = ghead[GH_ROUND], gbase = threadIdx.x - gl;
+            for (;;) {
+                const unsigned d = cur_off - hb, h = d / hc;
+                const unsigned t = gbase + ((gl + h) & (G - 1u));
+                const unsigned n = COLD_OF(t, K_DN);
+                if (n == 0u) break;            // (lane h is on the chain — the loop only comes here for such a lane — and still tracing)
+                const Rng e = load_res_st(t);
+#ifdef RL_SPEC_TIMERS
+                if (spc.stats) atomicAdd(&spc.stats[25], 1ull);
+#endif
+                res_i++; cur_off += n; st_slow_inc;
+                for (;;) {
+                    if (res_k >= S) break;
+                    const unsigned tk = lt + res_k, Mk = COLD_OF(tk, K_M);
+                    const unsigned* offs = OFF_OF(tk);
+                    while (res_j <= Mk && offs[res_j] < cur_off) res_j++;
+                    if (res_j <= Mk) break;
+                    res_k++; res_j = 0u;
+                }
+                if (res_i == spp) { ghead[GH_ACTIVE] = 0u; finish_pixel(cur_off, e); fin_now = true; break; }
+                if (res_k < S && OFF_OF(lt + res_k)[res_j] == cur_off) { ghead[GH_ACTIVE] = 0u; follow(rc, sc, res_i, res_k, res_j); fin_now = resolved; break; }
+                store_sample_state(rc, res_i, pix, e);
+                const unsigned d2 = cur_off - hb, h2 = d2 / hc;
+                if (h2 * hc != d2 || h2 >= H || COLD_OF(gbase + ((gl + h2) & (G - 1u)), K_DR) != hr) { dense_round(cur_off, e); break; }       // off the lanes' offsets: the next round starts here
             }
         }
         if (group_any(fin_now)) own++;
@@ -318,13 +413,12 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
             if (!planned) {
                 // a new batch: this lane's pixel
                 planned = true;
-                c = q0 + pl;
+                const unsigned c = q0 + pl;
                 valid = c < c_end;
                 pxy = (bx + c % bw) | ((by + c / bw) << 16);
-                pix = pix_base + (c - c_begin);
                 triv = valid && ((triv_bits[(c >> 5) & 7u] >> (c & 31u)) & 1u) != 0u;
                 resolved = false; copied = false; linked = false; cp_k0 = 0u; M = 0u; link_i = 0xffffffffu;
-                cnt = 0u; sum_n = 0u; sum_n2 = 0.0f;
+                cnt = 0u; sum_n = 0u; sum_n2 = 0.0f; nmin_cnt = 0xffff0000u;
                 if (sk == 0u && valid && !triv && (!have_est || spc.probe_every) && spc.probe > 0u) {
                     // nothing to predict this pixel's length from: a short walk somewhere in the stream nobody else probes
                     Rng r = load_anc(); rng_advance(r, (pl << 10) + 512u);
@@ -348,7 +442,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
                 if (!have_est || dl * dl > 9.0f * (pV + estV)) { estL = pL; estV = pV; }
                 have_est = true;
             }
-            cnt = 0u; sum_n = 0u; sum_n2 = 0.0f;
+            cnt = 0u; sum_n = 0u; sum_n2 = 0.0f; nmin_cnt = 0xffff0000u;
             const float eL = reinterpret_cast<const float&>(COLD_OF(lt, K_EST_L)), eV = reinterpret_cast<const float&>(COLD_OF(lt, K_EST_V));      // the pixel's (its leader's)
             const float Lp = valid ? (triv ? 2.0f * (float)spp : eL) : 0.0f;
             const float Vp = (valid && !triv) ? 2.0f * eV : 0.0f;        // the length it is predicted from is itself one draw of the same spread
@@ -439,12 +533,11 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
         if (__ballot(phase == SP_RESOLVE && own < NP) != 0ull) {
             for (;;) {
                 bool fin = false;
-                if (phase == SP_RESOLVE && own < NP && sk == 0u && pl == own && mode == SM_IDLE && !resolved) {
+                if (phase == SP_RESOLVE && own < NP && sk == 0u && pl == own && mode == SM_IDLE && !resolved && !(H && ghead[GH_ACTIVE])) {
                     // where the chain stands: after the predecessor's pixel (its leader's parked res_off / res_st), or at the anchor
                     unsigned b_off = 0u; Rng b_st;
                     if (own == 0u) b_st = load_anc();
                     else { b_off = COLD_OF(threadIdx.x - S, K_RES_OFF); b_st = load_res_st(threadIdx.x - S); }
-                    start_off = b_off;
                     if (!valid) { res_off = b_off; store_res_st(b_st); resolved = true; copied = true; fin = true; }       // past the block's end: hand the chain on
                     else if (triv) {
                         my_st[0] = make_ulonglong2(b_st.s0, b_st.s1); my_st[1] = make_ulonglong2(b_st.s2, b_st.s3);      // the copy-out steps through the pixel from here
@@ -511,6 +604,23 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
                 } else phase = SP_PROBE;
             }
         }
+        // ---- D2. helpers of a serial walk: lanes of a group whose leader runs one start on the round's sample h (h c draws on from its head); a round that is over stops them
+        if (H) {
+            const unsigned act = ghead[GH_ACTIVE], hr = ghead[GH_ROUND];
+            if (mode == SM_HELP && (!act || COLD(K_DR) != hr)) { mode = SM_IDLE; PU(U_FLAGS) = 0u; }
+            if (act && mode == SM_IDLE && COLD(K_DR) != hr) {
+                const unsigned h = (gl - ghead[GH_LGL]) & (G - 1u);
+                if (h < H) {
+                    Rng r;
+                    r.s0 = (unsigned long long)ghead[0] | ((unsigned long long)ghead[1] << 32); r.s1 = (unsigned long long)ghead[2] | ((unsigned long long)ghead[3] << 32);
+                    r.s2 = (unsigned long long)ghead[4] | ((unsigned long long)ghead[5] << 32); r.s3 = (unsigned long long)ghead[6] | ((unsigned long long)ghead[7] << 32);
+                    for (unsigned k = h * ghead[GH_C]; k > 0u; k--) rng_next_u64(r);
+                    COLD(K_DR) = hr; COLD(K_DN) = 0u;
+                    mode = SM_HELP;
+                    begin_sample_at(rc, sc, r, ghead[GH_PXY]);
+                }
+            }
+        }
         RL_ST1(3)
         if (__ballot(phase != SP_DONE) == 0ull) break;
 
@@ -529,15 +639,24 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
     }
 #undef RL_SPEC_KERNARGS
 #ifdef RL_SPEC_TIMERS
-    if (spc.stats && lane == 0u) { { unsigned long long* w = spc.stats + 32 + 8 * (tid >> 6); w[0] = wave_t0; w[1] = wall_clock64(); w[2] = n_full; w[3] = n_serial; w[4] = cyc_full; w[5] = cyc_serial; w[6] = n_idle; w[7] = st_slow; }
+    if (spc.stats && lane == 0u) { { unsigned long long* w = spc.stats + 32 + 8 * (tid >> 6); w[0] = wave_t0; w[1] = wall_clock64(); w[2] = n_full; w[3] = n_serial; w[4] = cyc_full; w[5] = cyc_serial; w[6] = n_idle; w[7] = gstat[1]; }
         for (int k = 0; k < 5; k++) { atomicAdd(&spc.stats[4 + k], tmr[k]); atomicAdd(&spc.stats[16 + k], tms[k]); } atomicAdd(&spc.stats[9], e_lanes); atomicAdd(&spc.stats[10], e_iters); atomicAdd(&spc.stats[11], e_slow_iters); }
 #endif
     if (spc.stats) {
-        unsigned a = st_spec, b = st_slow, p = st_probe;
-        for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); p += __shfl_down(p, off, 64); }
-        if (lane == 0u) { atomicAdd(&spc.stats[0], (unsigned long long)a); atomicAdd(&spc.stats[1], (unsigned long long)b); atomicAdd(&spc.stats[2], (unsigned long long)p); atomicAdd(&spc.stats[3], (unsigned long long)st_iter); }
+        if (G > 64u) __syncthreads();
+        if (gl == 0u) { atomicAdd(&spc.stats[0], (unsigned long long)gstat[0]); atomicAdd(&spc.stats[1], (unsigned long long)gstat[1]); atomicAdd(&spc.stats[2], (unsigned long long)gstat[2]); }
+        unsigned it = st_iter;
+        for (int off = 32; off > 0; off >>= 1) it += __shfl_down(it, off, 64);
+        if (lane == 0u) atomicAdd(&spc.stats[3], (unsigned long long)it);
     }
 #undef my_off
+#undef spc
+#undef pix
+#undef ghead
+#undef gstat
+#undef st_spec_inc
+#undef st_slow_inc
+#undef st_probe_inc
 #undef my_st
 #undef OFF_OF
 #undef ST_OF

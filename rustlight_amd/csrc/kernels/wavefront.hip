@@ -907,6 +907,8 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             spc.lead_max = getenv("RL_SPEC_LEAD_MAX") ? (unsigned)atoi(getenv("RL_SPEC_LEAD_MAX")) : 128u;
             spc.lead_var = getenv("RL_SPEC_LEAD_VAR") ? (float)atof(getenv("RL_SPEC_LEAD_VAR")) : 100.0f;      // (cbox 1080p x 128 spp: 265.5 -> 260.2 ms; probing every batch: 319.6 ms)
             spc.extra = getenv("RL_SPEC_EXTRA") ? (unsigned)atoi(getenv("RL_SPEC_EXTRA")) : 0u;      // (cbox 1080p x 128 spp: 2.84 M instead of 3.57 M serial samples, 383 M instead of 306 M walked: 261 vs 259 ms — a wash, off)
+            spc.dense = getenv("RL_SPEC_DENSE") ? std::min(64u, (unsigned)atoi(getenv("RL_SPEC_DENSE"))) : 16u;
+            spc.dense_frac = getenv("RL_SPEC_DENSE_FRAC") ? (float)atof(getenv("RL_SPEC_DENSE_FRAC")) : 0.6f;
             spc.probe_every = getenv("RL_SPEC_PROBE_EVERY") ? (unsigned)atoi(getenv("RL_SPEC_PROBE_EVERY")) : 0u;
             // window margins in standard deviations of the predicted offsets: with one block per wave a pixel the chain has to be walked through stalls the whole wave, so wider
             // (shard 0 of 8, 1024 spp: 1.65 / 2.5 sigma = 714 / 688 ms; full frame, two blocks per wave: 281 / 292)
@@ -951,7 +953,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             ra.n_state_pixels = ch.n_pix; ra.cursor_begin = ch.c0; ra.cursor_end = ch.c1;
             hipLaunchKernelGGL(k_chunk_pixels, dim3(((unsigned)owned.size() + 63) / 64), dim3(64), 0, st, ra);
             if (timing) hipEventRecord(ctx->events[0], st);
-            if (spec) (ctx->lds_scene ? launch_spec_lds : launch_spec_stream)(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, dim3(spec_threads / 256u), block, traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + (size_t)kSpecColdWords * 256 * 4 + (256 / 16) * 32 + 64, st, ra, ds, stc, spc);
+            if (spec) (ctx->lds_scene ? launch_spec_lds : launch_spec_stream)(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, dim3(spec_threads / 256u), block, traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + (size_t)kSpecColdWords * 256 * 4 + kSpecGroupLdsBytes, st, ra, ds, stc, spc);
             else
             (ctx->lds_scene ? (fast_math ? launch_chain_lds_fast : launch_chain_lds) : (fast_math ? launch_chain_stream_fast : launch_chain_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, dim3((plan_chain.P + 255) / 256), block, lds_chain, st, ra, ds, stc_c);
             if (timing) hipEventRecord(ctx->events[1], st);
@@ -982,6 +984,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         if (spec && spc.stats) {
             HIP_OK(hipMemcpy(spec_totals, ctx->d_spec_stats, sizeof(spec_totals), hipMemcpyDeviceToHost));
             spec_group = spc.group; spec_stat[0] = spec_totals[0]; spec_stat[1] = spec_totals[1]; spec_stat[2] = spec_totals[2];
+            if (getenv("RL_SPEC_STATS")) std::fprintf(stderr, "[spec] LDS per workgroup %zu bytes (scene %zu, %d stack levels)\n", traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + (size_t)kSpecColdWords * 256 * 4 + kSpecGroupLdsBytes, (size_t)(ctx->lds_scene ? ctx->scene_lds_bytes : 0), lds_levels_of(ctx));
             if (getenv("RL_SPEC_STATS")) std::fprintf(stderr, "[spec] group %u x sub %u cap %u: %llu speculative + %llu serial + %llu probe samples for %llu camera samples (%.2f x, %.2f serial per pixel), %llu wave iterations\n",
                 spc.group, spc.sub, spc.cap, spec_totals[0], spec_totals[1], spec_totals[2], (unsigned long long)n_pixels * params->spp,
                 (double)(spec_totals[0] + spec_totals[1] + spec_totals[2]) / std::max(1.0, (double)n_pixels * params->spp), (double)spec_totals[1] / std::max(1u, n_pixels), spec_totals[3]);
@@ -1001,6 +1004,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
                   std::fprintf(stderr, "[spec] iterations after a serial-only one (%.1f %% of all cycles): bookkeeping %.1f %%, plan %.1f %%, thread %.1f %%, copy-out %.1f %%, extend+shade %.1f %%\n", 100.0 * ts / tot,
                     100.0 * spec_totals[16] / ts, 100.0 * spec_totals[17] / ts, 100.0 * spec_totals[18] / ts, 100.0 * spec_totals[19] / ts, 100.0 * spec_totals[20] / ts); }
                 std::fprintf(stderr, "[spec] slow walks: %llu from a pixel's start, %llu across a missing link, %llu past the last track\n", spec_totals[12], spec_totals[13], spec_totals[14]);
+                std::fprintf(stderr, "[spec] serial walks on helpers: %llu (one lane: %llu), %llu rounds, %llu samples taken from them\n", spec_totals[26], spec_totals[27], spec_totals[24], spec_totals[25]);
             }
         }
         iterations = chunks.size();

@@ -115,7 +115,8 @@ def run(budget=20.0, seed=0, verbose=True, fast=False):
                 g = int(rng.choice([16, 32, 64, 256]))
                 spec_env = dict(RL_SPEC_FORCE="1", RL_SPEC_GROUP=str(g), RL_SPEC_SUB=str(int(rng.choice([s for s in (1, 2, 4, 8, 16) if s <= g]))), RL_SPEC_EXTRA=str(int(rng.integers(2))), RL_SPEC_PROBE_EVERY=str(int(rng.random() < 0.2)),
                                 RL_SPEC_CAP=str(int(rng.choice([4, 9, 40, 400]))), RL_SPEC_LEAD=str(int(rng.choice([0, 2, 24]))),
-                                RL_SPEC_KS=str(float(rng.choice([0.0, 1.65, 4.0]))), RL_SPEC_KE=str(float(rng.choice([0.0, 1.65, 4.0]))), RL_SPEC_PROBE=str(int(rng.choice([0, 3, 32]))))
+                                RL_SPEC_KS=str(float(rng.choice([0.0, 1.65, 4.0]))), RL_SPEC_KE=str(float(rng.choice([0.0, 1.65, 4.0]))), RL_SPEC_PROBE=str(int(rng.choice([0, 3, 32]))),
+                                RL_SPEC_DENSE=str(int(rng.choice([0, 2, 5, 16, 64]))), RL_SPEC_DENSE_FRAC=str(float(rng.choice([0.0, 0.3, 0.6, 0.9]))))      # (serial walks on the group's idle lanes)
                 if rng.random() < 0.2: spec_env["RL_SPEC_NO_TRIVIAL"] = "1"
                 if rng.random() < 0.2: spec_env["RL_STATE_BUDGET_MB"] = "1"
             os.environ.update(spec_env)

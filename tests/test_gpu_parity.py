@@ -857,7 +857,9 @@ def test_reference_order_speculative_chain(built, monkeypatch):
     shapes = [dict(RL_SPEC_GROUP="16", RL_SPEC_SUB="1"), dict(RL_SPEC_GROUP="32", RL_SPEC_SUB="2"), dict(RL_SPEC_GROUP="64", RL_SPEC_SUB="4"), dict(RL_SPEC_GROUP="64", RL_SPEC_SUB="8"),
               dict(RL_SPEC_GROUP="32", RL_SPEC_SUB="1", RL_SPEC_CAP="5"), dict(RL_SPEC_GROUP="64", RL_SPEC_SUB="2", RL_SPEC_LEAD="0", RL_SPEC_KS="0", RL_SPEC_KE="0", RL_SPEC_PROBE="0"),
               dict(RL_SPEC_GROUP="16", RL_SPEC_SUB="4", RL_SPEC_NO_TRIVIAL="1", RL_SPEC_KS="5", RL_SPEC_KE="5"),
-              dict(RL_SPEC_GROUP="256", RL_SPEC_SUB="16"), dict(RL_SPEC_GROUP="256", RL_SPEC_SUB="1", RL_SPEC_EXTRA="1"), dict(RL_SPEC_GROUP="64", RL_SPEC_SUB="16", RL_SPEC_EXTRA="1", RL_SPEC_PROBE_EVERY="1")]   # 256: a whole workgroup per block (votes and sums through the barrier)
+              dict(RL_SPEC_GROUP="256", RL_SPEC_SUB="16"), dict(RL_SPEC_GROUP="256", RL_SPEC_SUB="1", RL_SPEC_EXTRA="1"), dict(RL_SPEC_GROUP="64", RL_SPEC_SUB="16", RL_SPEC_EXTRA="1", RL_SPEC_PROBE_EVERY="1"),
+              dict(RL_SPEC_GROUP="32", RL_SPEC_SUB="2", RL_SPEC_DENSE="32", RL_SPEC_DENSE_FRAC="0"), dict(RL_SPEC_GROUP="64", RL_SPEC_SUB="1", RL_SPEC_DENSE="3", RL_SPEC_DENSE_FRAC="0", RL_SPEC_LEAD="0", RL_SPEC_KS="0", RL_SPEC_KE="0"),
+              dict(RL_SPEC_GROUP="16", RL_SPEC_SUB="2", RL_SPEC_DENSE="0")]   # 256: a whole workgroup per block (votes and sums through the barrier)
     keys = ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws")
     for n_case, (sd, kw) in enumerate(cases):
         ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
