@@ -22,6 +22,12 @@
 //     narrower windows, and `sub` times fewer samples per lane): each lane walks its segment and on into the next one for a lead-in's length,
 //     then finds where its walk first stands on an entry of the next lane's walk (LINK) — from there the two are the same walk.  The chain follows
 //     a pixel's sub-tracks link by link; a missing link is bridged by the slow path.
+//   * Where the slow path runs inside a pixel whose samples nearly all take the same number of draws c (two walks of such a pixel sit on different
+//     residues of c and stay apart for most of the pixel), the chain's next positions are predictable: the group's lanes — idle while a pixel is
+//     threaded — evaluate the samples that start c, 2c, ... draws on from the chain's head, and the leader consumes them in order for as long as the
+//     chain really stands on them (HELPERS, below).
+// The kernel is bound by LDS for occupancy (the lanes' parked state: 30 KB per workgroup): three workgroups per CU on the Cornell box, which is what
+// lets every heavy block of a 1080p frame (4900 of 8160, two per wave) start at once instead of in two generations.
 // The result is bit-for-bit the serial chain (tests: test_reference_order_two_pass_equals_single_pass, the fuzzer's reference-order cases;
 // RL_CHAIN_SERIAL=1 keeps k_stream_chain as the cross-check).  What it buys: a block's serial work drops from 256 x spp samples to a few
 // samples per pixel, and the rest runs on full waves.

@@ -907,7 +907,9 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             spc.lead_max = getenv("RL_SPEC_LEAD_MAX") ? (unsigned)atoi(getenv("RL_SPEC_LEAD_MAX")) : 128u;
             spc.lead_var = getenv("RL_SPEC_LEAD_VAR") ? (float)atof(getenv("RL_SPEC_LEAD_VAR")) : 100.0f;      // (cbox 1080p x 128 spp: 265.5 -> 260.2 ms; probing every batch: 319.6 ms)
             spc.extra = getenv("RL_SPEC_EXTRA") ? (unsigned)atoi(getenv("RL_SPEC_EXTRA")) : 0u;      // (cbox 1080p x 128 spp: 2.84 M instead of 3.57 M serial samples, 383 M instead of 306 M walked: 261 vs 259 ms — a wash, off)
-            spc.dense = getenv("RL_SPEC_DENSE") ? std::min(64u, (unsigned)atoi(getenv("RL_SPEC_DENSE"))) : 16u;
+            // (cbox 1080p x 128 spp, three workgroups per CU: 244 -> 198 ms; 8 / 16 / 32 lanes alike.  Scenes that stream their BVH: 2452 -> 2517 ms on the 508 k-triangle scene — a helper's sample is a
+            // chain of dependent fetches like any other there — so off)
+            spc.dense = getenv("RL_SPEC_DENSE") ? std::min(64u, (unsigned)atoi(getenv("RL_SPEC_DENSE"))) : (ctx->lds_scene ? 16u : 0u);
             spc.dense_frac = getenv("RL_SPEC_DENSE_FRAC") ? (float)atof(getenv("RL_SPEC_DENSE_FRAC")) : 0.6f;
             spc.probe_every = getenv("RL_SPEC_PROBE_EVERY") ? (unsigned)atoi(getenv("RL_SPEC_PROBE_EVERY")) : 0u;
             // window margins in standard deviations of the predicted offsets: with one block per wave a pixel the chain has to be walked through stalls the whole wave, so wider
