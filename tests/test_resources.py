@@ -25,4 +25,5 @@ def test_the_hot_kernels_keep_their_budgets(built):
     fused = rows[("fused_lds.hip.o", "k_path_fused<0, false, true, 1, 0>")]           # the diffuse Cornell box: the headline kernel
     assert fused["vgpr"] <= 128 and fused["vgpr_spill"] <= 8 and fused["max_waves_per_simd_by_vgpr"] >= 4
     spec = rows[("spec_lds.hip.o", "k_stream_spec<0, false, true, 0>")]              # its chain pass in reference-order streams
-    assert spec["vgpr"] <= 128 and spec["vgpr_spill"] == 0 and spec["max_waves_per_simd_by_vgpr"] >= 4
+    # three waves per SIMD since the parked state was cut to 30 words: three workgroups per CU is what LDS allows, so the registers of a fourth wave buy nothing
+    assert spec["vgpr"] <= 168 and spec["vgpr_spill"] == 0 and spec["max_waves_per_simd_by_vgpr"] >= 3
