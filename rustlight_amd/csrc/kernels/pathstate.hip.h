@@ -87,9 +87,9 @@ struct SpecConf {
 template <bool LDS_ONLY = false>
 RL_DEV TravStackT<LDS_ONLY> make_stack(const StackConf& sc_, unsigned* lds_after_list, size_t global_thread) {
     TravStackT<LDS_ONLY> st;
-    st.lds = reinterpret_cast<int2*>(lds_after_list) + threadIdx.x;
+    st.lds = (typename TravStackT<LDS_ONLY>::LdsPair*)(lds_after_list) + threadIdx.x;
     st.lds_levels = sc_.lds_levels;
-    st.glob = sc_.overflow ? sc_.overflow + global_thread : nullptr;
+    st.glob = sc_.overflow ? (typename TravStackT<LDS_ONLY>::GlobPair*)(sc_.overflow) + global_thread : nullptr;
     st.glob_stride = sc_.overflow_stride;
     return st;
 }

@@ -169,15 +169,28 @@ struct TravStackT {
     static constexpr int kTriStride4 = LDS_ONLY ? kLdsTriStride4 : 4;                              // float4s between triangle records
     static constexpr int kNodeRefScale = LDS_ONLY ? 4 * kLdsNodeStride : 1;                        // inner-node reference = index x this (LDS: byte offset)
     static constexpr int lds_stride = 256;       // every traversal kernel runs 256-lane workgroups
-    int2* lds; int lds_levels;   // lds already offset to this lane; one (code, distance bits) pair per level
-    int* glob; size_t glob_stride;               // glob already offset to this lane
-    RL_DEV void push(int sp, int code, float dist) const {
-        if (LDS_ONLY || sp < lds_levels) lds[sp * lds_stride] = make_int2(code, __float_as_int(dist));
-        else { size_t k = (size_t)(2 * (sp - lds_levels)); glob[k * glob_stride] = code; glob[(k + 1) * glob_stride] = __float_as_int(dist); }
+    // The two halves of the stack are addressed through pointers of their own address space.  With generic pointers the compiler merged the LDS and the overflow
+    // access of a pop into flat loads (and, given the chance, of a push into a flat store): every pop of a streaming kernel went through the vector-memory path,
+    // two instructions each.  Typed: ds_read_b64 / one global_load_dwordx2, and the overflow store only when the entry counts — 508 k triangles, 1080p x 128 spp:
+    // vector-memory reads 7.94 G -> 6.73 G, writes 1.00 G -> 0.56 G wave-instructions per render (what is left are scratch spills); the time did not move (305 ms):
+    // this kernel is not bound by the count of vector-memory instructions after all (profiles/NEGATIVES.md, round 4).  The stack itself rarely passes six pending
+    // entries: a ring that keeps the newest six in LDS changed neither count.
+    typedef int i2v __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) i2v LdsPair;
+    typedef __attribute__((address_space(1))) i2v GlobPair;
+    LdsPair* lds; int lds_levels;   // lds already offset to this lane; one (code, distance bits) pair per level
+    GlobPair* glob; size_t glob_stride;          // overflow levels, [level][thread] pairs; glob already offset to this lane
+    // `counts`: the entry will be popped (the BVH2 loops store the far child on every node trip and only advance sp when both children were hit: a free ds_write, not a free global store)
+    RL_DEV void push(int sp, int code, float dist, bool counts = true) const {
+        i2v e; e.x = code; e.y = __float_as_int(dist);
+        if (LDS_ONLY || sp < lds_levels) lds[sp * lds_stride] = e;
+        else if (counts) glob[(size_t)(sp - lds_levels) * glob_stride] = e;
     }
     RL_DEV void get(int sp, int* code, float* dist) const {
-        if (LDS_ONLY || sp < lds_levels) { const int2 e = lds[sp * lds_stride]; *code = e.x; *dist = __int_as_float(e.y); }
-        else { size_t k = (size_t)(2 * (sp - lds_levels)); *code = glob[k * glob_stride]; *dist = __int_as_float(glob[(k + 1) * glob_stride]); }
+        i2v e;
+        if (LDS_ONLY || sp < lds_levels) e = lds[sp * lds_stride];
+        else e = glob[(size_t)(sp - lds_levels) * glob_stride];
+        *code = e.x; *dist = __int_as_float(e.y);
     }
 };
 using TravStack = TravStackT<false>;
@@ -306,7 +319,7 @@ RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3
             const bool v1 = !(f1 <= d1), v2 = !(f2 <= d2);                 // box hit and entry distance < its.t
             // the reference orders by distance with a missed box at +inf and keeps the left child first on ties
             const bool right_first = v2 & (!v1 | (d1 > d2));
-            st.push(sp, right_first ? p.id1 : p.id2, right_first ? d1 : d2);
+            st.push(sp, right_first ? p.id1 : p.id2, right_first ? d1 : d2, v1 && v2);
             sp += (v1 && v2) ? 1 : 0;
             cur = (v1 || v2) ? (right_first ? p.id2 : p.id1) : kPop;
         }
@@ -623,7 +636,7 @@ RL_DEV bool traverse_coop(const SceneRecs& recs, int root, V3 root_lo, V3 root_h
                 const float f2 = __builtin_fminf(__builtin_fminf(__builtin_fminf((rfx - o.x) * inv_d.x, (rfy - o.y) * inv_d.y), (rfz - o.z) * inv_d.z), hit.t);
                 const bool v1 = !(f1 <= d1), v2 = !(f2 <= d2);
                 const bool right_first = v2 & (!v1 | (d1 > d2));
-                st.push(sp, right_first ? id1 : id2, right_first ? d1 : d2);
+                st.push(sp, right_first ? id1 : id2, right_first ? d1 : d2, v1 && v2);
                 sp += (v1 && v2) ? 1 : 0;
                 cur = (v1 || v2) ? (right_first ? id2 : id1) : kPop;
             }
@@ -775,7 +788,7 @@ RL_DEV bool traverse_pre(const float4* pre_nodes, const float2* pre_tris, const 
                 const int id1 = __float_as_int(b.x), id2 = __float_as_int(b.y);
                 const bool v1 = !(f1 <= d1), v2 = !(f2 <= d2);
                 const bool right_first = v2 & (!v1 | (d1 > d2));
-                st.push(sp, right_first ? id1 : id2, right_first ? d1 : d2);
+                st.push(sp, right_first ? id1 : id2, right_first ? d1 : d2, v1 && v2);
                 sp += (v1 && v2) ? 1 : 0;
                 cur = (v1 || v2) ? (right_first ? id2 : id1) : kPop;
             }
@@ -821,7 +834,7 @@ RL_DEV bool traverse_pre(const float4* pre_nodes, const float2* pre_tris, const 
 // the rest to global memory — for a chain every pop from that part is one more dependent round trip)
 struct ChainStack {
     int2* base;
-    RL_DEV void push(int sp, int code, float dist) const { base[sp] = make_int2(code, __float_as_int(dist)); }
+    RL_DEV void push(int sp, int code, float dist, bool = true) const { base[sp] = make_int2(code, __float_as_int(dist)); }
     RL_DEV void get(int sp, int* code, float* dist) const { const int2 e = base[sp]; *code = e.x; *dist = __int_as_float(e.y); }
 };
 template <class Stack>
@@ -864,7 +877,7 @@ RL_DEV bool traverse_treelet(const float4* nodes_t, const float4* tris, int root
             const float f2 = __builtin_fminf(__builtin_fminf(__builtin_fminf((p.rfx - o.x) * inv_d.x, (p.rfy - o.y) * inv_d.y), (p.rfz - o.z) * inv_d.z), hit.t);
             const bool v1 = !(f1 <= d1), v2 = !(f2 <= d2);
             const bool right_first = v2 & (!v1 | (d1 > d2));
-            st.push(sp, right_first ? p.id1 : p.id2, right_first ? d1 : d2);
+            st.push(sp, right_first ? p.id1 : p.id2, right_first ? d1 : d2, v1 && v2);
             sp += (v1 && v2) ? 1 : 0;
             cur = (v1 || v2) ? (right_first ? p.id2 : p.id1) : kPop;
         }
