@@ -353,6 +353,47 @@ def main():
             rr = sub("cbox_1080p_128spp_reference_order", r, "BASELINE configs[1] in RL_STREAM_REFERENCE_ORDER: rustlight's own stream assignment (one sampler per 16x16 block, "
                      "src/integrators/mod.rs:420-435), the plugin / CLI default; two passes: k_stream_spec (the block chains, speculative windows) + k_path_fused")
             reference_order_value = rr["value"]
+            # ---- the same frames with three of them in flight: three contexts of the scene, one host thread each (a frame's render is a chain of dependent launches whose
+            # tail leaves most of the chip idle; another context's frame fills it).  Timed like a step loop: barrier + synchronize, the frames dealt round-robin to the
+            # contexts, each rendered into its own pinned host buffer (rl_render_path + download), join + synchronize.  Same frames, same images as one after the other.
+            import threading
+            K_IN_FLIGHT = 3
+            ctxs = [ctx] + [api.Context(scene, device_index) for _ in range(K_IN_FLIGHT - 1)]
+
+            def in_flight_record(tag, what, stream_mode, n_frames, oracle):
+                bufs = [torch.zeros((1080, 1920, 3), dtype=torch.float32).pin_memory() for _ in range(3)]       # frames 0, 1, 2 are kept (frame 2 is the one the oracle's table holds), later ones land on frame 0's buffer
+                pp_if = api.path_params(spp=128, stream_mode=stream_mode)
+                seeds_f = [api.IndependentSampler(f).block_seeds(1920, 1080) for f in range(n_frames)]
+                scratch = [torch.zeros((1080, 1920, 3), dtype=torch.float32).pin_memory() for _ in range(K_IN_FLIGHT)]
+                errs = []
+
+                def flight(c, frames):
+                    try:
+                        for f in frames:
+                            dst = bufs[f] if 0 <= f < 3 else scratch[c]
+                            ctxs[c].render(seeds_f[f] if f >= 0 else api.IndependentSampler(1000 + c).block_seeds(1920, 1080), pp_if, out_host_ptr=dst.data_ptr())
+                    except Exception as e:      # noqa: BLE001
+                        errs.append(repr(e))
+                for c in range(K_IN_FLIGHT):
+                    flight(c, [-1])             # warm-up: every context renders one frame alone (its buffers get allocated)
+                torch.cuda.synchronize()
+                t_if = time.perf_counter()
+                th = [threading.Thread(target=flight, args=(c, list(range(c, n_frames, K_IN_FLIGHT)))) for c in range(K_IN_FLIGHT)]
+                for t in th: t.start()
+                for t in th: t.join()
+                torch.cuda.synchronize()
+                t_if = time.perf_counter() - t_if
+                crc_if = f"{zlib.crc32(bufs[2].numpy().tobytes()):08x}"
+                rec = {"workload": tag, "what": what, "frames": n_frames, "in_flight": K_IN_FLIGHT, "ms_per_step": t_if / n_frames * 1e3, "value": 1920 * 1080 * 128 * n_frames / t_if / 1e6, "unit": "Msamples/s",
+                       "image_crc32_frame_2": crc_if, "oracle_crc32": oracle, "oracle_crc_match": None if oracle is None else oracle == crc_if, "errors": errs or None}
+                also.append(rec)
+                return rec
+            reference_order_in_flight = in_flight_record(
+                "cbox_1080p_128spp_reference_order_3_in_flight", "the reference-order frames above, three in flight (three device contexts, one host thread each; rustlight_amd.api.render_in_flight / "
+                "IntegratorPathTracing.frames_in_flight, `rustlight-amd --frames-in-flight 3 -a ...`): throughput of independent frames, not the latency of one", api.STREAM_REFERENCE_ORDER, 9, rr["oracle_crc32"])
+            in_flight_record("cbox_1080p_128spp_3_in_flight", "the headline's frames (per-sample streams), three in flight: the same", api.STREAM_PER_SAMPLE, 18,
+                             oracle_crc("cbox", 1920, 1080, 128, "per_sample", 2))
+            for c in ctxs[1:]: c.close()
             ctx.close()
             for tag, name, w, h, steps, what in (
                     ("cbox_1080x1080_128spp", "cbox", 1080, 1080, 3, "BASELINE configs[1] on a square frame (no pixels looking past the box: V/sample 2.1 instead of 1.15)"),
@@ -417,6 +458,7 @@ def main():
         if also is not None:
             out["reference_order_value"] = reference_order_value
             out["reference_order_oracle_crc_match"] = rr["oracle_crc_match"]
+            out["reference_order_in_flight_value"] = reference_order_in_flight["value"]      # three independent frames in flight (see `also`); `reference_order_value` is one frame at a time
             out["also"] = also
         print(json.dumps(out))
         sys.stdout.flush()

@@ -391,10 +391,14 @@ class Context:
         except Exception:
             pass
 
-    def render(self, seeds: np.ndarray, params: abi.PathParams, out_device_ptr: Optional[int] = None, stream: Optional[int] = None):
-        """Integrator::compute.  Returns (image HxWx3 f32 | None when rendering into a device pointer, stats dict)."""
+    def render(self, seeds: np.ndarray, params: abi.PathParams, out_device_ptr: Optional[int] = None, stream: Optional[int] = None, out_host_ptr: Optional[int] = None):
+        """Integrator::compute.  Returns (image HxWx3 f32 | None when rendering into a device pointer or a caller's (e.g. pinned) host buffer, stats dict)."""
         seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
         st = abi.RenderStats()
+        if out_host_ptr is not None:
+            _check(lib().rl_render_path(self.h, C.byref(params), abi.u64ptr(seeds), seeds.shape[0], C.c_void_p(out_host_ptr), 0,
+                                        C.c_void_p(stream) if stream else None, C.byref(st)))
+            return None, st.as_dict()
         if out_device_ptr is None:
             img = np.zeros((self.height, self.width, 3), dtype=np.float32)
             _check(lib().rl_render_path(self.h, C.byref(params), abi.u64ptr(seeds), seeds.shape[0], img.ctypes.data_as(C.c_void_p), 0,
@@ -515,14 +519,18 @@ class IntegratorPathTracing:
     """struct IntegratorPathTracing (src/integrators/explicit/path.rs:14-20) + Integrator::compute."""
 
     def __init__(self, min_depth=0, max_depth=None, rr_depth=0, strategy=STRATEGY_ALL, single_scattering=False,
-                 stream_mode=STREAM_REFERENCE_ORDER, device=0, numerics=NUMERICS_EXACT):
+                 stream_mode=STREAM_REFERENCE_ORDER, device=0, numerics=NUMERICS_EXACT, frames_in_flight=1):
         """stream_mode: the plugin's default is rustlight's own per-block stream order (seed-for-seed the reference's image);
-        STREAM_PER_SAMPLE is the opt-in throughput decomposition."""
+        STREAM_PER_SAMPLE is the opt-in throughput decomposition.  frames_in_flight (MI355X-specific, not in the reference): how many
+        independent frames `compute_frames` — and the progressive wrappers through it — keep on the GPU at once (one device context and
+        one host thread each; the images are those of one frame after the other)."""
         self.min_depth, self.max_depth, self.rr_depth = min_depth, max_depth, rr_depth
         self.strategy, self.single_scattering = strategy, single_scattering
         self.stream_mode, self.device, self.numerics = stream_mode, device, numerics
+        self.frames_in_flight = max(1, int(frames_in_flight))
         self.last_stats = None
         self._ctx = None
+        self._extra = []
 
     def compute(self, sampler: IndependentSampler, scene: Scene, nb_samples: int = 1):
         """IntegratorType::compute (integrators/mod.rs:274-338): BVH build (untimed) then the render."""
@@ -534,6 +542,57 @@ class IntegratorPathTracing:
                         self.stream_mode, sampler.variant, numerics=self.numerics)
         img, self.last_stats = self._ctx.render(seeds, p)
         return img
+
+    def compute_frames(self, sampler: IndependentSampler, scene: Scene, nb_samples: int, n_frames: int):
+        """`n_frames` consecutive `compute` calls — the block seeds of every frame are drawn from the master sampler in call order, exactly
+        as that many sequential calls would draw them — with up to `frames_in_flight` of them on the GPU at once.  A frame's render is a
+        chain of dependent launches that leaves much of the chip idle at its tail (reference-order streams: the chain pass ends with its
+        slowest wave); another context's frame fills it.  Returns the images in frame order."""
+        if self._ctx is None or self._ctx.scene is not scene:
+            self._ctx = Context(scene, self.device)
+            self._extra = []
+        k = min(self.frames_in_flight, max(1, n_frames))
+        while len(self._extra) < k - 1:
+            self._extra.append(Context(scene, self.device))
+        w, h = scene.size
+        jobs = [(sampler.block_seeds(w, h),
+                 path_params(nb_samples, self.min_depth, self.max_depth, self.rr_depth, self.strategy, self.single_scattering,
+                             self.stream_mode, sampler.variant, numerics=self.numerics)) for _ in range(n_frames)]
+        out = render_in_flight([self._ctx] + self._extra[:k - 1], jobs)
+        if out:
+            self.last_stats = out[-1][1]
+        return [img for img, _ in out]
+
+
+def render_in_flight(contexts, jobs):
+    """Render `jobs` = [(block seeds, path params), ...] on `contexts` (same scene, any devices), job j on context j % len(contexts), one host
+    thread per context (rl_render_path is synchronous; contexts own their streams and share nothing mutable, and ctypes releases the GIL
+    for the call).  Returns [(image, stats), ...] in job order; the first error is re-raised after every thread has stopped."""
+    import threading
+    k = max(1, min(len(contexts), len(jobs)))
+    out = [None] * len(jobs)
+    errors = []
+
+    def work(c):
+        try:
+            for j in range(c, len(jobs), k):
+                if errors:
+                    return
+                out[j] = contexts[c].render(*jobs[j])
+        except Exception as e:      # noqa: BLE001 — handed to the caller below
+            errors.append(e)
+
+    if k == 1:
+        work(0)
+    else:
+        threads = [threading.Thread(target=work, args=(c,)) for c in range(k)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    if errors:
+        raise errors[0]
+    return out
 
 
 def _load_with(fn_name: str, path: str) -> np.ndarray:
@@ -582,9 +641,22 @@ class IntegratorAverage:
         base, ext = os.path.splitext(output_img_path)
         csv = open(base + "_time.csv", "w") if self.dump_all else None
         bitmap, iteration, elapsed = None, 1, 0.0
+        # frames in flight (an inner integrator that has `frames_in_flight` > 1): the passes are rendered a batch at a time and folded in pass order, each
+        # charged its share of the batch's time; with a time-out the passes of the last batch beyond it are dropped (their seeds are drawn: the next
+        # call of the same sampler goes on after them)
+        batch = max(1, getattr(self.integrator, "frames_in_flight", 1)) if hasattr(self.integrator, "compute_frames") else 1
+        pending = []
         while True:
             t0 = time.perf_counter()
-            new = self.integrator.compute(sampler, scene, nb_samples)
+            if batch > 1:
+                if not pending:
+                    n = batch if self.max_iterations is None else min(batch, self.max_iterations - iteration + 1)
+                    pending = self.integrator.compute_frames(sampler, scene, nb_samples, n)
+                    share = (time.perf_counter() - t0) / len(pending)
+                new = pending.pop(0)
+                t0 = time.perf_counter() - share
+            else:
+                new = self.integrator.compute(sampler, scene, nb_samples)
             if iteration == 1:
                 bitmap = new
             else:   # bitmap.scale(iteration); accumulate_bitmap; scale(1 / (iteration + 1))   (avg.rs:59-61, sic)

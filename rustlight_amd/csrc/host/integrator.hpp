@@ -14,6 +14,8 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../../include/rustlight_amd.h"
@@ -77,15 +79,86 @@ struct IntegratorPathTracing {
     // own host thread into its own framebuffer in HBM; ONE ncclReduce over xGMI merges them on the first GPU (rl_multi_*)
     int n_gpus = 1;
 
+    // frames in flight (one GPU): how many independent frames `compute_frames` — and the progressive wrappers through it — keep on the GPU at once, one device
+    // context and one host thread each.  A frame's render is a chain of dependent launches that leaves much of the chip idle at its tail (reference-order
+    // streams: the chain pass ends with its slowest wave); another context's frame fills it.  The images are those of one frame after the other.
+    int frames_in_flight = 1;
+
     // the device contexts (BVH + uploaded scene) are built once per scene, like `BVHAccel::new` in IntegratorType::compute
     rl_context* ctx = nullptr;
+    std::vector<rl_context*> extra_ctx;      // frames in flight: contexts 2 .. frames_in_flight
     rl_multi* multi = nullptr;
     const Scene* ctx_scene = nullptr;
     int ctx_gpus = 0;
     IntegratorPathTracing() = default;
     IntegratorPathTracing(const IntegratorPathTracing&) = delete;
     ~IntegratorPathTracing() { release(); }
-    void release() { if (ctx) rl_context_destroy(ctx); if (multi) rl_multi_destroy(multi); ctx = nullptr; multi = nullptr; }
+    void release() {
+        if (ctx) rl_context_destroy(ctx);
+        for (rl_context* c : extra_ctx) rl_context_destroy(c);
+        extra_ctx.clear();
+        if (multi) rl_multi_destroy(multi);
+        ctx = nullptr; multi = nullptr;
+    }
+    rl_path_params params_for(const IndependentSampler& sampler, const Scene& scene) const {
+        rl_path_params p;
+        rl_path_params_default(&p);
+        p.spp = (uint32_t)scene.nb_samples;
+        p.has_min_depth = min_depth.has_value(); p.min_depth = min_depth.value_or(0);
+        p.has_max_depth = max_depth.has_value(); p.max_depth = max_depth.value_or(0);
+        p.has_rr_depth = rr_depth.has_value(); p.rr_depth = rr_depth.value_or(0);
+        p.strategy = (int)strategy;
+        p.single_scattering = single_scattering;
+        p.stream_mode = stream_mode;
+        p.numerics = numerics;
+        p.seed_variant = sampler.variant;
+        p.shard_index = shard_index; p.shard_count = shard_count;
+        return p;
+    }
+
+    // `n_frames` consecutive compute() calls with up to `frames_in_flight` of them on the GPU at once: the block seeds of every frame are drawn from the master
+    // sampler in call order (exactly what that many sequential calls draw), frame j renders on context j % k from host thread j % k; images in frame order.
+    std::vector<BufferCollection> compute_frames(IndependentSampler& sampler, Scene& scene, size_t n_frames) {
+        std::vector<BufferCollection> out;
+        const size_t k = std::min<size_t>((size_t)std::max(1, frames_in_flight), std::max<size_t>(1, n_frames));
+        if (k <= 1 || std::max(1, n_gpus) > 1) {
+            for (size_t j = 0; j < n_frames; j++) out.push_back(compute(sampler, scene));
+            return out;
+        }
+        if (ctx_scene != &scene || ctx_gpus != 1 || !ctx) {
+            release();
+            if (rl_context_create(scene.handle, device, &ctx) != RL_OK) throw std::runtime_error(std::string("rl_context_create: ") + rl_last_error());
+            ctx_scene = &scene; ctx_gpus = 1;
+        }
+        while (extra_ctx.size() + 1 < k) {
+            rl_context* c = nullptr;
+            if (rl_context_create(scene.handle, device, &c) != RL_OK) throw std::runtime_error(std::string("rl_context_create: ") + rl_last_error());
+            extra_ctx.push_back(c);
+        }
+        const rl_path_params p = params_for(sampler, scene);
+        out.resize(n_frames);
+        std::vector<std::vector<uint64_t>> seeds(n_frames);
+        for (size_t j = 0; j < n_frames; j++) {
+            rl_scene_image_size(scene.handle, &out[j].width, &out[j].height);
+            out[j].primal.assign((size_t)3 * out[j].width * out[j].height, 0.0f);
+            seeds[j].resize(rl_block_count(out[j].width, out[j].height));
+            rl_generate_block_seeds(&sampler.rnd, out[j].width, out[j].height, seeds[j].data(), seeds[j].size());   // generate_img_blocks, in frame order
+        }
+        std::vector<std::string> errors(k);
+        std::vector<rl_render_stats> stats(k);
+        std::vector<std::thread> threads;
+        for (size_t c = 0; c < k; c++)
+            threads.emplace_back([&, c]() {
+                rl_context* cx = c == 0 ? ctx : extra_ctx[c - 1];
+                for (size_t j = c; j < n_frames; j += k) {
+                    if (rl_render_path(cx, &p, seeds[j].data(), seeds[j].size(), out[j].primal.data(), 0, nullptr, &stats[c]) != RL_OK) { errors[c] = rl_last_error(); return; }   // (the error string is per thread)
+                }
+            });
+        for (std::thread& t : threads) t.join();
+        for (const std::string& e : errors) if (!e.empty()) throw std::runtime_error("rl_render_path: " + e);
+        last_stats = stats[(n_frames - 1) % k];
+        return out;
+    }
 
     // IntegratorType::compute + Integrator::compute: builds the BVH (untimed, first call), renders, returns the image
     BufferCollection compute(IndependentSampler& sampler, Scene& scene) {
@@ -108,25 +181,15 @@ struct IntegratorPathTracing {
         BufferCollection img;
         rl_scene_image_size(scene.handle, &img.width, &img.height);
         img.primal.assign((size_t)3 * img.width * img.height, 0.0f);
-        rl_path_params p;
-        rl_path_params_default(&p);
-        p.spp = (uint32_t)scene.nb_samples;
-        p.has_min_depth = min_depth.has_value(); p.min_depth = min_depth.value_or(0);
-        p.has_max_depth = max_depth.has_value(); p.max_depth = max_depth.value_or(0);
-        p.has_rr_depth = rr_depth.has_value(); p.rr_depth = rr_depth.value_or(0);
-        p.strategy = (int)strategy;
-        p.single_scattering = single_scattering;
-        p.stream_mode = stream_mode;
-        p.numerics = numerics;
-        p.seed_variant = sampler.variant;
+        rl_path_params p = params_for(sampler, scene);
         std::vector<uint64_t> seeds(rl_block_count(img.width, img.height));
         rl_generate_block_seeds(&sampler.rnd, img.width, img.height, seeds.data(), seeds.size());   // generate_img_blocks
         if (n == 1) {
-            p.shard_index = shard_index; p.shard_count = shard_count;
             int rc = rl_render_path(ctx, &p, seeds.data(), seeds.size(), img.primal.data(), 0, nullptr, &last_stats);
             if (rc != RL_OK) throw std::runtime_error(std::string("rl_render_path: ") + rl_last_error());
             return img;
         }
+        p.shard_index = 0; p.shard_count = 1;      // (rl_multi deals the blocks itself)
         int rc = rl_multi_render_path(multi, &p, seeds.data(), seeds.size(), img.primal.data(), &last_stats);
         if (rc != RL_OK) throw std::runtime_error(std::string("rl_multi_render_path: ") + rl_last_error());
         return img;
@@ -179,6 +242,8 @@ struct IntegratorDirect : IntegratorMC {
 
 // IntegratorAverage (src/integrators/avg.rs:5-131) and IntegratorEqualTime (src/integrators/equal_time.rs:4-66):
 // host loops around any inner integrator with `compute(IndependentSampler&, Scene&)`.
+template <class T, class = void> struct has_frames_in_flight : std::false_type {};
+template <class T> struct has_frames_in_flight<T, std::void_t<decltype(std::declval<T&>().frames_in_flight)>> : std::true_type {};
 template <class Inner>
 struct IntegratorAverage {
     Inner& integrator;
@@ -195,9 +260,26 @@ struct IntegratorAverage {
         BufferCollection bitmap;
         size_t iteration = 1;
         double elapsed = 0.0;
+        // frames in flight (an inner integrator with frames_in_flight > 1): the passes are rendered a batch at a time and folded in pass order, each charged its
+        // share of the batch's time; the passes of the last batch beyond the time-out are dropped (their seeds are drawn)
+        std::vector<BufferCollection> pending;
+        size_t next_pending = 0;
+        double share = 0.0;
         for (;;) {
             auto t0 = std::chrono::steady_clock::now();
-            BufferCollection nb = integrator.compute(sampler, scene);
+            BufferCollection nb;
+            if constexpr (has_frames_in_flight<Inner>::value) {
+                if (integrator.frames_in_flight > 1) {
+                    if (next_pending == pending.size()) {
+                        pending = integrator.compute_frames(sampler, scene, (size_t)integrator.frames_in_flight);
+                        next_pending = 0;
+                        share = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / (double)pending.size();
+                    }
+                    nb = std::move(pending[next_pending++]);
+                    elapsed += share;
+                    t0 = std::chrono::steady_clock::now();
+                } else nb = integrator.compute(sampler, scene);
+            } else nb = integrator.compute(sampler, scene);
             if (iteration == 1) bitmap = nb;
             else { bitmap.scale((float)iteration); bitmap.accumulate_bitmap(nb); bitmap.scale(1.0f / (float)(iteration + 1)); }   // avg.rs:59-61
             elapsed += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
