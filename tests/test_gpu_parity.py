@@ -1056,6 +1056,13 @@ def test_bench_two_ranks_on_one_gpu(built):
     assert out["reference_order_value"] == ro["value"] > 0 and len(ro["ranks"]) == 2
     assert all(r["chain_ms"] > 0 and r["kernel_ms"] > 0 and r["reduce_ms"] >= 0 for r in ro["ranks"])
     assert all("reduce_ms_per_step" in r for r in out["distributed"]["ranks"])
+    # ... and with three frames in flight per rank (three contexts each): the last frame's reduced image is the one-at-a-time image of that frame
+    fl = ro["three_frames_in_flight"]
+    assert fl["errors"] is None and fl["value"] > 0 and out["reference_order_in_flight_value"] == fl["value"]
+    ctx = api.Context(api.Scene(scenes.cbox(320, 200)), 0)
+    img, _ = ctx.render(api.IndependentSampler(fl["frames"] - 1).block_seeds(320, 200), api.path_params(spp=8, stream_mode=api.STREAM_REFERENCE_ORDER))
+    import zlib
+    assert fl["image_crc32_last_frame"] == f"{zlib.crc32(img.tobytes()):08x}"
 
 
 def test_fast_numerics_tolerance_mode(built):
