@@ -260,38 +260,43 @@ def main():
         K_IF, F_IF = 3, 6
         in_flight = {"in_flight": K_IF, "frames": F_IF, "errors": None}
         errs = []
-        try:
-            ctxs = [ctx] + [api.Context(scene, device_index) for _ in range(K_IF - 1)]
+        ctxs, fbs, host_if = [ctx], [], None
+        pp_if = api.path_params(spp=spp_total, shard_index=rank, shard_count=world, stream_mode=api.STREAM_REFERENCE_ORDER)
+
+        def flight(c, frames):
+            try:
+                for f in frames:
+                    ctxs[c].render(api.IndependentSampler(f if f >= 0 else 1000 + c).block_seeds(args.width, args.height), pp_if, out_device_ptr=fbs[max(f, 0)].data_ptr())
+            except Exception as e:      # noqa: BLE001
+                errs.append(repr(e))
+        try:        # everything that can fail on ONE rank (memory) happens before the ranks agree to go on: no rank is left alone in a collective
+            ctxs += [api.Context(scene, device_index) for _ in range(K_IF - 1)]
             fbs = [torch.zeros((args.height, args.width, 3), dtype=torch.float32, device=dev) for _ in range(F_IF)]
             host_if = torch.zeros((args.height, args.width, 3), dtype=torch.float32).pin_memory() if rank == 0 else None
-            pp_if = api.path_params(spp=spp_total, shard_index=rank, shard_count=world, stream_mode=api.STREAM_REFERENCE_ORDER)
-
-            def flight(c, frames):
-                try:
-                    for f in frames:
-                        ctxs[c].render(api.IndependentSampler(f if f >= 0 else 1000 + c).block_seeds(args.width, args.height), pp_if, out_device_ptr=fbs[max(f, 0)].data_ptr())
-                except Exception as e:      # noqa: BLE001
-                    errs.append(repr(e))
             for c in range(1, K_IF):
                 flight(c, [-1])             # warm-up of the new contexts (the first one rendered above)
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+        if rd.max_over_ranks(1.0 if errs else 0.0) == 0.0:
             rd.barrier()
             torch.cuda.synchronize()
             t_if = time.perf_counter()
             th = [threading.Thread(target=flight, args=(c, list(range(c, F_IF, K_IF)))) for c in range(K_IF)]
             for t in th: t.start()
             for t in th: t.join()
-            for f in range(F_IF):
+            for f in range(F_IF):           # (every rank issues these whatever its threads reported)
                 rd.reduce_framebuffer(fbs[f])
                 if rank == 0:
                     host_if.copy_(fbs[f], non_blocking=True)
             rd.barrier()
             torch.cuda.synchronize()
             t_if = rd.max_over_ranks(time.perf_counter() - t_if)
-            for c in ctxs[1:]: c.close()
             in_flight.update({"ms_per_step": t_if / F_IF * 1e3, "value": args.width * args.height * spp_total * F_IF / t_if / 1e6, "unit": "Msamples/s",
                               "image_crc32_last_frame": f"{zlib.crc32(host_if.numpy().tobytes()):08x}" if rank == 0 else None})
-        except Exception as e:      # noqa: BLE001
-            errs.append(repr(e))
+        else:
+            in_flight["skipped"] = "a rank could not set its contexts up"
+        for c in ctxs[1:]:
+            c.close()
         in_flight["errors"] = errs or None
         if rank == 0:
             ref_multi = {"workload": f"cbox {args.width}x{args.height}x{spp_total}spp in RL_STREAM_REFERENCE_ORDER on {world} shards", "steps": 2, "ms_per_step": rrec["dt"] / 2 * 1e3,
