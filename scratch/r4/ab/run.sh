@@ -1,4 +1,4 @@
-# dev: A/B on one box — current tree vs the generic-pointer traversal stack (trace.hip.h / pathstate.hip.h of dd30cc2), streaming kernels
+# dev: A/B on one box — current tree vs the generic-pointer traversal stack.  Before the call: git show dd30cc2:rustlight_amd/csrc/kernels/trace.hip.h > scratch/r4/ab/trace.hip.h.old (same for pathstate.hip.h); the copies are not kept in the tree
 R=$GRAFT_REPO_ROOT; cd $R
 one() {
   for a in "" "--numerics fast" "--tris 4000000" "--tris 4000000 --numerics fast"; do
