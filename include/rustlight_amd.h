@@ -317,6 +317,14 @@ int rl_render_path(rl_context* ctx, const rl_path_params* params, const uint64_t
                    size_t n_blocks, float* out_rgb, int out_is_device, void* stream,
                    rl_render_stats* stats);
 
+/* Frames in flight behind one call (the progressive wrappers' passes, avg.rs:5-131 / equal_time.rs:4-66: N independent renders of one scene): frame f — block
+ * seeds `block_seeds[f]`, host image `out_rgb[f]` (W*H*3 f32) — renders on `ctxs[f % n_ctx]` from host thread f % n_ctx; `ctxs` are distinct contexts of the same
+ * scene.  Returns when every frame is done; the images (and `stats[f]`, if not NULL) are those of `n_frames` rl_render_path calls one after the other.  On an
+ * error the first failing thread's code is returned and rl_last_error carries its message; the other frames may or may not have been rendered. */
+int rl_render_path_frames(rl_context* const* ctxs, size_t n_ctx, const rl_path_params* params,
+                          const uint64_t* const* block_seeds, size_t n_blocks, size_t n_frames,
+                          float* const* out_rgb, rl_render_stats* stats);
+
 /* ---- the whole scene as ONE plain-old-data description ("SceneDesc POD: counts + pointers") ------------------
  * What a Rust host fills from `&Scene` (src/scene.rs:16-30) in one go instead of the builder calls above; the arrays are only read during
  * the call.  Equivalent to: rl_scene_create, rl_scene_set_camera_matrices (has_camera_matrices) or rl_scene_set_camera, rl_scene_add_bitmap (in order: their ids are 0, 1, ...), rl_scene_add_mesh

@@ -33,7 +33,7 @@ PUBLIC_SYMBOLS = [
     "rl_scene_set_environment", "rl_scene_set_environment_map", "rl_scene_build_emitters", "rl_scene_enable_ats", "rl_scene_load_pbrt", "rl_scene_load_mitsuba", "rl_scene_load",
     "rl_scene_image_size", "rl_scene_counts", "rl_sampler_seed", "rl_sampler_next_u64", "rl_sampler_next_f32",
     "rl_path_params_default", "rl_device_count", "rl_context_create", "rl_context_destroy", "rl_last_error", "rl_block_count",
-    "rl_generate_block_seeds", "rl_render_path", "rl_multi_create", "rl_multi_destroy", "rl_multi_info", "rl_multi_describe", "rl_multi_shard_stats", "rl_multi_render_path", "rl_render_ao", "rl_render_direct", "rl_trace_batch", "rl_visible_batch", "rl_load_pfm", "rl_load_image", "rl_save_pfm", "rl_save_png", "rl_save_exr", "rl_save_image", "rl_build_info",
+    "rl_generate_block_seeds", "rl_render_path", "rl_render_path_frames", "rl_multi_create", "rl_multi_destroy", "rl_multi_info", "rl_multi_describe", "rl_multi_shard_stats", "rl_multi_render_path", "rl_render_ao", "rl_render_direct", "rl_trace_batch", "rl_visible_batch", "rl_load_pfm", "rl_load_image", "rl_save_pfm", "rl_save_png", "rl_save_exr", "rl_save_image", "rl_build_info",
 ]
 
 
@@ -98,6 +98,7 @@ def lib():
     L.rl_block_count.restype = C.c_size_t
     L.rl_generate_block_seeds.argtypes = [C.POINTER(abi.Sampler), C.c_uint32, C.c_uint32, u64p, C.c_size_t]
     L.rl_render_path.argtypes = [vp, C.POINTER(abi.PathParams), u64p, C.c_size_t, vp, C.c_int, vp, C.POINTER(abi.RenderStats)]
+    L.rl_render_path_frames.argtypes = [C.POINTER(vp), C.c_size_t, C.POINTER(abi.PathParams), C.POINTER(u64p), C.c_size_t, C.c_size_t, C.POINTER(C.POINTER(C.c_float)), C.POINTER(abi.RenderStats)]
     for fn in (L.rl_render_ao, L.rl_render_direct):
         fn.argtypes = [vp, C.POINTER(abi.McParams), u64p, C.c_size_t, vp, C.c_int, vp, C.POINTER(abi.RenderStats)]
     L.rl_multi_create.argtypes = [vp, C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
@@ -562,6 +563,22 @@ class IntegratorPathTracing:
         if out:
             self.last_stats = out[-1][1]
         return [img for img, _ in out]
+
+
+def render_frames(contexts, seeds_list, params: abi.PathParams):
+    """rl_render_path_frames: the frames of `seeds_list` (block seeds per frame) with the same parameters, frame f on contexts[f % len(contexts)] — the library's own
+    threads.  Returns ([image, ...], [stats dict, ...]) in frame order."""
+    n = len(seeds_list)
+    w, h = contexts[0].width, contexts[0].height
+    seeds = [np.ascontiguousarray(s, dtype=np.uint64) for s in seeds_list]
+    imgs = [np.zeros((h, w, 3), dtype=np.float32) for _ in range(n)]
+    vp, u64p, fp = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_float)
+    c_ctx = (vp * len(contexts))(*[c.h.value for c in contexts])
+    c_seeds = (u64p * max(n, 1))(*[abi.u64ptr(s) for s in seeds])
+    c_out = (fp * max(n, 1))(*[abi.fptr(i) for i in imgs])
+    st = (abi.RenderStats * max(n, 1))()
+    _check(lib().rl_render_path_frames(c_ctx, len(contexts), C.byref(params), c_seeds, seeds[0].shape[0] if n else 0, n, c_out, st))
+    return imgs, [st[f].as_dict() for f in range(n)]
 
 
 def render_in_flight(contexts, jobs):

@@ -493,6 +493,14 @@ def test_frames_in_flight_render_the_same_frames(built, cbox64, tmp_path):
         for (wi, ws), (gi, gs) in zip(want, got):
             np.testing.assert_array_equal(gi, wi)
             assert gs["rng_draws"] == ws["rng_draws"] and gs["vertices"] == ws["vertices"]
+        # the same behind one C-ABI call (the library's own threads), and its argument checks
+        cs = [api.Context(scene, 0) for _ in range(2)]
+        imgs, sts = api.render_frames(cs, [j[0] for j in jobs], jobs[0][1])
+        for (wi, ws), gi, gs in zip(want, imgs, sts):
+            np.testing.assert_array_equal(gi, wi)
+            assert gs["rng_draws"] == ws["rng_draws"]
+        with pytest.raises(api.RustlightError):
+            api.render_frames([cs[0], cs[0]], [j[0] for j in jobs[:2]], jobs[0][1])      # one frame at a time per context
     seq = api.IntegratorAverage(api.IntegratorPathTracing(), max_iterations=5, dump_all=False)
     a = seq.compute(api.IndependentSampler(9), scene, nb_samples=2, output_img_path=str(tmp_path / "a.pfm"))
     s2 = api.IndependentSampler(9)
