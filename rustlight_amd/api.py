@@ -701,9 +701,18 @@ class IntegratorEqualTime:
     def compute(self, sampler, scene, nb_samples=1):
         import time
         bitmap, iteration, elapsed = None, 1, 0.0
+        batch = max(1, getattr(self.integrator, "frames_in_flight", 1)) if hasattr(self.integrator, "compute_frames") else 1      # frames in flight: as in IntegratorAverage
+        pending = []
         while True:
             t0 = time.perf_counter()
-            new = self.integrator.compute(sampler, scene, nb_samples)
+            if batch > 1:
+                if not pending:
+                    pending = self.integrator.compute_frames(sampler, scene, nb_samples, batch)
+                    share = (time.perf_counter() - t0) / len(pending)
+                new = pending.pop(0)
+                t0 = time.perf_counter() - share
+            else:
+                new = self.integrator.compute(sampler, scene, nb_samples)
             bitmap = new if iteration == 1 else bitmap + new
             elapsed += time.perf_counter() - t0
             if elapsed * 1000.0 >= self.target_time_ms:

@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
             else if (a == "-t" || a == "--threads") (void)val();   // host threads are irrelevant on the GPU path
             else if (a == "--device") device = std::atoi(val().c_str());
             else if (a == "--gpus") gpus = std::atoi(val().c_str());
-            else if (a == "--frames-in-flight") frames_in_flight = std::max(1, std::atoi(val().c_str()));   // -a: that many independent passes on the GPU at once (same images, more of the chip busy)
+            else if (a == "--frames-in-flight") frames_in_flight = std::max(1, std::atoi(val().c_str()));   // -a / -e: that many independent passes on the GPU at once (same images, more of the chip busy)
             else if (a == "--stream-mode") mode = val() == "reference" ? RL_STREAM_REFERENCE_ORDER : RL_STREAM_PER_SAMPLE;
             else if (a == "--numerics") numerics = val() == "fast" ? RL_NUMERICS_FAST : RL_NUMERICS_EXACT;
             else if (a == "-a" || a == "--average") average = val();

@@ -303,9 +303,24 @@ struct IntegratorEqualTime {
         BufferCollection bitmap;
         size_t iteration = 1;
         double elapsed_ms = 0.0;
+        std::vector<BufferCollection> pending;      // frames in flight: as in IntegratorAverage
+        size_t next_pending = 0;
+        double share_ms = 0.0;
         for (;;) {
             auto t0 = std::chrono::steady_clock::now();
-            BufferCollection nb = integrator.compute(sampler, scene);
+            BufferCollection nb;
+            if constexpr (has_frames_in_flight<Inner>::value) {
+                if (integrator.frames_in_flight > 1) {
+                    if (next_pending == pending.size()) {
+                        pending = integrator.compute_frames(sampler, scene, (size_t)integrator.frames_in_flight);
+                        next_pending = 0;
+                        share_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (double)pending.size();
+                    }
+                    nb = std::move(pending[next_pending++]);
+                    elapsed_ms += share_ms;
+                    t0 = std::chrono::steady_clock::now();
+                } else nb = integrator.compute(sampler, scene);
+            } else nb = integrator.compute(sampler, scene);
             if (iteration == 1) bitmap = nb; else bitmap.accumulate_bitmap(nb);
             elapsed_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (elapsed_ms >= target_time_ms) break;

@@ -508,6 +508,9 @@ def test_frames_in_flight_render_the_same_frames(built, cbox64, tmp_path):
     b = par.compute(s2, scene, nb_samples=2, output_img_path=str(tmp_path / "b.pfm"))
     np.testing.assert_array_equal(b, a)
     assert par.iterations == 5
+    eq = api.IntegratorEqualTime(api.IntegratorPathTracing(frames_in_flight=3), target_time_ms=0.0)      # stops after the first pass of its first batch
+    np.testing.assert_array_equal(eq.compute(api.IndependentSampler(9), scene, nb_samples=2),
+                                  api.IntegratorEqualTime(api.IntegratorPathTracing(), target_time_ms=0.0).compute(api.IndependentSampler(9), scene, nb_samples=2))
     # the C++ mirror through the CLI: -a 0 stops after the first pass of the first batch; its image is the plain render's
     import subprocess
     from rustlight_amd import export
