@@ -18,7 +18,10 @@ per launch / mean launch duration from HIP events on the render stream.  `cpu_ba
 CPU oracle (a C++ restatement of rustlight's path integrator — NOT rustlight itself) on a bounded
 sample of the same workload on the host cores.  On the default single-GPU run the line also carries `also`: the other BASELINE
 configurations and stream modes timed the same way in the same process (configs[2] stand-in, configs[4], configs[1] in
-rustlight's own reference-order streams, configs[1] on a square frame), and `reference_order_value` at the top level."""
+rustlight's own reference-order streams, configs[1] on a square frame), and `reference_order_value` at the top level.
+`value`, `reference_order_value` and every `ms_per_step` are ONE frame at a time (rl_render_path is synchronous, like Integrator::compute).  Next to
+them, never in their place: `reference_order_in_flight_value` and the `*_3_in_flight` records — the same frames with three of them on the GPU at once
+(three contexts of the scene, one host thread each; DESIGN.md 5 "Frames in flight") — and, for N > 1, `reference_order.three_frames_in_flight` per rank."""
 from __future__ import annotations
 
 import argparse
