@@ -69,7 +69,7 @@ struct IntegratorPathTracing {
     // MI355X-specific knobs (not in the reference)
     int device = 0;
     // RL_STREAM_REFERENCE_ORDER = rustlight's own stream assignment (seed-for-seed the reference's image); RL_STREAM_PER_SAMPLE is the
-    // throughput decomposition (statistically the same image, ~30x faster on the Cornell box at 1080p x 128 spp): opt-in
+    // throughput decomposition (statistically the same image, ~5x faster on the Cornell box at 1080p x 128 spp since round 4): opt-in
     rl_stream_mode stream_mode = RL_STREAM_REFERENCE_ORDER;
     uint32_t numerics = RL_NUMERICS_EXACT;      // RL_NUMERICS_FAST: opt-in tolerance mode
     uint32_t shard_index = 0, shard_count = 1;
