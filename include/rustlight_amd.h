@@ -220,8 +220,9 @@ typedef enum rl_path_strategy { RL_STRATEGY_ALL = 0, RL_STRATEGY_BSDF = 1, RL_ST
  *  RL_STREAM_REFERENCE_ORDER: one serial stream per 16x16 block, consumed over (iy, ix, sample)
  *      exactly as compute_mc does (src/integrators/mod.rs:420-435) — equals rustlight proper.  Runs in two passes on the
  *      GPU: a draw-count walk of every block's stream records the sampler state at the start of each camera sample (what is
- *      serial is only how many numbers a sample takes), then all samples are evaluated in parallel from those states; 15x
- *      slower than RL_STREAM_PER_SAMPLE on the Cornell box, same image and counters as the one-lane-per-block walk.
+ *      serial is only how many numbers a sample takes; since round 4 that walk is speculative: per-pixel windows of the block's stream walked by
+ *      every lane, the true chain threaded through them), then all samples are evaluated in parallel from those states; 5x
+ *      slower than RL_STREAM_PER_SAMPLE on the Cornell box at 1080p x 128 spp, same image and counters as the one-lane-per-block walk.
  *  RL_STREAM_PER_SAMPLE: the block stream is forked with the reference's own clone_box rule
  *      (samplers/independent.rs:18-22) once per pixel and once per sample — throughput mode. */
 typedef enum rl_stream_mode { RL_STREAM_REFERENCE_ORDER = 0, RL_STREAM_PER_SAMPLE = 1 } rl_stream_mode;
