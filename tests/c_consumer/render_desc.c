@@ -58,6 +58,24 @@ int main(int argc, char** argv) {
     params.stream_mode = SCENE_STREAM_MODE;
     if ((rc = rl_render_path(ctx, &params, seeds, n_blocks, image, 0, NULL, &stats)) != RL_OK) return fail("rl_render_path", rc);
 
+    {   /* frames in flight behind one call: the same frame twice on two contexts at once must be the same image twice (rl_render_path_frames) */
+        rl_context* ctx2 = NULL;
+        rl_context* both[2];
+        const uint64_t* frame_seeds[2];
+        float* frame_out[2];
+        rl_render_stats frame_stats[2];
+        int k;
+        if ((rc = rl_context_create(scene, 0, &ctx2)) != RL_OK) return fail("rl_context_create (2)", rc);
+        both[0] = ctx; both[1] = ctx2;
+        frame_seeds[0] = seeds; frame_seeds[1] = seeds;
+        for (k = 0; k < 2; k++) { frame_out[k] = (float*)malloc(n_floats * sizeof(float)); if (!frame_out[k]) return 4; }
+        if ((rc = rl_render_path_frames(both, 2, &params, frame_seeds, n_blocks, 2, frame_out, frame_stats)) != RL_OK) return fail("rl_render_path_frames", rc);
+        for (k = 0; k < 2; k++) {
+            if (memcmp(frame_out[k], image, n_floats * sizeof(float)) != 0 || frame_stats[k].rng_draws != stats.rng_draws) { fprintf(stderr, "frame %d in flight differs from the plain render\n", k); return 6; }
+            free(frame_out[k]);
+        }
+        rl_context_destroy(ctx2);
+    }
     f = fopen(argv[1], "wb");
     if (!f || fwrite(image, sizeof(float), n_floats, f) != n_floats) { fprintf(stderr, "cannot write %s\n", argv[1]); return 5; }
     fclose(f);

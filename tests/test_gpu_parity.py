@@ -1211,7 +1211,8 @@ def test_verbatim_reference_scene_renders_like_the_fixture(built):
 def test_c99_consumer_renders_the_same_image(built, tmp_path):
     """The drop-in boundary from plain C (gcc -std=c99 -pedantic, nothing but include/rustlight_amd.h + the shared library) — what a Rust FFI
     caller does, minus Rust: rl_scene_create_from_desc -> rl_context_create -> rl_generate_block_seeds -> rl_render_path with the CLI's
-    default parameters (reference-order streams).  Image and counters equal the ctypes binding's and the oracle's, bit for bit."""
+    default parameters (reference-order streams).  Image and counters equal the ctypes binding's and the oracle's, bit for bit.  The consumer then renders
+    the same frame twice more through rl_render_path_frames (two contexts, two frames in flight) and exits non-zero unless both equal the first."""
     import subprocess
     from rustlight_amd import abi
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
