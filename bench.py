@@ -444,7 +444,7 @@ def main():
             try:        # (an extra: a failure here — memory — must not cost the line the driver reads)
                 reference_order_in_flight = in_flight_record(
                     "cbox_1080p_128spp_reference_order_3_in_flight", "the reference-order frames above, three in flight (three device contexts, one host thread each; rustlight_amd.api.render_in_flight / "
-                    "IntegratorPathTracing.frames_in_flight, `rustlight-amd --frames-in-flight 3 -a ...`): throughput of independent frames, not the latency of one", api.STREAM_REFERENCE_ORDER, 9, rr["oracle_crc32"])
+                    "IntegratorPathTracing.frames_in_flight, `rustlight-amd --frames-in-flight 3 -a ...`): throughput of independent frames, not the latency of one", api.STREAM_REFERENCE_ORDER, 12, rr["oracle_crc32"])
                 in_flight_record("cbox_1080p_128spp_3_in_flight", "the headline's frames (per-sample streams), three in flight: the same", api.STREAM_PER_SAMPLE, 18,
                                  oracle_crc("cbox", 1920, 1080, 128, "per_sample", 2))
             except Exception as e:      # noqa: BLE001
