@@ -125,6 +125,21 @@ def oracle_crc(workload, width, height, spp, stream_mode, seed):
     return e["crc32"] if e else None
 
 
+def utilisation_fields(live, key, kernel, src_hash):
+    """The honest utilisation next to the nominal `frac`: from the counter summary of profiles/pmc_live.json for this workload — VALU issue slots
+    busy (SQ_INSTS_VALU x calibrated cycles per wave64 instruction / SIMD cycles), live lanes per issued VALU instruction (SQ_THREAD_CYCLES_VALU / 64 SQ_ACTIVE_INST_VALU)
+    and their product = the share of the chip's FP32 lane-slots doing work.  None when no entry exists for this workload and kernel; `pmc_current` says whether the
+    counters were collected on the kernel sources this run uses."""
+    e = (live or {}).get(key)
+    if not e or e.get("kernel") != kernel:
+        return None
+    busy = (e.get("valu_issue_model") or {}).get("valu_issue_busy")
+    lanes = e.get("lane_utilisation")
+    return {"valu_issue_busy": busy, "lane_utilisation": lanes, "valu_lane_slots_used": (busy * lanes) if (busy is not None and lanes is not None) else None,
+            "wave_time_waiting": (e.get("wave_time_shares") or {}).get("SQ_WAIT_ANY"), "l2_hit_rate": e.get("l2_hit_rate"), "hbm_bytes_per_launch": e.get("hbm_bytes_per_launch"),
+            "kernel_ms_under_profiler": e.get("kernel_ms_under_profiler"), "pmc_current": e.get("kernel_src_hash") == src_hash, "pmc_commit": e.get("commit")}
+
+
 def pipeline_bytes(stats_sum, pixels, steps):
     """SURVEY.md §8(d) / DESIGN.md §4: algorithmic bytes of the whole pipeline = 248 B / camera sample + 352 B / expanded vertex + 12 B / pixel."""
     return 248 * stats_sum["camera_samples"] + 352 * stats_sum["vertices"] + 12 * pixels * steps
@@ -170,6 +185,31 @@ def main():
         raise SystemExit(f"bench.py --gpus {args.gpus} is running with WORLD_SIZE={world}: launch it with --nproc-per-node {args.gpus} (or without a launcher)")
     if world > 1:
         assert dist.is_initialized() and dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+    # ---- N > 1 on a box that HAS N devices: the collective must be RCCL over N distinct GPUs, or the run is not a scaling measurement and must not look like one
+    # (non-zero exit: the driver's SCALE record then shows the failure instead of a number measured through gloo or on shared devices)
+    rccl_check = None
+    if world > 1 and not shared:
+        problems = []
+        if backend != "nccl": problems.append(f"backend is {backend!r}, not nccl (= RCCL)")
+        if n_dev < world: problems.append(f"{n_dev} devices visible for {world} ranks")
+        try:
+            props = torch.cuda.get_device_properties(device_index)
+            ident = f"{getattr(props, 'uuid', '')}|{getattr(props, 'pci_bus_id', '')}|{getattr(props, 'pci_device_id', '')}|{device_index}"
+        except Exception as e:      # noqa: BLE001
+            ident = f"?{e!r}|{device_index}"
+        with _Watchdog("the RCCL check (all_gather_object + all_reduce of ones)", args.init_timeout, who):
+            idents = rd.gather_objects(ident)            # every rank's device identity, on every rank
+            ones = torch.ones(1, device=dev)
+            dist.all_reduce(ones)                        # a device-side collective: N ranks must have contributed
+            torch.cuda.synchronize()
+            if int(ones.item()) != world: problems.append(f"all_reduce of ones gave {ones.item()} on {world} ranks")
+            if len(set(idents)) != world: problems.append(f"ranks do not sit on {world} distinct devices: {idents}")
+            bad = rd.max_over_ranks(1.0 if problems else 0.0)
+        rccl_check = {"backend": backend, "world_size": world, "devices_visible": n_dev, "distinct_devices": len(set(idents)), "all_reduce_of_ones": int(ones.item()), "ok": not problems}
+        if bad:
+            print(f"bench.py: --gpus {args.gpus} is not an RCCL run over {world} GPUs: {problems or 'another rank failed its check'}: {json.dumps(who)}", file=sys.stderr, flush=True)
+            rd.finalize()
+            raise SystemExit(4)
 
     # ONE explicit stream for everything a step enqueues (render, reduce, download): torch's default stream has handle 0, which the C-ABI
     # reads as "use the context's own stream" — the next step's framebuffer memset would then race the previous step's reduce / download
@@ -306,6 +346,21 @@ def main():
                          "value": rrec["samples_per_step"] * 2 / rrec["dt"] / 1e6, "unit": "Msamples/s", "ranks": per_rank,
                          "image_crc32": f"{zlib.crc32(rrec['host_img'].tobytes()):08x}", "three_frames_in_flight": in_flight}
 
+    # ---- N > 1, weak default: the strong-scaling pair in the same invocation — the same frame as the 1-GPU run (spp in TOTAL, tiles split N ways), both
+    # stream modes, 3 steps each: the N-GPU images must carry the CRCs the oracle gave for the 1-GPU frames (seed 2)
+    strong = None
+    if world > 1 and args.scaling == "weak" and args.scene == "cbox" and args.stream_mode == "per_sample" and args.numerics == "exact" and not args.no_also:
+        strong = []
+        for mode in ("per_sample", "reference"):
+            srec = time_workload(ctx, args.width, args.height, args.spp, mode, "exact", 3, 1, shard=(rank, world))
+            per_rank = rd.gather_objects({"rank": rank, "kernel_ms": srec["ms"]["ms_other"] / 3, "chain_ms": srec["ms"]["ms_prepass"] / 3, "reduce_ms": srec["reduce_ms"]})
+            if rank == 0:
+                crc_s = f"{zlib.crc32(srec['host_img'].tobytes()):08x}"
+                want_s = oracle_crc("cbox", args.width, args.height, args.spp, mode, 2)
+                strong.append({"workload": f"cbox {args.width}x{args.height}x{args.spp}spp in total on {world} shards, {mode} streams (strong scaling)", "stream_mode": mode, "steps": 3,
+                               "ms_per_step": srec["dt"] / 3 * 1e3, "value": srec["samples_per_step"] * 3 / srec["dt"] / 1e6, "unit": "Msamples/s", "ranks": per_rank,
+                               "image_crc32": crc_s, "oracle_crc32": want_s, "oracle_crc_match": None if want_s is None else want_s == crc_s})
+
     if rank == 0:
         # ---- the N-GPU image must be the 1-GPU image, bit for bit (sums with zeros are exact): re-render the last step's
         # frame on this GPU alone, untimed, and compare CRCs
@@ -349,7 +404,7 @@ def main():
         # PMC numbers are NOT collected in this run (rocprofv3 --pmc needs its own passes: scratch/pmc_collect.sh).  They are quoted
         # only when they were collected on this very kernel source (hash of csrc/kernels + flags), with their provenance.
         src_hash = provenance.kernel_source_hash()
-        traffic, pmc_entry = None, None
+        traffic, pmc_entry, live = None, None, None
         try:
             live = json.load(open(os.path.join(ROOT, "profiles", "pmc_live.json")))
             key = f"{args.scene}{':tris' + str(args.tris) if args.tris else ''}:{args.width}x{args.height}x{args.spp}:{args.stream_mode}:{args.numerics}"
@@ -369,6 +424,10 @@ def main():
                     "pipeline_algorithmic_GBps": pipe_bytes / dt / 1e9, "pipeline_frac": pipe_bytes / dt / 1e9 / PEAK_HBM_GBPS,
                     "rays_per_s": (agg_all["extension_rays"] + agg_all["shadow_rays"]) / dt,
                     "kernel_src_hash": src_hash, "pmc": pmc_entry}
+        # the honest utilisation, first-class next to the nominal `frac`: what share of the VALU issue slots is busy, how many of the 64 lanes of an issued instruction are
+        # live, and the product (None when this workload has no counter summary; `pmc_current` false when it was collected on other kernel sources)
+        util = utilisation_fields(live, f"{args.scene}{':tris' + str(args.tris) if args.tris else ''}:{args.width}x{args.height}x{args.spp}:{args.stream_mode}:{args.numerics}", dominant, src_hash) if world == 1 else None
+        roofline.update({k: (util or {}).get(k) for k in ("valu_issue_busy", "lane_utilisation", "valu_lane_slots_used", "wave_time_waiting", "pmc_current")})
 
         # ---- `also`: the other BASELINE configurations and stream modes, timed the same way in this process (default single-GPU run only)
         also, reference_order_value = None, None
@@ -393,6 +452,11 @@ def main():
                 r["oracle_crc_match"] = None if want is None else want == r["image_crc32"]        # the last timed frame against the CPU oracle's render of it
                 if rec["spec"]["spec_group"]:
                     r["chain_pass"] = dict(rec["spec"], note="k_stream_spec: lanes per block, samples walked speculatively / serially / by the estimate probes in the last step")
+                # utilisation of the record's longest kernel, when profiles/pmc_live.json holds its counters
+                longest = max(kernel_ms, key=kernel_ms.get) if kernel_ms else None
+                u = utilisation_fields(live, f"{scene_name}:{width}x{height}x{rec['spp']}:{rec['stream_mode']}:exact", longest, src_hash)
+                if u is not None:
+                    r["utilisation"] = dict(u, kernel=longest)
                 r.update(extra or {})
                 also.append(r)
                 return r
@@ -463,6 +527,11 @@ def main():
                 t_build = time.perf_counter() - t_build
                 r = time_workload(ctx2, w, h, 128, "per_sample", "exact", steps, 1)
                 sub(tag, r, what, {"context_build_s": round(t_build, 2), "triangles": int(sd2.n_triangles)}, scene_name=name)
+                if name != "cbox":
+                    # the drop-in default on the two slow configs: rustlight's own reference-order streams, ONE timed step (seed 0) after one
+                    # warm-up render, against the oracle's CRC of that frame — the weakest numbers of the product's default mode, driver-timed
+                    r = time_workload(ctx2, w, h, 128, "reference", "exact", 1, 1)
+                    sub(tag + "_reference_order", r, what + " — in RL_STREAM_REFERENCE_ORDER (the plugin / CLI default): chain pass + k_path_fused", {"triangles": int(sd2.n_triangles)}, scene_name=name)
                 ctx2.close()
 
         cpu = None
@@ -510,6 +579,9 @@ def main():
         want = oracle_crc(args.scene, args.width, args.height, spp_total, args.stream_mode, args.steps - 1) if world == 1 and args.numerics == "exact" and args.tris == 0 else None
         out["oracle_crc32"] = want
         out["oracle_crc_match"] = None if want is None else want == f"{crc:08x}"        # the last timed frame == the CPU oracle's render of the same frame (tests/golden/bench_crcs.json)
+        out["distributed"]["rccl_check"] = rccl_check
+        if strong is not None:
+            out["strong_scaling"] = strong
         if ref_multi is not None:
             out["reference_order_value"] = ref_multi["value"]
             out["reference_order_in_flight_value"] = ref_multi["three_frames_in_flight"].get("value")

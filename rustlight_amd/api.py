@@ -452,6 +452,22 @@ class Context:
         _check(fn(self.h, n, abi.fptr(o), abi.fptr(d), abi.fptr(t), m.ctypes.data_as(i32p), tr.ctypes.data_as(i32p), st.ctypes.data_as(i32p)))
         return t, m, tr, st
 
+    def trace_two_level(self, origins, directions, segment_lengths=None):
+        """Test hook: rl_trace_batch through the two-level node records (trace.hip.h: traverse2): (t, u, v, mesh, tri, node trips per ray); with `segment_lengths`
+        the any-hit form: (found, node trips per ray)."""
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        any_hit = segment_lengths is not None
+        t = np.ascontiguousarray(segment_lengths, dtype=np.float32).copy() if any_hit else np.zeros(n, np.float32)
+        u = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+        m = np.zeros(n, np.int32); tr = np.zeros(n, np.int32); st = np.zeros(n, np.int32)
+        i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+        fn = lib().rl_debug_trace_batch_two_level
+        fn.argtypes = [C.c_void_p, C.c_size_t, f32p, f32p, f32p, f32p, f32p, i32p, i32p, i32p, C.c_int]
+        _check(fn(self.h, n, abi.fptr(o), abi.fptr(d), abi.fptr(t), abi.fptr(u), abi.fptr(v), m.ctypes.data_as(i32p), tr.ctypes.data_as(i32p), st.ctypes.data_as(i32p), int(any_hit)))
+        return (t != 0.0, st) if any_hit else (t, u, v, m, tr, st)
+
     def visible(self, p0, p1):
         a = np.ascontiguousarray(p0, dtype=np.float32).reshape(-1, 3)
         b = np.ascontiguousarray(p1, dtype=np.float32).reshape(-1, 3)

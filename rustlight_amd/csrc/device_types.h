@@ -21,6 +21,24 @@ struct alignas(16) BvhNode {
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 static const int32_t RL_CHILD_NONE = (int32_t)0x80000000;
 
+// ---- two-level record of the exact build on scenes that stream their BVH (round 5): node N with the exact f32 boxes of its (up to four) GRANDCHILDREN,
+// so that one fetch decides two levels of the reference's recursion (src/accel.rs:256-287) with the identical comparisons in the identical order:
+// AABB::intersect (src/structure.rs:849-869) reads the ray and the box only — never its.t — so the slab result of a grandchild box is the same number whether it is
+// evaluated on this trip or on the next, and its.t cannot change in between (no triangle is tested between a node and its near child).  A child's own box is the
+// exact min / max union of its two children's (range_box folds the same primitive boxes with the same fmin / fmax; the host checks every node, bvh.cpp:
+// two_level_nodes), so the record needs no child boxes: the child's slab distances are the min / max of its two slots' per-axis distances (the plane -> distance
+// map (p - o) * (1 / d) is monotone for a finite ray; rays with a zero / infinite / NaN component take the union of the PLANES instead: trace.hip.h, traverse2).
+// Slots 2c, 2c + 1 belong to child c.  A child that is a leaf — or an inner node whose box failed the host's union check — is NOT expanded: its own box and
+// reference sit in slot 2c and slot 2c + 1 is empty (lo = +inf, hi = -inf, RL_CHILD_NONE).  Plane-major: one float4 per plane holds the four slots.
+struct alignas(16) BvhNode2 {
+    float lox[4], loy[4], loz[4];
+    float hix[4], hiy[4], hiz[4];
+    int32_t slot[4];          // child encoding as in BvhNode; inner indices refer to this array (same numbering as `nodes`)
+    int32_t child[2];         // the two children themselves (what the traversal stack holds)
+    int32_t pad[2];
+};
+static_assert(sizeof(BvhNode2) == 128, "BvhNode2 must be 128 bytes");
+
 // ---- BVH4 node of the tolerance build (`numerics = fast`, scenes that stream their BVH): the SAME BVH2 collapsed two levels at a time
 // (host: build_bvh4) with the child boxes quantised to 8 bits per plane on the node's own grid — conservatively (a quantised box contains the
 // child box), so a traversal visits a superset of the leaves the BVH2 visits.  One 64-byte fetch decides four children: about half the node
@@ -146,6 +164,8 @@ struct DeviceScene {
     // a whole block with the idle lanes of a chain's group and walks up to four levels without another round trip to memory (null when the scene is staged in LDS)
     const BvhNode* nodes_t;
     int32_t root_t;
+    // exact build on streaming scenes: the two-level records (same node numbering as `nodes`; always uploaded: rl_trace_batch reads them on every scene)
+    const BvhNode2* nodes2;
     // tolerance build on streaming scenes: the BVH2 above collapsed into quantised BVH4 nodes (null / NONE when the scene is staged in LDS)
     const Bvh4Node* nodes4;
     int32_t root4;

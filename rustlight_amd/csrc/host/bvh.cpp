@@ -177,6 +177,46 @@ static double area_of(const Child2& c) {
 }
 }  // namespace
 
+void two_level_nodes(const BvhBuild& bvh, std::vector<BvhNode2>* out, uint64_t* stats3) {
+    out->assign(bvh.nodes.size(), BvhNode2{});
+    uint64_t n_exp = 0, n_leaf = 0, n_plain = 0;
+    // a == b as boxes: every plane equal as a float (+0 == -0: the sign of a zero plane never reaches a verdict or a distance — entry distances are >= tnear > 0);
+    // range_box never produces a NaN plane (fmin / fmax from +-FLT_MAX skip NaN vertices), so a NaN here only means "do not expand"
+    auto same = [](const Child2& a, const float lo[3], const float hi[3]) {
+        for (int k = 0; k < 3; k++) if (!(a.lo[k] == lo[k]) || !(a.hi[k] == hi[k])) return false;
+        return true;
+    };
+    for (size_t i = 0; i < bvh.nodes.size(); i++) {
+        BvhNode2& r = (*out)[i];
+        Child2 ch[2];
+        children_of(bvh.nodes[i], &ch[0], &ch[1]);
+        for (int c = 0; c < 2; c++) {
+            r.child[c] = ch[c].code;
+            Child2 g[2];
+            bool expand = false;
+            if (ch[c].code >= 0) {
+                children_of(bvh.nodes[ch[c].code], &g[0], &g[1]);
+                float lo[3], hi[3];
+                for (int k = 0; k < 3; k++) { lo[k] = std::fmin(g[0].lo[k], g[1].lo[k]); hi[k] = std::fmax(g[0].hi[k], g[1].hi[k]); }     // AABB::union_aabb (structure.rs:779-784)
+                expand = same(ch[c], lo, hi) && g[0].code != RL_CHILD_NONE && g[1].code != RL_CHILD_NONE;
+                if (expand) n_exp++; else n_plain++;
+            } else n_leaf++;
+            if (!expand) {
+                g[0] = ch[c];
+                g[1].code = RL_CHILD_NONE;
+                for (int k = 0; k < 3; k++) { g[1].lo[k] = INFINITY; g[1].hi[k] = -INFINITY; }      // the identity of the union, never entered
+            }
+            for (int s = 0; s < 2; s++) {
+                const int q = 2 * c + s;
+                r.lox[q] = g[s].lo[0]; r.loy[q] = g[s].lo[1]; r.loz[q] = g[s].lo[2];
+                r.hix[q] = g[s].hi[0]; r.hiy[q] = g[s].hi[1]; r.hiz[q] = g[s].hi[2];
+                r.slot[q] = g[s].code;
+            }
+        }
+    }
+    if (stats3) { stats3[0] = n_exp; stats3[1] = n_leaf; stats3[2] = n_plain; }
+}
+
 void treelet_blocks(const BvhBuild& bvh, std::vector<BvhNode>* nodes_out, int32_t* root_out) {
     nodes_out->clear();
     *root_out = bvh.root;
@@ -303,6 +343,58 @@ void build_bvh4(const BvhBuild& bvh, Bvh4Build* out) {
 // Host-only check of the two structures derived from the BVH2 (test hook, no GPU): the treelet-blocked copy must be the same tree (same boxes, same
 // leaves, every inner node in exactly one slot), and every BVH4 node must cover the same set of BVH2 subtrees with boxes that contain the originals.
 // out[0] = BVH2 inner nodes, [1] = slots of the blocked copy, [2] = BVH4 nodes, [3] = violations found, [4] = BVH4 leaves, [5] = BVH2 leaves.
+// Host-only check of the two-level records (test hook, no GPU): walking them two levels at a time must meet the very nodes, boxes and leaves of the BVH2, every
+// expanded child's box must be the union of its slots.  out[0] = BVH2 inner nodes, [1] = expanded children, [2] = leaf children, [3] = inner children left
+// unexpanded, [4] = violations, [5] = leaves reached through the records.
+extern "C" int rl_debug_check_two_level(const rl_scene* scene, uint64_t* out6) {
+    using namespace rl;
+    if (!scene || !out6) return -1;
+    BvhBuild bvh;
+    build_bvh(*scene, &bvh);
+    std::vector<BvhNode2> n2;
+    uint64_t st[3] = {0, 0, 0};
+    two_level_nodes(bvh, &n2, st);
+    uint64_t bad = 0, leaves = 0;
+    if (n2.size() != bvh.nodes.size()) bad++;
+    std::vector<char> seen(bvh.nodes.size(), 0);
+    std::vector<int32_t> todo;
+    if (bvh.root >= 0) todo.push_back(bvh.root);
+    while (!todo.empty() && !bad) {
+        const int32_t i = todo.back();
+        todo.pop_back();
+        if (i < 0 || (size_t)i >= n2.size() || seen[i]) { bad++; break; }
+        seen[i] = 1;
+        const BvhNode2& r = n2[i];
+        Child2 ch[2];
+        children_of(bvh.nodes[i], &ch[0], &ch[1]);
+        for (int c = 0; c < 2; c++) {
+            if (r.child[c] != ch[c].code) bad++;
+            const int a = 2 * c, b = a + 1;
+            const float lo[3] = {std::fmin(r.lox[a], r.lox[b]), std::fmin(r.loy[a], r.loy[b]), std::fmin(r.loz[a], r.loz[b])};
+            const float hi[3] = {std::fmax(r.hix[a], r.hix[b]), std::fmax(r.hiy[a], r.hiy[b]), std::fmax(r.hiz[a], r.hiz[b])};
+            for (int k = 0; k < 3; k++) if (!(lo[k] == ch[c].lo[k]) || !(hi[k] == ch[c].hi[k])) bad++;        // the union of the slots IS the child's box
+            if (r.slot[b] == RL_CHILD_NONE) {         // not expanded: the child itself
+                if (r.slot[a] != ch[c].code) bad++;
+                if (ch[c].code >= 0) todo.push_back(ch[c].code); else if (ch[c].code != RL_CHILD_NONE) leaves++;
+            } else {
+                if (ch[c].code < 0) { bad++; continue; }
+                Child2 g[2];
+                children_of(bvh.nodes[ch[c].code], &g[0], &g[1]);
+                for (int s = 0; s < 2; s++) {
+                    const int q = a + s;
+                    if (r.slot[q] != g[s].code) bad++;
+                    const float bl[3] = {r.lox[q], r.loy[q], r.loz[q]}, bh[3] = {r.hix[q], r.hiy[q], r.hiz[q]};
+                    if (std::memcmp(bl, g[s].lo, 12) != 0 || std::memcmp(bh, g[s].hi, 12) != 0) bad++;
+                }
+                todo.push_back(ch[c].code);                // (its own record is what a traversal fetches when the child is popped from the stack)
+            }
+        }
+    }
+    for (size_t i = 0; i < seen.size(); i++) if (bvh.root >= 0 && !seen[i]) bad++;
+    out6[0] = bvh.nodes.size(); out6[1] = st[0]; out6[2] = st[1]; out6[3] = st[2]; out6[4] = bad; out6[5] = leaves;
+    return 0;
+}
+
 extern "C" int rl_debug_check_derived_bvhs(const rl_scene* scene, uint64_t* out6) {
     using namespace rl;
     if (!scene || !out6) return -1;

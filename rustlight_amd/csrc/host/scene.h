@@ -94,6 +94,10 @@ void build_bvh(const rl_scene& scene, BvhBuild* out);
 // The inner nodes of `bvh` re-laid in blocks of 16 slots: a block holds one treelet (a connected piece of the tree around its root, chosen largest box first) or
 // several small ones; references are renumbered (block * 16 + slot), boxes and leaves untouched — every traversal visits the same nodes in the same order.
 void treelet_blocks(const BvhBuild& bvh, std::vector<BvhNode>* nodes_out, int32_t* root_out);
+// Two-level records of the exact build (device_types.h: BvhNode2): node i of `bvh.nodes` with its grandchildren's boxes.  A child is expanded only when it is an
+// inner node whose stored box equals the fmin / fmax union of its own two children's boxes (always, for boxes made by range_box; checked here so that the
+// kernel's shortcut is right by construction).  stats (optional): [0] expanded children, [1] leaf children, [2] inner children left unexpanded by the check.
+void two_level_nodes(const BvhBuild& bvh, std::vector<BvhNode2>* out, uint64_t* stats3 = nullptr);
 // The tolerance build's BVH4 (device_types.h: Bvh4Node): the BVH2 of `bvh` collapsed — the child with the largest box is replaced by its own two
 // children until a node has four (or only leaves are left) — and its child boxes quantised conservatively.  Same leaves, same triangle order.
 struct Bvh4Build { std::vector<Bvh4Node> nodes; int32_t root = RL_CHILD_NONE; uint32_t stack_depth = 1; };

@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_CHAIN_WAVES : RL_CHAIN_WAV
         recs.nodes = smem; recs.tris = smem + lds_nodes_float4s(sc0.n_nodes);
         after_scene = smem + lds_scene_float4s(sc0.n_nodes, sc0.n_prims);
     } else {
-        recs.nodes = TravStackT<false>::kBvh4 ? reinterpret_cast<const float4*>(sc0.nodes4) : reinterpret_cast<const float4*>(sc0.nodes);   // tolerance build: quantised BVH4 nodes
+        recs.nodes = streamed_nodes<TravStackT<false>>(sc0);   // exact build: two-level records; tolerance build: quantised BVH4 nodes
         recs.tris = reinterpret_cast<const float4*>(sc0.tris);
     }
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;

@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
         recs.nodes = smem; recs.tris = smem + lds_nodes_float4s(sc.n_nodes);
         after_scene = smem + lds_scene_float4s(sc.n_nodes, sc.n_prims);
     } else {
-        recs.nodes = TravStackT<false>::kBvh4 ? reinterpret_cast<const float4*>(sc.nodes4) : reinterpret_cast<const float4*>(sc.nodes);   // tolerance build: quantised BVH4 nodes
+        recs.nodes = streamed_nodes<TravStackT<false>>(sc);   // exact build: two-level records; tolerance build: quantised BVH4 nodes
         recs.tris = reinterpret_cast<const float4*>(sc.tris);
     }
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;

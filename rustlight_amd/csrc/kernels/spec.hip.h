@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
         recs.nodes = smem; recs.tris = smem + lds_nodes_float4s(sc0.n_nodes);
         after_scene = smem + lds_scene_float4s(sc0.n_nodes, sc0.n_prims);
     } else {
-        recs.nodes = reinterpret_cast<const float4*>(sc0.nodes);
+        recs.nodes = streamed_nodes<TravStackT<false>>(sc0);
         recs.tris = reinterpret_cast<const float4*>(sc0.tris);
     }
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, tid0 = blockIdx.x * blockDim.x;

@@ -157,6 +157,13 @@ struct SceneRecs {
 // in LDS (96 B/lane) lets 8 waves/SIMD stay resident on scenes whose BVH is 20-40 levels deep.
 struct NodeFetchLds;
 struct NodeFetchGlobal;
+#ifndef RL_TWO_LEVEL
+// 1: scenes that stream their BVH traverse the two-level records (traverse2) in the exact build.  OFF: measured slower — 508 k triangles, 1080p x 128 spp: node trips per
+// ray 19.1 -> 10.5, k_path_fused 305 -> 374 ms, same CRC (profiles/NEGATIVES.md, round 5): the kernel pays per ISSUED instruction (64-lane instructions at 22 % live lanes),
+// not per dependent round trip, and a two-level trip issues twice the loads and slab arithmetic of a one-level trip.  The construction stays tested through
+// TravStack2 / rl_debug_trace_batch_two_level.
+#define RL_TWO_LEVEL 0
+#endif
 template <bool LDS_ONLY>
 struct TravStackT {
     using NodeFetch = typename std::conditional<LDS_ONLY, NodeFetchLds, NodeFetchGlobal>::type;   // LDS-only stacks go with LDS-staged scenes
@@ -165,6 +172,11 @@ struct TravStackT {
     static constexpr bool kBvh4 = !LDS_ONLY;       // tolerance build, streaming scenes: quantised BVH4 nodes (traverse4)
 #else
     static constexpr bool kBvh4 = false;
+#endif
+#if RL_TWO_LEVEL && !defined(RL_FAST_MATH)
+    static constexpr bool kTwoLevel = !LDS_ONLY;   // exact build, streaming scenes: two-level records (device_types.h: BvhNode2; traverse2)
+#else
+    static constexpr bool kTwoLevel = false;
 #endif
     static constexpr int kTriStride4 = LDS_ONLY ? kLdsTriStride4 : 4;                              // float4s between triangle records
     static constexpr int kNodeRefScale = LDS_ONLY ? 4 * kLdsNodeStride : 1;                        // inner-node reference = index x this (LDS: byte offset)
@@ -210,6 +222,11 @@ struct TravStackT {
     }
 };
 using TravStack = TravStackT<false>;
+struct TravStack2 : TravStackT<false> {          // the same stack, traversed through the two-level records whatever RL_TWO_LEVEL says (test hook)
+    static constexpr bool kTwoLevel = true;
+    static constexpr bool kBvh4 = false;
+    RL_DEV explicit TravStack2(const TravStackT<false>& s) : TravStackT<false>(s) {}
+};
 
 // One inner node: both child boxes against the ray, verdicts already folded with the current closest hit.
 // `AABB::intersect` clips the far plane with the ray's tfar and the caller then asks `d < its.t` (accel.rs:262-284); its.t never
@@ -287,11 +304,19 @@ struct NodeFetchGlobal {
 #endif
 template <bool ANY_HIT, class Stack>
 RL_DEV bool traverse4(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3 o, V3 d, float tnear, float tfar, Hit& hit, const Stack& st);
+template <bool ANY_HIT, class Stack>
+RL_DEV bool traverse2(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3 o, V3 d, float tnear, float tfar, Hit& hit, const Stack& st);
+// the node array `traverse` reads through a stack of type Stack on a scene that streams its BVH (root: sc.root4 for the BVH4, else sc.root)
+template <class Stack>
+RL_DEV const float4* streamed_nodes(const DeviceScene& sc) {
+    return Stack::kBvh4 ? reinterpret_cast<const float4*>(sc.nodes4) : (Stack::kTwoLevel ? reinterpret_cast<const float4*>(sc.nodes2) : reinterpret_cast<const float4*>(sc.nodes));
+}
 
 template <bool ANY_HIT, class Stack>
 RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3 o, V3 d, float tnear, float tfar,
                      Hit& hit, const Stack& st) {
     if constexpr (Stack::kBvh4) return traverse4<ANY_HIT>(recs, root, root_lo, root_hi, o, d, tnear, tfar, hit, st);
+    if constexpr (Stack::kTwoLevel) return traverse2<ANY_HIT>(recs, root, root_lo, root_hi, o, d, tnear, tfar, hit, st);
     V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
     float dummy;
     int cur = root >= 0 ? root * Stack::kNodeRefScale : root;
@@ -411,6 +436,149 @@ RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3
     }
     if (!ANY_HIT && found) {   // barycentrics of the closest hit (see tri_test)
         const float4* q = recs.tris + Stack::kTriStride4 * hit.prim;
+        tri_uv(q[0], q[1], q[2], q[3], o, d, hit.t, &hit.u, &hit.v);
+    }
+    return found;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// traverse2 — the exact build's traversal of scenes that stream their BVH (round 5): two levels of the reference's recursion per fetched record
+// (device_types.h: BvhNode2; host: two_level_nodes).  The streaming kernels are bound by the latency of a ray's DEPENDENT record fetches (~19 per ray on the
+// 508 k-triangle scene; profiles/NEGATIVES.md round 4); a record that carries the grandchildren's exact boxes halves the chain at 2 x the bytes per fetch.
+//
+// Same visits, same order, same bits as `traverse` — by construction:
+//  * AABB::intersect (src/structure.rs:849-869) is a pure function of (ray, tnear, tfar, box); its.t enters only through `if d < its.t` (accel.rs:277-284), folded
+//    into the far clip exactly as in `traverse`.  Between a node's trip and its near child's trip no triangle is tested, so its.t — hence every verdict and
+//    distance of the child's trip — is already decided when the node's record arrives.
+//  * the child boxes are not stored: child c is the min / max union of slots 2c, 2c + 1 (checked per node on the host).  The per-axis plane -> distance map
+//    g(p) = (p - o) * (1 / d) is monotone under round-to-nearest (non-decreasing for 1 / d > 0, non-increasing for 1 / d < 0) whenever 1 / d is finite and non-zero
+//    and o is finite, and no NaN arises then (box planes are never NaN; an empty slot's +-inf planes map to +-inf), so g(min(p, q)) = min(g(p), g(q)) exactly:
+//    the child's near distances are the minima of its slots' near distances, its far distances the maxima.  A ray with a zero / infinite / NaN direction component
+//    or a non-finite origin (0 * inf = NaN planes the reference's compare chain skips) takes the union of the PLANES and then the one-level arithmetic (`unsafe`).
+//  * second level: the entered child's two slots with the same tnear and the same its.t — the one-level trip at that child, operation for operation.
+template <bool ANY_HIT, class Stack>
+RL_DEV bool traverse2(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3 o, V3 d, float tnear, float tfar, Hit& hit, const Stack& st) {
+    const V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
+    float dummy;
+    int cur = root;
+    if (!slab(root_lo, root_hi, o, inv_d, tnear, tfar, &dummy)) cur = RL_CHILD_NONE;   // accel.rs:293-295 / 338-340
+    int sp = 0;
+    bool found = false;
+    constexpr int kPop = -1;
+    const bool sx = inv_d.x < 0.0f, sy = inv_d.y < 0.0f, sz = inv_d.z < 0.0f;
+    const float ax = __builtin_fabsf(inv_d.x), ay = __builtin_fabsf(inv_d.y), az = __builtin_fabsf(inv_d.z);
+    const float inf = f32_inf();
+    const bool unsafe = !((ax > 0.0f) & (ax < inf) & (ay > 0.0f) & (ay < inf) & (az > 0.0f) & (az < inf) &
+                          (__builtin_fabsf(o.x) < inf) & (__builtin_fabsf(o.y) < inf) & (__builtin_fabsf(o.z) < inf));
+    auto node_trip = [&]() {
+        if (cur >= 0) {
+            hit.steps++;
+            f4v lox, loy, loz, hix, hiy, hiz, sl, ch;
+            const int cur0 = __builtin_amdgcn_readfirstlane(cur);
+            if (RL_UNIFORM_TRIPS && __ballot(cur != cur0) == 0ull) {      // every lane holds the same node: through the scalar cache
+                const F4c* q = (const F4c*)(recs.nodes) + 8 * cur0;
+                lox = q[0]; loy = q[1]; loz = q[2]; hix = q[3]; hiy = q[4]; hiz = q[5]; sl = q[6]; ch = q[7];
+            } else {
+                const f4v* q = reinterpret_cast<const f4v*>(recs.nodes) + 8 * cur;
+                lox = q[0]; loy = q[1]; loz = q[2]; hix = q[3]; hiy = q[4]; hiz = q[5]; sl = q[6]; ch = q[7];
+            }
+            float nx[4], ny[4], nz[4], fx[4], fy[4], fz[4], tn[4], tf[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                nx[k] = ((sx ? hix[k] : lox[k]) - o.x) * inv_d.x; fx[k] = ((sx ? lox[k] : hix[k]) - o.x) * inv_d.x;
+                ny[k] = ((sy ? hiy[k] : loy[k]) - o.y) * inv_d.y; fy[k] = ((sy ? loy[k] : hiy[k]) - o.y) * inv_d.y;
+                nz[k] = ((sz ? hiz[k] : loz[k]) - o.z) * inv_d.z; fz[k] = ((sz ? loz[k] : hiz[k]) - o.z) * inv_d.z;
+                tn[k] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx[k], ny[k]), nz[k]), tnear);
+                tf[k] = __builtin_fminf(__builtin_fminf(fx[k], fy[k]), fz[k]);       // (unclipped: the clip with its.t is applied where the level is decided)
+            }
+            // first level: the two children, each the union of its two slots
+            float d1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(nx[0], nx[1]), __builtin_fminf(ny[0], ny[1])), __builtin_fminf(nz[0], nz[1])), tnear);
+            float f1 = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaxf(fx[0], fx[1]), __builtin_fmaxf(fy[0], fy[1])), __builtin_fmaxf(fz[0], fz[1])), hit.t);
+            float d2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(nx[2], nx[3]), __builtin_fminf(ny[2], ny[3])), __builtin_fminf(nz[2], nz[3])), tnear);
+            float f2 = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaxf(fx[2], fx[3]), __builtin_fmaxf(fy[2], fy[3])), __builtin_fmaxf(fz[2], fz[3])), hit.t);
+            if (__ballot(unsafe) != 0ull) {       // (wave-uniform; a ray along an axis: ~2^-23 of the cosine-sampled directions)
+                if (unsafe) {
+                    // the union of the planes (AABB::union_aabb), then the one-level trip's arithmetic on the child boxes
+#define RL_UN(S, HI, LO, A, B) (S ? __builtin_fmaxf(HI[A], HI[B]) : __builtin_fminf(LO[A], LO[B]))
+#define RL_UF(S, HI, LO, A, B) (S ? __builtin_fminf(LO[A], LO[B]) : __builtin_fmaxf(HI[A], HI[B]))
+                    d1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((RL_UN(sx, hix, lox, 0, 1) - o.x) * inv_d.x, (RL_UN(sy, hiy, loy, 0, 1) - o.y) * inv_d.y), (RL_UN(sz, hiz, loz, 0, 1) - o.z) * inv_d.z), tnear);
+                    f1 = __builtin_fminf(__builtin_fminf(__builtin_fminf((RL_UF(sx, hix, lox, 0, 1) - o.x) * inv_d.x, (RL_UF(sy, hiy, loy, 0, 1) - o.y) * inv_d.y), (RL_UF(sz, hiz, loz, 0, 1) - o.z) * inv_d.z), hit.t);
+                    d2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((RL_UN(sx, hix, lox, 2, 3) - o.x) * inv_d.x, (RL_UN(sy, hiy, loy, 2, 3) - o.y) * inv_d.y), (RL_UN(sz, hiz, loz, 2, 3) - o.z) * inv_d.z), tnear);
+                    f2 = __builtin_fminf(__builtin_fminf(__builtin_fminf((RL_UF(sx, hix, lox, 2, 3) - o.x) * inv_d.x, (RL_UF(sy, hiy, loy, 2, 3) - o.y) * inv_d.y), (RL_UF(sz, hiz, loz, 2, 3) - o.z) * inv_d.z), hit.t);
+#undef RL_UN
+#undef RL_UF
+                }
+            }
+            const bool v1 = !(f1 <= d1), v2 = !(f2 <= d2);                 // box hit and entry distance < its.t
+            const bool right_first = v2 & (!v1 | (d1 > d2));               // missed box = +inf, ties keep the left child first
+            const bool both = v1 & v2, any = v1 | v2;
+            const int c0 = __float_as_int(ch[0]), c1 = __float_as_int(ch[1]);
+            st.push(sp, right_first ? c0 : c1, right_first ? d1 : d2, both);
+            sp += both ? 1 : 0;
+            // second level: the entered child's own trip (accel.rs:256-287 once more), decided now — its.t cannot change before it
+            const int s0 = __float_as_int(sl[0]), s1 = __float_as_int(sl[1]), s2 = __float_as_int(sl[2]), s3 = __float_as_int(sl[3]);
+            const int sa = right_first ? s2 : s0, sb = right_first ? s3 : s1;
+            const float da = right_first ? tn[2] : tn[0], db = right_first ? tn[3] : tn[1];
+            const float fa = __builtin_fminf(right_first ? tf[2] : tf[0], hit.t), fb = __builtin_fminf(right_first ? tf[3] : tf[1], hit.t);
+            const bool expanded = sb != RL_CHILD_NONE;                     // else slot a is the child itself (a leaf, or an inner node the host left whole)
+            const bool va = !(fa <= da), vb = !(fb <= db);
+            const bool rf2 = vb & (!va | (da > db));
+            const bool both2 = expanded & any & va & vb;
+            st.push(sp, rf2 ? sa : sb, rf2 ? da : db, both2);
+            sp += both2 ? 1 : 0;
+            cur = !any ? kPop : (!expanded ? sa : ((va | vb) ? (rf2 ? sb : sa) : kPop));
+        }
+        if (cur == kPop) {
+            cur = RL_CHILD_NONE;
+            if (sp > 0) {
+                sp--;
+                int code; float dist;
+                st.get(sp, &code, &dist);
+                cur = dist < hit.t ? code : kPop;      // `if d2 < its.t` evaluated after the near subtree (accel.rs:279-284)
+            }
+        }
+    };
+    auto leaf_visit = [&]() -> bool {
+        const unsigned int code = (unsigned int)(~cur);
+        const int first = (int)(code >> 2), count = (int)(code & 3u);
+        bool uni = false;
+        if (RL_UNIFORM_TRIPS) uni = __ballot(cur != __builtin_amdgcn_readfirstlane(cur)) == 0ull;
+        for (int k = 0; k < count; k++) {
+            hit.tris++;
+            float4 q0, q1, q2, q3;
+            if (uni) {
+                const F4c* q = (const F4c*)(recs.tris) + 4 * (__builtin_amdgcn_readfirstlane(first) + k);
+                const f4v a = q[0], b = q[1], c = q[2], e = q[3];
+                q0 = make_float4(a.x, a.y, a.z, a.w); q1 = make_float4(b.x, b.y, b.z, b.w); q2 = make_float4(c.x, c.y, c.z, c.w); q3 = make_float4(e.x, e.y, e.z, e.w);
+            } else {
+                const float4* q = recs.tris + 4 * (first + k);
+                q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+            }
+            if (tri_test(q0, q1, q2, q3, o, d, hit, first + k)) {
+                found = true;
+                if (ANY_HIT) return true;
+            }
+        }
+        cur = kPop;
+        return false;
+    };
+#if defined(RL_TRAVERSE_SPARSE)
+    while (cur != RL_CHILD_NONE) {          // k_stream_chain: no vote (see traverse)
+        if (cur >= 0 || cur == kPop) node_trip();
+        else if (leaf_visit()) return true;
+    }
+#else
+    for (;;) {
+        const bool in_node = cur >= 0 || cur == kPop;
+        const bool in_leaf = !in_node && cur != RL_CHILD_NONE;
+        const int n_node = __popcll(__ballot(in_node)), n_leaf = __popcll(__ballot(in_leaf));
+        if (n_node + n_leaf == 0) break;
+        if (n_node > 0 && n_node * RL_VOTE_DEN >= RL_VOTE_NUM * n_leaf) { if (in_node) node_trip(); }
+        else if (in_leaf && leaf_visit()) return true;
+    }
+#endif
+    if (!ANY_HIT && found) {
+        const float4* q = recs.tris + 4 * hit.prim;
         tri_uv(q[0], q[1], q[2], q[3], o, d, hit.t, &hit.u, &hit.v);
     }
     return found;

@@ -14,6 +14,11 @@ int rl_debug_numerics(int device, size_t n, const float* a, const float* b, floa
 // closest hits of a batch of rays through the tolerance build's traversal of a streaming scene (quantised BVH4, numerics = fast); steps = node trips per ray.
 // RL_ERR_UNSUPPORTED for scenes staged in LDS (they have no BVH4).
 int rl_debug_trace_batch_fast(rl_context* ctx, size_t n, const float* origins, const float* directions, float* t_out, int32_t* mesh_out, int32_t* tri_out, int32_t* steps_out);
+// rl_trace_batch through the two-level node records (trace.hip.h: traverse2; off by default, RL_TWO_LEVEL) + node trips per ray; any_hit: t_inout = segment lengths in, 1 / 0 out
+int rl_debug_trace_batch_two_level(rl_context* ctx, size_t n, const float* origins, const float* directions, float* t_inout, float* u_out, float* v_out,
+                                   int32_t* mesh_out, int32_t* tri_out, int32_t* steps_out, int any_hit);
+// host only: the two-level records against the BVH2 they are derived from (bvh.cpp)
+int rl_debug_check_two_level(const rl_scene* scene, uint64_t* out6);
 // rng_advance (kernels/rngjump.h) on the device: states_out[i] = sampler states_in[i] (4 x u64) after counts[i] more draws
 int rl_debug_rng_advance(int device, size_t n, const uint64_t* states_in, const uint32_t* counts, uint64_t* states_out);
 // host only: out[y * W + x] = 1 where every camera sample of the pixel takes exactly two draws (its rays cannot reach the scene's bounding box; k_stream_spec's shortcut)

@@ -135,7 +135,7 @@ RL_DEV void trace_kernel_body(const DeviceScene& sc, const Pool& pool, const Sta
         stage_scene_lds(sc, smem, smem + lds_nodes_float4s(sc.n_nodes));
         recs.nodes = smem; recs.tris = smem + lds_nodes_float4s(sc.n_nodes);
     } else {
-        recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
+        recs.nodes = streamed_nodes<TravStackT<false>>(sc);
         recs.tris = reinterpret_cast<const float4*>(sc.tris);
     }
 #ifdef RL_TRAV_STATS
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256) k_trace_batch(DeviceScene sc, StackConf s
                                                      float* v_out, int* mesh_out, int* tri_out) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneRecs recs;
-    recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
+    recs.nodes = streamed_nodes<TravStackT<false>>(sc);
     recs.tris = reinterpret_cast<const float4*>(sc.tris);
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const TravStack stack = make_stack(stc, reinterpret_cast<unsigned*>(smem), i);
@@ -185,10 +185,30 @@ __global__ void __launch_bounds__(256) k_trace_batch(DeviceScene sc, StackConf s
     else { mesh_out[i] = -1; tri_out[i] = -1; }
 }
 
+// test hook: the same batch through the two-level records (trace.hip.h: traverse2), whatever the build traverses by default
+__global__ void __launch_bounds__(256) k_trace_batch_two_level(DeviceScene sc, StackConf stc, unsigned n, const float* o, const float* d, float* t_out, float* u_out,
+                                                               float* v_out, int* mesh_out, int* tri_out, int* steps_out, int any_hit) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    SceneRecs recs;
+    recs.nodes = reinterpret_cast<const float4*>(sc.nodes2);
+    recs.tris = reinterpret_cast<const float4*>(sc.tris);
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    const TravStack2 stack(make_stack(stc, reinterpret_cast<unsigned*>(smem), i));
+    if (i >= n) return;
+    V3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    Hit hit; hit.t = kF32Max; hit.u = 0.0f; hit.v = 0.0f; hit.prim = -1;
+    const V3 lo = mk3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), hi = mk3(sc.root_max[0], sc.root_max[1], sc.root_max[2]);
+    if (any_hit) { hit.t = t_out[i]; const bool f = traverse<true>(recs, sc.root, lo, hi, ro, rd, kEps, hit.t, hit, stack); t_out[i] = f ? 1.0f : 0.0f; steps_out[i] = hit.steps; return; }   // t_out in: the segment length
+    traverse<false>(recs, sc.root, lo, hi, ro, rd, kEps, kF32Max, hit, stack);
+    t_out[i] = hit.t; u_out[i] = hit.u; v_out[i] = hit.v; steps_out[i] = hit.steps;
+    if (hit.prim >= 0) { mesh_out[i] = sc.tris[hit.prim].mesh; tri_out[i] = sc.tris[hit.prim].tri; }
+    else { mesh_out[i] = -1; tri_out[i] = -1; }
+}
+
 __global__ void __launch_bounds__(256) k_visible_batch(DeviceScene sc, StackConf stc, unsigned n, const float* p0a, const float* p1a, unsigned char* out) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneRecs recs;
-    recs.nodes = reinterpret_cast<const float4*>(sc.nodes);
+    recs.nodes = streamed_nodes<TravStackT<false>>(sc);
     recs.tris = reinterpret_cast<const float4*>(sc.tris);
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const TravStack stack = make_stack(stc, reinterpret_cast<unsigned*>(smem), i);
@@ -336,6 +356,11 @@ extern "C" int rl_context_create(const rl_scene* scene, int device, rl_context**
         ds.stack_depth = bvh.stack_depth;
         ds.nodes4 = nullptr; ds.root4 = RL_CHILD_NONE; ds.stack_depth4 = 0;
         ds.nodes_t = nullptr; ds.root_t = RL_CHILD_NONE;
+        {   // the exact build's two-level records (traverse2): what every kernel that streams the BVH — and rl_trace_batch / rl_visible_batch on any scene — reads
+            std::vector<BvhNode2> n2;
+            two_level_nodes(bvh, &n2);
+            if ((rc = upload(ctx, n2, &ds.nodes2)) != RL_OK) break;
+        }
         if ((rc = upload(ctx, flat.tri_indices, &ds.tri_indices)) != RL_OK) break;
         if ((rc = upload(ctx, flat.positions, &ds.positions)) != RL_OK) break;
         if ((rc = upload(ctx, flat.normals, &ds.normals)) != RL_OK) break;
@@ -1325,6 +1350,33 @@ extern "C" int rl_debug_trace_batch_fast(rl_context* ctx, size_t n, const float*
     HIP_OK(hipStreamSynchronize(ctx->stream));
     HIP_OK(hipMemcpy(t_out, b_t.as<float>(), n * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(mesh_out, b_m.as<int>(), n * 4, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(tri_out, b_tr.as<int>(), n * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(steps_out, b_s.as<int>(), n * 4, hipMemcpyDeviceToHost));
+    return RL_OK;
+}
+
+// test hook: rl_trace_batch through the two-level records (traverse2) + node trips per ray; any_hit != 0: t_inout holds the segment lengths on entry and 1 / 0
+// (a triangle was found / not) on return, as Acceleration::visible's inner `intersect` would (u, v, mesh, tri untouched)
+extern "C" int rl_debug_trace_batch_two_level(rl_context* ctx, size_t n, const float* origins, const float* directions, float* t_inout, float* u_out, float* v_out,
+                                              int32_t* mesh_out, int32_t* tri_out, int32_t* steps_out, int any_hit) {
+    if (!ctx || !n || !origins || !directions || !t_inout || !u_out || !v_out || !mesh_out || !tri_out || !steps_out) return RL_ERR_INVALID_ARGUMENT;
+    if (n > kMaxBatch) { rl_set_error("batch too large"); return RL_ERR_INVALID_ARGUMENT; }
+    HIP_OK(hipSetDevice(ctx->device));
+    DevBuf b_o, b_d, b_t, b_u, b_v, b_m, b_tr, b_s;
+    HIP_OK(b_o.alloc(3 * n * 4)); HIP_OK(b_d.alloc(3 * n * 4)); HIP_OK(b_t.alloc(n * 4)); HIP_OK(b_u.alloc(n * 4)); HIP_OK(b_v.alloc(n * 4));
+    HIP_OK(b_m.alloc(n * 4)); HIP_OK(b_tr.alloc(n * 4)); HIP_OK(b_s.alloc(n * 4));
+    HIP_OK(hipMemcpy(b_o.as<float>(), origins, 3 * n * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(b_d.as<float>(), directions, 3 * n * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(b_t.as<float>(), t_inout, n * 4, hipMemcpyHostToDevice));
+    StackConf stc;
+    { int r = stack_conf(ctx, (n + 255) / 256 * 256, &stc); if (r != RL_OK) return r; }
+    hipLaunchKernelGGL(k_trace_batch_two_level, dim3((unsigned)((n + 255) / 256)), dim3(256), traversal_lds_bytes(ctx, false, 256, false), ctx->stream, ctx->ds, stc, (unsigned)n,
+                       b_o.as<float>(), b_d.as<float>(), b_t.as<float>(), b_u.as<float>(), b_v.as<float>(), b_m.as<int>(), b_tr.as<int>(), b_s.as<int>(), any_hit);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    HIP_OK(hipMemcpy(t_inout, b_t.as<float>(), n * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(steps_out, b_s.as<int>(), n * 4, hipMemcpyDeviceToHost));
+    if (!any_hit) {
+        HIP_OK(hipMemcpy(u_out, b_u.as<float>(), n * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(v_out, b_v.as<float>(), n * 4, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(mesh_out, b_m.as<int>(), n * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(tri_out, b_tr.as<int>(), n * 4, hipMemcpyDeviceToHost));
+    }
     return RL_OK;
 }
 

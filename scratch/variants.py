@@ -12,13 +12,18 @@ def build(specs):
     from rustlight_amd import build as rb
     rb.build()
     os.makedirs(VDIR, exist_ok=True)
-    for f in glob.glob(os.path.join(VDIR, "*.so")): os.remove(f)
+    if not os.environ.get("VKEEP"):
+        for f in glob.glob(os.path.join(VDIR, "*.so")): os.remove(f)
     jobs = []
     for spec in specs:
         name, _, flags = spec.partition(":")
         flags = [f for f in flags.split(",") if f]
+        only = [x for x in os.environ.get("VSRC", "").split(",") if x]      # VSRC=fused_stream.hip,wavefront.hip: rebuild only these units, the rest come from the default build
         for src in rb.HIP_SOURCES:
             obj = os.path.join(VDIR, f"{name}.{os.path.basename(src)}.o")
+            if only and os.path.basename(src) not in only:
+                jobs.append((name, os.path.join(LIBDIR, os.path.basename(src) + ".o"), ["true"]))
+                continue
             jobs.append((name, obj, [rb.HIPCC, "--offload-arch=gfx950", *rb.COMMON, *rb.HIP_EXTRA, *flags, "-c", os.path.join(rb.CSRC, src), "-o", obj]))
     def run(j):
         r = subprocess.run(j[2], cwd="/tmp", stderr=subprocess.PIPE, text=True)
@@ -31,7 +36,8 @@ def build(specs):
         bad = [r for r in mine if r[2]]
         if bad: print(name, "FAILED\n", bad[0][3][-2000:]); continue
         subprocess.check_call([rb.HIPCC, "--offload-arch=gfx950", "-shared", "-o", os.path.join(VDIR, f"lib{name}.so"), *[r[1] for r in mine], *host, "-lz", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
-        for r in mine: os.remove(r[1])
+        for r in mine:
+            if r[1].startswith(VDIR): os.remove(r[1])
         print("built", name)
 
 def run_one(libpath, scene, pipeline, spp):

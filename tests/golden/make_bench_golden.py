@@ -25,6 +25,12 @@ FRAMES = [  # (workload, scene factory, width, height, spp, stream mode name, or
     ("cbox", lambda w, h: scenes.cbox(w, h), 1080, 1080, 128, "per_sample", 1, (2,)),                  # square frame
     ("living_room", lambda w, h: scenes.living_room(w, h), 1920, 1080, 128, "per_sample", 1, (2,)),    # configs[2] stand-in
     ("cbox_medium", lambda w, h: scenes.cbox_medium(w, h, 0.5), 1920, 1080, 128, "per_sample", 1, (2,)),   # configs[4]
+    # round 5: the drop-in default (reference-order streams) on the two slow configs, one timed step (seed 0), and configs[3]'s per-rank workload
+    # (shard 0 of 8 at 1024 spp: key suffix ":shard0of8"), both stream modes
+    ("living_room", lambda w, h: scenes.living_room(w, h), 1920, 1080, 128, "reference", 0, (0,)),
+    ("cbox_medium", lambda w, h: scenes.cbox_medium(w, h, 0.5), 1920, 1080, 128, "reference", 0, (0,)),
+    ("cbox", lambda w, h: scenes.cbox(w, h), 1920, 1080, 1024, "reference", 0, (0,), (0, 8)),
+    ("cbox", lambda w, h: scenes.cbox(w, h), 1920, 1080, 1024, "per_sample", 1, (0,), (0, 8)),
 ]
 
 
@@ -32,18 +38,19 @@ def main():
     only = set(sys.argv[1:])
     table = json.load(open(OUT)) if os.path.exists(OUT) else {}
     threads = len(os.sched_getaffinity(0))
-    for name, make, w, h, spp, mode, smode, seeds in FRAMES:
+    for name, make, w, h, spp, mode, smode, seeds, *rest in FRAMES:
+        shard = rest[0] if rest else (0, 1)
         if only and name not in only and f"{name}:{mode}" not in only:
             continue
         sc = None
         for seed in seeds:
-            key = f"{name}:{w}x{h}x{spp}:{mode}:seed{seed}"
+            key = f"{name}:{w}x{h}x{spp}:{mode}:seed{seed}" + (f":shard{shard[0]}of{shard[1]}" if shard[1] > 1 else "")
             if key in table:
                 continue
             if sc is None:
                 sc = orc.Scene(make(w, h))
             t0 = time.time()
-            img, st = sc.render(master_seed=seed, spp=spp, stream_mode=smode, eval_order=1, threads=threads)      # eval_order 1: the forward accumulation the kernels use
+            img, st = sc.render(master_seed=seed, spp=spp, stream_mode=smode, eval_order=1, threads=threads, shard_index=shard[0], shard_count=shard[1])      # eval_order 1: the forward accumulation the kernels use
             table[key] = {"crc32": f"{zlib.crc32(img.tobytes()):08x}", "image_mean": float(img.mean()), "camera_samples": st["camera_samples"], "vertices": st["vertices"],
                           "rng_draws": st["rng_draws"], "oracle_seconds": round(time.time() - t0, 1)}
             print(key, table[key], flush=True)

@@ -346,3 +346,34 @@ def test_structures_derived_from_the_bvh2_are_the_same_tree(built, maker):
     assert bad == 0, list(out)
     if n2:
         assert slots % 16 == 0 and n2 <= slots <= 16 * n2 and leaves4 == leaves2 == n2 + 1 and 0 < n4 <= n2
+
+
+def _nan_scene():
+    """A Cornell box with a few non-finite vertices (the geometry of test_non_finite_and_degenerate_geometry_parity's kind)."""
+    sd = scenes.cbox(32, 32)
+    m = sd.meshes[2]
+    m.vertices = m.vertices.copy()
+    m.vertices[0, 1] = np.nan
+    m.vertices[1, 0] = np.inf
+    return sd
+
+
+@pytest.mark.parametrize("maker", [lambda: scenes.cbox(64, 64), lambda: scenes.living_room(64, 64, n_spheres=27, tess=12), lambda: scenes.living_room(64, 64, n_spheres=64, tess=24),
+                                   lambda: scenes.single_triangle(), lambda: scenes.many_lights(64, 48, n=5, use_ats=False), _nan_scene])
+def test_two_level_records_are_the_bvh2(built, maker):
+    """Host-only: the two-level node records the exact build traverses on scenes that stream their BVH (device_types.h: BvhNode2, trace.hip.h: traverse2) hold the
+    BVH2 itself — every record's children and slots are the BVH2's children and grandchildren with bit-identical boxes, the union of a child's two slots IS the
+    child's box (what lets the kernel derive a child's slab distances from its slots'), and walking the records reaches every inner node and every leaf once.
+    src/accel.rs:183-188 (node boxes), src/structure.rs:779-784 (union_aabb)."""
+    import ctypes as C
+    sc = api.Scene(maker())
+    out = (C.c_uint64 * 6)()
+    fn = api.lib().rl_debug_check_two_level
+    fn.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    assert fn(sc.h, out) == 0
+    n2, expanded, leaf_children, plain, bad, leaves = (int(x) for x in out)
+    assert bad == 0, list(out)
+    if n2:
+        assert expanded + leaf_children + plain == 2 * n2 and leaves == n2 + 1 == leaf_children
+        assert expanded + plain == n2 - 1                 # every inner node but the root is some node's child
+        assert plain == 0                                  # boxes made by range_box always pass the union check

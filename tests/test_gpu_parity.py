@@ -75,6 +75,68 @@ def test_trace_batch_matches_oracle(built, maker):
     np.testing.assert_array_equal(got[0][:20000], brute[0])
 
 
+def test_two_level_records_find_the_reference_hits(built):
+    """traverse2 (trace.hip.h): two levels of the reference's recursion (src/accel.rs:256-287) per fetched record — the grandchildren's exact boxes ride with the node,
+    AABB::intersect (src/structure.rs:849-869) never reads its.t, so one fetch decides both levels with the identical comparisons.  Must be the oracle's hit for every
+    ray, bit for bit (t, u, v, mesh, triangle) — random rays, camera rays, rays ALONG the axes from origins ON box planes (1 / d = inf, 0 * inf = NaN planes: the
+    `unsafe` path that unions planes instead of distances), non-finite geometry — in about half the node trips.  (The build traverses the one-level records by
+    default: profiles/NEGATIVES.md round 5 — fewer trips, more instructions; this keeps the construction honest.)"""
+    def spoiled(kind):
+        rng = np.random.default_rng(kind)
+        sd = scenes.cbox(24, 20)
+        c = rng.uniform(-0.8, 0.8, (30, 1, 3)); c[:, :, 1] += 1.0
+        v = (c + rng.uniform(-0.3, 0.3, (30, 3, 3))).astype(np.float32).reshape(-1, 3)
+        if kind == 0: v[rng.integers(0, len(v), 6)] = np.nan
+        if kind == 1: v[rng.integers(0, len(v), 6), rng.integers(0, 3, 6)] = np.inf
+        if kind == 2: v *= np.float32(1e30)
+        sd.meshes.append(scenes.MeshData("adv", v, np.arange(90, dtype=np.uint32).reshape(-1, 3), None, None, scenes.matte((0.6, 0.6, 0.6))))
+        return sd
+    for n_case, maker in enumerate([lambda: scenes.cbox(64, 64), lambda: scenes.living_room(64, 64, n_spheres=27, tess=12), lambda: scenes.living_room(64, 64, n_spheres=64, tess=20),
+                                    lambda: spoiled(0), lambda: spoiled(1), lambda: spoiled(2), lambda: scenes.single_triangle()]):
+        sd = maker()
+        ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+        o, d = _random_rays(sd, 150000, 11 + n_case)
+        if sd.n_triangles > 1000:
+            o = o * 3.0
+            o[:, 1] += 4.0
+        # rays along the axes and in the axis planes (zero direction components), from origins snapped onto the planes of the BVH's boxes
+        boxes = osc.bvh()[0].reshape(-1, 2, 3)
+        rng = np.random.default_rng(5 + n_case)
+        n_ax = 30000
+        oa = rng.uniform(-1.0, 1.0, (n_ax, 3)).astype(np.float32); oa[:, 1] += 1.0
+        if len(boxes):
+            fin = boxes[np.isfinite(boxes).all(axis=(1, 2))]
+            if len(fin):
+                pick = fin[rng.integers(0, len(fin), n_ax)]
+                for k in range(3):
+                    snap = rng.random(n_ax) < 0.5
+                    oa[snap, k] = pick[snap, rng.integers(0, 2, n_ax)[snap], k]
+        da = np.zeros((n_ax, 3), np.float32)
+        ax = rng.integers(0, 3, n_ax)
+        da[np.arange(n_ax), ax] = rng.choice([-1.0, 1.0], n_ax)
+        planar = rng.random(n_ax) < 0.4            # a second non-zero component: still one zero, 1 / d = inf on one axis
+        ang = rng.uniform(0, 2 * np.pi, n_ax)
+        da[planar, (ax[planar] + 1) % 3] = np.sin(ang[planar]); da[planar, ax[planar]] = np.cos(ang[planar])
+        o = np.concatenate([o, oa]).astype(np.float32); d = np.concatenate([d, da]).astype(np.float32)
+        got, ref, one = ctx.trace_two_level(o, d), osc.trace(o, d), ctx.trace(o, d)
+        for g, r, w, name in zip(got, ref, one, ["t", "u", "v", "mesh", "tri"]):
+            np.testing.assert_array_equal(g, r, err_msg=f"case {n_case} {name}")
+            np.testing.assert_array_equal(g, w, err_msg=f"case {n_case} {name} (one-level)")
+        # any-hit form against Acceleration::visible's inner traversal: segment o -> o + d * len
+        seg = rng.uniform(0.2, 3.0, len(o)).astype(np.float32)
+        found, _ = ctx.trace_two_level(o, d, segment_lengths=seg)
+        ref_t = ref[0]
+        # (a closest hit strictly inside the segment means the any-hit query finds something; one beyond it means it cannot)
+        assert not (found & (ref[3] < 0)).any() and found[(ref[3] >= 0) & (ref_t < seg * 0.999)].all() and not found[(ref[3] >= 0) & (ref_t > seg * 1.001)].any()
+    sd = scenes.living_room(64, 64, n_spheres=64, tess=20)
+    ctx = api.Context(api.Scene(sd), 0)
+    o, d = _random_rays(sd, 100000, 3); o = o * 3.0; o[:, 1] += 4.0
+    steps2 = ctx.trace_two_level(o, d)[5]
+    if not ctx.debug_sizes()["lds_scene"]:
+        steps4 = ctx.trace_fast(o, d)[3]
+        assert 0 < steps2.mean() < 1.1 * steps4.mean() * 1.6      # (the BVH4 collapses by area, the two-level records by depth: same order of magnitude)
+
+
 def test_bvh4_of_the_tolerance_build_finds_the_same_hits(built, monkeypatch):
     """`numerics = fast` on scenes that stream their BVH traverses the same tree collapsed into quantised BVH4 nodes (build_bvh4 / traverse4:
     conservative 8-bit child boxes, a superset of the leaves).  Ray by ray against the exact BVH2 traversal (which equals the oracle and the
@@ -1006,6 +1068,39 @@ def test_bench_frames_equal_the_oracle(built):
         assert f"{zlib.crc32(img.tobytes()):08x}" == e["crc32"], (w, h, spp)
         assert (st["camera_samples"], st["vertices"], st["rng_draws"]) == (e["camera_samples"], e["vertices"], e["rng_draws"])
         assert (st["spec_group"] > 0) == (spp == 128)          # the large frame goes through k_stream_spec, the small one through k_stream_chain
+
+
+def test_cfg4_one_rank_of_eight(built):
+    """BASELINE configs[3]'s per-rank workload exactly: cbox 1920 x 1080, 1024 spp, the blocks of rank 0 of 8 (b % 8 == 0: the round-robin deal of compute_mc's block
+    list, src/integrators/mod.rs:351-450 / DESIGN.md 5), in both stream modes.  The whole shard against the oracle's render of the same shard (CRC and counters from
+    tests/golden/bench_crcs.json, made by tests/golden/make_bench_golden.py with the parity build) and eight blocks of it — the busiest four + fixed ones inside and
+    outside the box — against the oracle's walk of the same block streams run here, bit for bit.  In reference-order streams the chain pass must be the speculative one."""
+    import json
+    import zlib
+    table = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_crcs.json")))
+    sd = scenes.cbox(1920, 1080)
+    ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+    seeds = api.IndependentSampler(0).block_seeds(1920, 1080)
+    nby, nb = 68, 120 * 68
+    for mode, name, omode in ((api.STREAM_PER_SAMPLE, "per_sample", 1), (api.STREAM_REFERENCE_ORDER, "reference", 0)):
+        img, st = ctx.render(seeds, api.path_params(spp=1024, shard_index=0, shard_count=8, stream_mode=mode))
+        e = table[f"cbox:1920x1080x1024:{name}:seed0:shard0of8"]
+        assert f"{zlib.crc32(img.tobytes()):08x}" == e["crc32"], name
+        assert (st["camera_samples"], st["vertices"], st["rng_draws"]) == (e["camera_samples"], e["vertices"], e["rng_draws"]), name
+        assert st["camera_samples"] == sum(min(16, 1920 - (b // nby) * 16) * min(16, 1080 - (b % nby) * 16) for b in range(0, nb, 8)) * 1024
+        if mode == api.STREAM_REFERENCE_ORDER:
+            assert st["ms_prepass"] > 0.0 and st["spec_group"] > 0
+        owned = [b for b in _busiest_blocks(img, 64) if b % 8 == 0][:4] + [60 * 68 + 32, 45 * 68 + 20, 75 * 68 + 44, 2 * 68 + 0]
+        assert len(owned) == 8 and all(b % 8 == 0 for b in owned)
+        verts = 0
+        for b in owned:
+            ref, ost = osc.render(seeds=seeds, spp=1024, stream_mode=omode, eval_order=1, shard_index=int(b), shard_count=nb)
+            x0, y0 = (b // nby) * 16, (b % nby) * 16
+            np.testing.assert_array_equal(img[y0:y0 + 16, x0:x0 + 16], ref[y0:y0 + 16, x0:x0 + 16], err_msg=f"{name}: block {b} at ({x0}, {y0})")
+            verts += ost["vertices"]
+        assert verts > 500000, verts
+        # a block of another rank stays black on this one
+        assert not img[16:32, 0:16].any()
 
 
 def test_multi_context_rccl_reduce(built, cbox64, ctx_cbox):
