@@ -319,9 +319,12 @@ int rl_render_path(rl_context* ctx, const rl_path_params* params, const uint64_t
                    rl_render_stats* stats);
 
 /* Frames in flight behind one call (the progressive wrappers' passes, avg.rs:5-131 / equal_time.rs:4-66: N independent renders of one scene): frame f — block
- * seeds `block_seeds[f]`, host image `out_rgb[f]` (W*H*3 f32) — renders on `ctxs[f % n_ctx]` from host thread f % n_ctx; `ctxs` are distinct contexts of the same
- * scene.  Returns when every frame is done; the images (and `stats[f]`, if not NULL) are those of `n_frames` rl_render_path calls one after the other.  On an
- * error the first failing thread's code is returned and rl_last_error carries its message; the other frames may or may not have been rendered. */
+ * seeds `block_seeds[f]`, host image `out_rgb[f]` (W*H*3 f32) — renders on `ctxs[f % k]` from host thread f % k, k = min(n_ctx, n_frames); `ctxs` are distinct
+ * contexts of the same scene.  Returns when every frame is done; the images (and `stats[f]`, if not NULL) are those of `n_frames` rl_render_path calls one after
+ * the other.  On an error the first failing thread's code is returned and rl_last_error carries its message; the other threads stop before their next frame
+ * (frames not yet started are not rendered).  Every context in flight keeps its own render buffers (several GB at 1080p x 128 spp in reference-order streams)
+ * until it is destroyed.  The process environment must not be changed (setenv / putenv) while frames are in flight: the library reads its test-only RL_* knobs
+ * with getenv during a render. */
 int rl_render_path_frames(rl_context* const* ctxs, size_t n_ctx, const rl_path_params* params,
                           const uint64_t* const* block_seeds, size_t n_blocks, size_t n_frames,
                           float* const* out_rgb, rl_render_stats* stats);
@@ -330,7 +333,11 @@ int rl_render_path_frames(rl_context* const* ctxs, size_t n_ctx, const rl_path_p
  * What a Rust host fills from `&Scene` (src/scene.rs:16-30) in one go instead of the builder calls above; the arrays are only read during
  * the call.  Equivalent to: rl_scene_create, rl_scene_set_camera_matrices (has_camera_matrices) or rl_scene_set_camera, rl_scene_add_bitmap (in order: their ids are 0, 1, ...), rl_scene_add_mesh
  * (in order), rl_scene_set_medium, rl_scene_add_point_light / _directional_light (in order), rl_scene_set_environment[_map],
- * rl_scene_enable_ats, rl_scene_build_emitters — with the same checks and error codes. */
+ * rl_scene_enable_ats, rl_scene_build_emitters — with the same checks and error codes.
+ * The structs below carry no size or version member: ZERO-INITIALISE them (memset / `= {0}` / Rust `std::mem::zeroed()`) before filling the fields you know —
+ * fields added later (round 4: emission_type / _scale / _bitmap_id, has_camera_matrices / sample_to_camera / to_world) then read as 0 = the old behaviour
+ * (EmissionType::Color, Camera::new from the scalar parameters); a consumer built against an older header must be rebuilt (the layout is checked by
+ * tests/test_abi_layout.py against this header, the ctypes mirror and the Rust block of INTEGRATION.md). */
 typedef struct rl_mesh_desc {          /* struct Mesh (src/geometry.rs:107-119) */
     const float* vertices; size_t n_vertices;      /* xyz */
     const uint32_t* indices; size_t n_triangles;   /* 3 per triangle */

@@ -118,6 +118,7 @@ int main(int argc, char** argv) {
                 std::vector<float> px((size_t)3 * bw * bh);
                 if (rl_load_image("butterfly.jpg", &bw, &bh, px.data(), px.size()) != RL_OK) { std::fprintf(stderr, "texture-light: %s\n", rl_last_error()); return 1; }
                 bitmap = rl_scene_add_bitmap(scene->handle, bw, bh, px.data());
+                if (bitmap < 0) { std::fprintf(stderr, "texture-light: %s\n", rl_last_error()); return 1; }      // (a negative return is an error code, not a bitmap id)
             }
             if (rl_scene_override_light_emission(scene->handle, light_override, bitmap) != RL_OK) { std::fprintf(stderr, "-x %s: %s\n", light_override == RL_EMISSION_HSV ? "hvs-light" : "texture-light", rl_last_error()); return 1; }
         }

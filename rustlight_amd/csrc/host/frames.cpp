@@ -3,6 +3,7 @@
 // another frame's workgroups ("Frames in flight").  What the progressive wrappers of the reference (src/integrators/avg.rs:5-131, equal_time.rs:4-66: N
 // independent renders of one scene) can call as it is.
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <thread>
 #include <vector>
@@ -23,12 +24,13 @@ extern "C" int rl_render_path_frames(rl_context* const* ctxs, size_t n_ctx, cons
     const size_t k = std::min(n_ctx, std::max<size_t>(n_frames, 1));
     std::vector<int> rc(k, RL_OK);
     std::vector<std::string> msg(k);
+    std::atomic<bool> failed{false};         // one frame failed: the other threads stop before their next frame instead of rendering the rest of a call that already has its answer
     auto work = [&](size_t c) {
-        for (size_t f = c; f < n_frames; f += k) {
+        for (size_t f = c; f < n_frames && !failed.load(std::memory_order_relaxed); f += k) {
             rl_render_stats st{};
             const int r = rl_render_path(ctxs[c], params, block_seeds[f], n_blocks, out_rgb[f], 0, nullptr, &st);
             if (stats) stats[f] = st;
-            if (r != RL_OK) { rc[c] = r; msg[c] = rl_last_error(); return; }      // (the error string is per thread: carried over to the caller's below)
+            if (r != RL_OK) { rc[c] = r; msg[c] = rl_last_error(); failed.store(true, std::memory_order_relaxed); return; }      // (the error string is per thread: carried over to the caller's below)
         }
     };
     if (k == 1) work(0);

@@ -28,7 +28,12 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneRecs recs;
     float4* after_scene = smem;
-    if (LDS_SCENE) {
+    constexpr bool LDS2 = LDS_SCENE && RL_LDS_TWO_LEVEL;      // LDS-staged scenes: two-level node records (trace.hip.h: traverse2, stage_scene_lds2)
+    if (LDS2) {
+        stage_scene_lds2(sc, smem, smem + lds_nodes2_float4s(sc.n_nodes));
+        recs.nodes = smem; recs.tris = smem + lds_nodes2_float4s(sc.n_nodes);
+        after_scene = smem + lds_scene2_float4s(sc.n_nodes, sc.n_prims);
+    } else if (LDS_SCENE) {
         stage_scene_lds(sc, smem, smem + lds_nodes_float4s(sc.n_nodes));
         recs.nodes = smem; recs.tris = smem + lds_nodes_float4s(sc.n_nodes);
         after_scene = smem + lds_scene_float4s(sc.n_nodes, sc.n_prims);
@@ -41,7 +46,8 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
     unsigned long long* cold_q = reinterpret_cast<unsigned long long*>(after_scene);
     float* cold_f = reinterpret_cast<float*>(cold_q + 256 * FusedState::kColdQ);
     unsigned* cold_u = reinterpret_cast<unsigned*>(cold_f + 256 * FusedState::kColdF);
-    const TravStackT<LDS_SCENE> stack = make_stack<LDS_SCENE>(stc, cold_u + 256 * FusedState::kColdU, tid);
+    using StackT = typename std::conditional<LDS2, TravStackLds2, TravStackT<LDS_SCENE>>::type;
+    const StackT stack(make_stack<LDS_SCENE>(stc, cold_u + 256 * FusedState::kColdU, tid));
     // streaming scenes: per-wave staging area of the cooperative record fetch, after the stacks
     constexpr bool COOP = !LDS_SCENE && RL_COOP_FETCH;
     float4* stage = reinterpret_cast<float4*>(cold_u + 256 * FusedState::kColdU + 2 * 256 * stc.lds_levels) + (threadIdx.x >> 6) * kCoopStageFloat4s;

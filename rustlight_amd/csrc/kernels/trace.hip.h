@@ -32,9 +32,13 @@ struct Hit { float t, u, v; int prim; int steps = 0, tris = 0, fetches = 0; };  
 #define RL_LDS_TRI_STRIDE4 5
 #endif
 static constexpr int kLdsNodeStride = RL_LDS_NODE_STRIDE;      // dwords
+static constexpr int kLdsNode2Stride = 36;                     // dwords between two-level records staged in LDS (32 + 4: ds_read_b128 rows stay 16-byte aligned, consecutive records start 4 banks apart)
 static constexpr int kLdsTriStride4 = RL_LDS_TRI_STRIDE4;      // float4s
 RL_DEV __host__ unsigned lds_nodes_float4s(unsigned n_nodes) { return (n_nodes * (unsigned)kLdsNodeStride + 3u) / 4u; }
 RL_DEV __host__ unsigned lds_scene_float4s(unsigned n_nodes, unsigned n_prims) { return lds_nodes_float4s(n_nodes) + n_prims * (unsigned)kLdsTriStride4; }
+// the same scene with the nodes as two-level records (k_path_fused on LDS-staged scenes: traverse2)
+RL_DEV __host__ unsigned lds_nodes2_float4s(unsigned n_nodes) { return n_nodes * (unsigned)(kLdsNode2Stride / 4); }
+RL_DEV __host__ unsigned lds_scene2_float4s(unsigned n_nodes, unsigned n_prims) { return lds_nodes2_float4s(n_nodes) + n_prims * (unsigned)kLdsTriStride4; }
 
 // AABB::intersect (src/structure.rs:849-869) with 1/d hoisted out of the loop, restated without its per-axis
 // early exit and compare/select chains — same value, same verdict, a third fewer VALU instructions:
@@ -222,6 +226,16 @@ struct TravStackT {
     }
 };
 using TravStack = TravStackT<false>;
+#ifndef RL_LDS_TWO_LEVEL
+// 1: k_path_fused on LDS-staged scenes traverses two-level records (one LDS round trip decides two levels; the near / far rows come pre-swizzled as six ds_read_b128,
+// no selects).  OFF: measured slower on the same box — cbox 1080p x 128 spp 50.7 -> 59.0 ms, square frame 51.6 -> 59.8, cbox + medium (32 spp) 103.1 -> 115.4, same CRCs
+// (profiles/NEGATIVES.md round 5): half the children of a 19-node tree are leaves, so half of the second-level slabs are wasted, and the kernel is bound by VALU issue.
+#define RL_LDS_TWO_LEVEL 0
+#endif
+struct TravStackLds2 : TravStackT<true> {        // LDS-staged scene, two-level records (stage_scene_lds2)
+    static constexpr bool kTwoLevel = true;
+    RL_DEV explicit TravStackLds2(const TravStackT<true>& s) : TravStackT<true>(s) {}
+};
 struct TravStack2 : TravStackT<false> {          // the same stack, traversed through the two-level records whatever RL_TWO_LEVEL says (test hook)
     static constexpr bool kTwoLevel = true;
     static constexpr bool kBvh4 = false;
@@ -458,9 +472,10 @@ RL_DEV bool traverse(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3
 //  * second level: the entered child's two slots with the same tnear and the same its.t — the one-level trip at that child, operation for operation.
 template <bool ANY_HIT, class Stack>
 RL_DEV bool traverse2(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V3 o, V3 d, float tnear, float tfar, Hit& hit, const Stack& st) {
+    constexpr bool LDS = Stack::kLdsOnly;       // the records are staged in LDS (stage_scene_lds<true>: 36 dwords apart, inner references = byte offsets)
     const V3 inv_d = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));
     float dummy;
-    int cur = root;
+    int cur = (LDS && root >= 0) ? root * (4 * kLdsNode2Stride) : root;
     if (!slab(root_lo, root_hi, o, inv_d, tnear, tfar, &dummy)) cur = RL_CHILD_NONE;   // accel.rs:293-295 / 338-340
     int sp = 0;
     bool found = false;
@@ -470,24 +485,41 @@ RL_DEV bool traverse2(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V
     const float inf = f32_inf();
     const bool unsafe = !((ax > 0.0f) & (ax < inf) & (ay > 0.0f) & (ay < inf) & (az > 0.0f) & (az < inf) &
                           (__builtin_fabsf(o.x) < inf) & (__builtin_fabsf(o.y) < inf) & (__builtin_fabsf(o.z) < inf));
+    // LDS: the sign of 1 / d picks the near / far plane row once per ray (byte offsets into a record: lox 0, loy 16, loz 32, hix 48, hiy 64, hiz 80, slots 96, children 112)
+    const int onx = sx ? 48 : 0, ofx = sx ? 0 : 48, ony = sy ? 64 : 16, ofy = sy ? 16 : 64, onz = sz ? 80 : 32, ofz = sz ? 32 : 80;
     auto node_trip = [&]() {
         if (cur >= 0) {
             hit.steps++;
-            f4v lox, loy, loz, hix, hiy, hiz, sl, ch;
-            const int cur0 = __builtin_amdgcn_readfirstlane(cur);
-            if (RL_UNIFORM_TRIPS && __ballot(cur != cur0) == 0ull) {      // every lane holds the same node: through the scalar cache
-                const F4c* q = (const F4c*)(recs.nodes) + 8 * cur0;
-                lox = q[0]; loy = q[1]; loz = q[2]; hix = q[3]; hiy = q[4]; hiz = q[5]; sl = q[6]; ch = q[7];
+            f4v npx, npy, npz, fpx, fpy, fpz, sl, ch;       // near / far PLANES of the four slots per axis, slot references, child references
+            if constexpr (LDS) {
+                typedef __attribute__((address_space(3))) const char LdsBytes;
+                LdsBytes* b = (LdsBytes*)(recs.nodes) + cur;
+#define RL_ROW(off) (*reinterpret_cast<__attribute__((address_space(3))) const f4v*>(b + (off)))
+                npx = RL_ROW(onx); fpx = RL_ROW(ofx); npy = RL_ROW(ony); fpy = RL_ROW(ofy); npz = RL_ROW(onz); fpz = RL_ROW(ofz); sl = RL_ROW(96); ch = RL_ROW(112);
+#undef RL_ROW
             } else {
-                const f4v* q = reinterpret_cast<const f4v*>(recs.nodes) + 8 * cur;
-                lox = q[0]; loy = q[1]; loz = q[2]; hix = q[3]; hiy = q[4]; hiz = q[5]; sl = q[6]; ch = q[7];
+                f4v lox, loy, loz, hix, hiy, hiz;
+                const int cur0 = __builtin_amdgcn_readfirstlane(cur);
+                if (RL_UNIFORM_TRIPS && __ballot(cur != cur0) == 0ull) {      // every lane holds the same node: through the scalar cache
+                    const F4c* q = (const F4c*)(recs.nodes) + 8 * cur0;
+                    lox = q[0]; loy = q[1]; loz = q[2]; hix = q[3]; hiy = q[4]; hiz = q[5]; sl = q[6]; ch = q[7];
+                } else {
+                    const f4v* q = reinterpret_cast<const f4v*>(recs.nodes) + 8 * cur;
+                    lox = q[0]; loy = q[1]; loz = q[2]; hix = q[3]; hiy = q[4]; hiz = q[5]; sl = q[6]; ch = q[7];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    npx[k] = sx ? hix[k] : lox[k]; fpx[k] = sx ? lox[k] : hix[k];
+                    npy[k] = sy ? hiy[k] : loy[k]; fpy[k] = sy ? loy[k] : hiy[k];
+                    npz[k] = sz ? hiz[k] : loz[k]; fpz[k] = sz ? loz[k] : hiz[k];
+                }
             }
             float nx[4], ny[4], nz[4], fx[4], fy[4], fz[4], tn[4], tf[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                nx[k] = ((sx ? hix[k] : lox[k]) - o.x) * inv_d.x; fx[k] = ((sx ? lox[k] : hix[k]) - o.x) * inv_d.x;
-                ny[k] = ((sy ? hiy[k] : loy[k]) - o.y) * inv_d.y; fy[k] = ((sy ? loy[k] : hiy[k]) - o.y) * inv_d.y;
-                nz[k] = ((sz ? hiz[k] : loz[k]) - o.z) * inv_d.z; fz[k] = ((sz ? loz[k] : hiz[k]) - o.z) * inv_d.z;
+                nx[k] = (npx[k] - o.x) * inv_d.x; fx[k] = (fpx[k] - o.x) * inv_d.x;
+                ny[k] = (npy[k] - o.y) * inv_d.y; fy[k] = (fpy[k] - o.y) * inv_d.y;
+                nz[k] = (npz[k] - o.z) * inv_d.z; fz[k] = (fpz[k] - o.z) * inv_d.z;
                 tn[k] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx[k], ny[k]), nz[k]), tnear);
                 tf[k] = __builtin_fminf(__builtin_fminf(fx[k], fy[k]), fz[k]);       // (unclipped: the clip with its.t is applied where the level is decided)
             }
@@ -498,13 +530,14 @@ RL_DEV bool traverse2(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V
             float f2 = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaxf(fx[2], fx[3]), __builtin_fmaxf(fy[2], fy[3])), __builtin_fmaxf(fz[2], fz[3])), hit.t);
             if (__ballot(unsafe) != 0ull) {       // (wave-uniform; a ray along an axis: ~2^-23 of the cosine-sampled directions)
                 if (unsafe) {
-                    // the union of the planes (AABB::union_aabb), then the one-level trip's arithmetic on the child boxes
-#define RL_UN(S, HI, LO, A, B) (S ? __builtin_fmaxf(HI[A], HI[B]) : __builtin_fminf(LO[A], LO[B]))
-#define RL_UF(S, HI, LO, A, B) (S ? __builtin_fminf(LO[A], LO[B]) : __builtin_fmaxf(HI[A], HI[B]))
-                    d1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((RL_UN(sx, hix, lox, 0, 1) - o.x) * inv_d.x, (RL_UN(sy, hiy, loy, 0, 1) - o.y) * inv_d.y), (RL_UN(sz, hiz, loz, 0, 1) - o.z) * inv_d.z), tnear);
-                    f1 = __builtin_fminf(__builtin_fminf(__builtin_fminf((RL_UF(sx, hix, lox, 0, 1) - o.x) * inv_d.x, (RL_UF(sy, hiy, loy, 0, 1) - o.y) * inv_d.y), (RL_UF(sz, hiz, loz, 0, 1) - o.z) * inv_d.z), hit.t);
-                    d2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((RL_UN(sx, hix, lox, 2, 3) - o.x) * inv_d.x, (RL_UN(sy, hiy, loy, 2, 3) - o.y) * inv_d.y), (RL_UN(sz, hiz, loz, 2, 3) - o.z) * inv_d.z), tnear);
-                    f2 = __builtin_fminf(__builtin_fminf(__builtin_fminf((RL_UF(sx, hix, lox, 2, 3) - o.x) * inv_d.x, (RL_UF(sy, hiy, loy, 2, 3) - o.y) * inv_d.y), (RL_UF(sz, hiz, loz, 2, 3) - o.z) * inv_d.z), hit.t);
+                    // the union of the planes (AABB::union_aabb: the near plane of the union is the max of the hi planes when 1 / d < 0, else the min of the lo planes),
+                    // then the one-level trip's arithmetic on the child boxes
+#define RL_UN(S, P, A, B) (S ? __builtin_fmaxf(P[A], P[B]) : __builtin_fminf(P[A], P[B]))
+#define RL_UF(S, P, A, B) (S ? __builtin_fminf(P[A], P[B]) : __builtin_fmaxf(P[A], P[B]))
+                    d1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((RL_UN(sx, npx, 0, 1) - o.x) * inv_d.x, (RL_UN(sy, npy, 0, 1) - o.y) * inv_d.y), (RL_UN(sz, npz, 0, 1) - o.z) * inv_d.z), tnear);
+                    f1 = __builtin_fminf(__builtin_fminf(__builtin_fminf((RL_UF(sx, fpx, 0, 1) - o.x) * inv_d.x, (RL_UF(sy, fpy, 0, 1) - o.y) * inv_d.y), (RL_UF(sz, fpz, 0, 1) - o.z) * inv_d.z), hit.t);
+                    d2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf((RL_UN(sx, npx, 2, 3) - o.x) * inv_d.x, (RL_UN(sy, npy, 2, 3) - o.y) * inv_d.y), (RL_UN(sz, npz, 2, 3) - o.z) * inv_d.z), tnear);
+                    f2 = __builtin_fminf(__builtin_fminf(__builtin_fminf((RL_UF(sx, fpx, 2, 3) - o.x) * inv_d.x, (RL_UF(sy, fpy, 2, 3) - o.y) * inv_d.y), (RL_UF(sz, fpz, 2, 3) - o.z) * inv_d.z), hit.t);
 #undef RL_UN
 #undef RL_UF
                 }
@@ -542,7 +575,7 @@ RL_DEV bool traverse2(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V
         const unsigned int code = (unsigned int)(~cur);
         const int first = (int)(code >> 2), count = (int)(code & 3u);
         bool uni = false;
-        if (RL_UNIFORM_TRIPS) uni = __ballot(cur != __builtin_amdgcn_readfirstlane(cur)) == 0ull;
+        if (!LDS && RL_UNIFORM_TRIPS) uni = __ballot(cur != __builtin_amdgcn_readfirstlane(cur)) == 0ull;
         for (int k = 0; k < count; k++) {
             hit.tris++;
             float4 q0, q1, q2, q3;
@@ -551,7 +584,7 @@ RL_DEV bool traverse2(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V
                 const f4v a = q[0], b = q[1], c = q[2], e = q[3];
                 q0 = make_float4(a.x, a.y, a.z, a.w); q1 = make_float4(b.x, b.y, b.z, b.w); q2 = make_float4(c.x, c.y, c.z, c.w); q3 = make_float4(e.x, e.y, e.z, e.w);
             } else {
-                const float4* q = recs.tris + 4 * (first + k);
+                const float4* q = recs.tris + Stack::kTriStride4 * (first + k);
                 q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
             }
             if (tri_test(q0, q1, q2, q3, o, d, hit, first + k)) {
@@ -562,23 +595,30 @@ RL_DEV bool traverse2(const SceneRecs& recs, int root, V3 root_lo, V3 root_hi, V
         cur = kPop;
         return false;
     };
+    if constexpr (LDS) {
+        while (cur != RL_CHILD_NONE) {          // "while-while", as in traverse
+            while (cur >= 0 || cur == kPop) node_trip();
+            if (cur != RL_CHILD_NONE && leaf_visit()) return true;
+        }
+    } else {
 #if defined(RL_TRAVERSE_SPARSE)
-    while (cur != RL_CHILD_NONE) {          // k_stream_chain: no vote (see traverse)
-        if (cur >= 0 || cur == kPop) node_trip();
-        else if (leaf_visit()) return true;
-    }
+        while (cur != RL_CHILD_NONE) {          // k_stream_chain: no vote (see traverse)
+            if (cur >= 0 || cur == kPop) node_trip();
+            else if (leaf_visit()) return true;
+        }
 #else
-    for (;;) {
-        const bool in_node = cur >= 0 || cur == kPop;
-        const bool in_leaf = !in_node && cur != RL_CHILD_NONE;
-        const int n_node = __popcll(__ballot(in_node)), n_leaf = __popcll(__ballot(in_leaf));
-        if (n_node + n_leaf == 0) break;
-        if (n_node > 0 && n_node * RL_VOTE_DEN >= RL_VOTE_NUM * n_leaf) { if (in_node) node_trip(); }
-        else if (in_leaf && leaf_visit()) return true;
-    }
+        for (;;) {
+            const bool in_node = cur >= 0 || cur == kPop;
+            const bool in_leaf = !in_node && cur != RL_CHILD_NONE;
+            const int n_node = __popcll(__ballot(in_node)), n_leaf = __popcll(__ballot(in_leaf));
+            if (n_node + n_leaf == 0) break;
+            if (n_node > 0 && n_node * RL_VOTE_DEN >= RL_VOTE_NUM * n_leaf) { if (in_node) node_trip(); }
+            else if (in_leaf && leaf_visit()) return true;
+        }
 #endif
+    }
     if (!ANY_HIT && found) {
-        const float4* q = recs.tris + 4 * hit.prim;
+        const float4* q = recs.tris + Stack::kTriStride4 * hit.prim;
         tri_uv(q[0], q[1], q[2], q[3], o, d, hit.t, &hit.u, &hit.v);
     }
     return found;
@@ -1113,6 +1153,22 @@ RL_DEV void stage_scene_lds(const DeviceScene& sc, float4* lds_nodes, float4* ld
         float v = gn[i];
         if (f >= 12u) { const int id = __float_as_int(v); if (id >= 0) v = __int_as_float(id * 4 * kLdsNodeStride); }   // byte offset
         ln[node * (unsigned)kLdsNodeStride + f] = v;
+    }
+    for (unsigned int i = threadIdx.x; i < 4u * sc.n_prims; i += blockDim.x) lds_tris[(i >> 2) * (unsigned)kLdsTriStride4 + (i & 3u)] = gt[i];
+    __syncthreads();
+}
+
+// The same with the nodes as two-level records (device_types.h: BvhNode2) kLdsNode2Stride dwords apart; inner references (slots and children) become byte offsets.
+RL_DEV void stage_scene_lds2(const DeviceScene& sc, float4* lds_nodes, float4* lds_tris) {
+    const float* gn = reinterpret_cast<const float*>(sc.nodes2);
+    const float4* gt = reinterpret_cast<const float4*>(sc.tris);
+    float* ln = reinterpret_cast<float*>(lds_nodes);
+    for (unsigned int i = threadIdx.x; i < 32u * sc.n_nodes; i += blockDim.x) {
+        const unsigned int node = i >> 5, f = i & 31u;
+        if (f >= 30u) continue;                                  // padding words of the 128-byte record
+        float v = gn[i];
+        if (f >= 24u) { const int id = __float_as_int(v); if (id >= 0) v = __int_as_float(id * 4 * kLdsNode2Stride); }   // byte offset
+        ln[node * (unsigned)kLdsNode2Stride + f] = v;
     }
     for (unsigned int i = threadIdx.x; i < 4u * sc.n_prims; i += blockDim.x) lds_tris[(i >> 2) * (unsigned)kLdsTriStride4 + (i & 3u)] = gt[i];
     __syncthreads();

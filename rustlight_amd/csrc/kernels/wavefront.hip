@@ -276,6 +276,7 @@ struct rl_context {
     bool lds_scene = false;
     bool area_lights_only = false;   // every emitter is a mesh area light, no light tree: the fused kernel's NEE code is specialised (same results)
     size_t scene_lds_bytes = 0;
+    size_t lds_limit = 64 * 1024;     // dynamic LDS a workgroup may ask for on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
     // render scratch (grown on demand)
     Pool pool{};
     size_t pool_capacity = 0;
@@ -419,12 +420,14 @@ extern "C" int rl_context_create(const rl_scene* scene, int device, rl_context**
         // stage the scene in LDS when nodes + triangles are small (<= 48 KiB leaves room for the stacks)
         ctx->scene_lds_bytes = (size_t)16 * lds_scene_float4s(ds.n_nodes, ds.n_prims);     // padded LDS layout (trace.hip.h)
         // LDS-staged scenes also keep their whole traversal stack in LDS (TravStackT<true>)
-        ctx->lds_scene = ctx->scene_lds_bytes <= 48 * 1024 && ds.stack_depth <= (uint32_t)kLdsStackLevels;
+        ctx->lds_scene = ctx->scene_lds_bytes <= 48 * 1024 && ds.stack_depth <= (uint32_t)kLdsStackLevels && (!RL_LDS_TWO_LEVEL || (size_t)16 * lds_scene2_float4s(ds.n_nodes, ds.n_prims) <= 64 * 1024);
         {   // worst-case dynamic LDS of any kernel that stages the scene: [scene][compaction list | cold path state][12 stack levels];
             // it must fit what a workgroup may ask for on this device, else the scene streams from L2 / HBM instead
             int lds_limit = 64 * 1024;
-            hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
-            const size_t worst = ctx->scene_lds_bytes + std::max<size_t>(272 * sizeof(unsigned), kFusedColdBytes) + (size_t)2 * kLdsStackLevels * 256 * sizeof(int);
+            if (hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess) { (void)hipGetLastError(); lds_limit = 64 * 1024; }
+            ctx->lds_limit = (size_t)std::max(lds_limit, 16 * 1024);
+            const size_t scene2 = RL_LDS_TWO_LEVEL ? (size_t)16 * lds_scene2_float4s(ds.n_nodes, ds.n_prims) : 0;      // k_path_fused's staging (two-level node records)
+            const size_t worst = std::max(ctx->scene_lds_bytes, scene2) + std::max<size_t>(272 * sizeof(unsigned), kFusedColdBytes) + (size_t)2 * kLdsStackLevels * 256 * sizeof(int);
             if (worst > (size_t)lds_limit) ctx->lds_scene = false;
         }
         if (getenv("RL_FORCE_STREAMING")) ctx->lds_scene = false;     // dev / test knob: small scenes through the kernels that stream the BVH (tests/parity_fuzz.py)
@@ -873,7 +876,9 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     };
     double ms_fused = 0.0, ms_chain = 0.0;
     unsigned long long spec_stat[3] = {0, 0, 0}; unsigned spec_group = 0;     // k_stream_spec's counters (rl_render_stats.reserved)
-    const size_t lds_fused = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + kFusedColdBytes + ((ctx->lds_scene || RL_COOP_FETCH != 1) ? 0 : (size_t)4 * kCoopStageFloat4s * sizeof(float4));
+    // (LDS-staged scenes: k_path_fused stages the nodes as two-level records, 144 instead of 68 bytes each)
+    const size_t lds_two_level_extra = (ctx->lds_scene && RL_LDS_TWO_LEVEL) ? (size_t)16 * (lds_scene2_float4s(ctx->ds.n_nodes, ctx->ds.n_prims) - lds_scene_float4s(ctx->ds.n_nodes, ctx->ds.n_prims)) : 0;
+    const size_t lds_fused = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + lds_two_level_extra + kFusedColdBytes + ((ctx->lds_scene || RL_COOP_FETCH != 1) ? 0 : (size_t)4 * kCoopStageFloat4s * sizeof(float4));
     auto launch_fused = [&](const RenderConst& rcl, dim3 grid) {
         (ctx->lds_scene ? (fast_math ? launch_fused_lds_fast : launch_fused_lds) : (fast_math ? launch_fused_stream_fast : launch_fused_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, ctx->area_lights_only, grid, block, lds_fused, st, rcl, ds, stc);
     };
@@ -892,7 +897,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         {
             const size_t want = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + (treelets ? (size_t)(256 / stc_c.pre_group) * (72 + (ctx->ds.stack_depth + 1) / 2) * 16
                                 : (stc_c.pre_group ? (size_t)(256 / stc_c.pre_group) * ((size_t)ctx->ds.n_nodes * 32 + (size_t)ctx->ds.n_prims * 8) : 0));
-            if (want > (size_t)64 * 1024) stc_c.pre_group = 0;
+            if (want > ctx->lds_limit) stc_c.pre_group = 0;
         }
         const bool treelets_on = treelets && stc_c.pre_group != 0;
         const size_t lds_chain = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + (treelets_on ? (size_t)(256 / stc_c.pre_group) * (72 + (ctx->ds.stack_depth + 1) / 2) * 16
@@ -908,6 +913,11 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             const double nbar = ctx->draws_per_sample > 0.0 ? ctx->draws_per_sample : (medium ? 150.0 : 12.0);
             if ((double)params->spp < 4.0 * nbar) spec = false;
         }
+        // its workgroup parks 30 words of state per lane + the groups' scratch in LDS on top of the scene and the stacks: where that exceeds what a workgroup may ask for on
+        // this device the launch would be refused — the serial chain (k_stream_chain), whose workgroup is the plain traversal one, renders those scenes instead
+        const size_t lds_spec = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + (size_t)kSpecColdWords * 256 * 4 + kSpecGroupLdsBytes;
+        const size_t spec_lds_limit = getenv("RL_SPEC_LDS_LIMIT_TEST") ? (size_t)atoll(getenv("RL_SPEC_LDS_LIMIT_TEST")) : ctx->lds_limit;      // (test knob: a device with a smaller limit)
+        if (lds_spec > spec_lds_limit) spec = false;
         SpecConf spc{};
         unsigned spec_threads = 0;
         unsigned long long spec_totals[32] = {0};
@@ -980,7 +990,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             ra.n_state_pixels = ch.n_pix; ra.cursor_begin = ch.c0; ra.cursor_end = ch.c1;
             hipLaunchKernelGGL(k_chunk_pixels, dim3(((unsigned)owned.size() + 63) / 64), dim3(64), 0, st, ra);
             if (timing) hipEventRecord(ctx->events[0], st);
-            if (spec) (ctx->lds_scene ? launch_spec_lds : launch_spec_stream)(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, dim3(spec_threads / 256u), block, traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + (size_t)kSpecColdWords * 256 * 4 + kSpecGroupLdsBytes, st, ra, ds, stc, spc);
+            if (spec) (ctx->lds_scene ? launch_spec_lds : launch_spec_stream)(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, dim3(spec_threads / 256u), block, lds_spec, st, ra, ds, stc, spc);
             else
             (ctx->lds_scene ? (fast_math ? launch_chain_lds_fast : launch_chain_lds) : (fast_math ? launch_chain_stream_fast : launch_chain_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, dim3((plan_chain.P + 255) / 256), block, lds_chain, st, ra, ds, stc_c);
             if (timing) hipEventRecord(ctx->events[1], st);

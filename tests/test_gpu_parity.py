@@ -1019,6 +1019,12 @@ def test_reference_order_speculative_chain(built, monkeypatch):
         for k in env: monkeypatch.delenv(k)
         assert st["spec_group"] == int(env["RL_SPEC_GROUP"])
         np.testing.assert_array_equal(img, whole[0], err_msg=str(env))
+    # a device whose workgroups may not ask for the pass's LDS (53 KB on this scene): the serial chain renders the frame instead of a refused launch
+    monkeypatch.setenv("RL_SPEC_LDS_LIMIT_TEST", "32768")
+    img, st = ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=40))
+    monkeypatch.delenv("RL_SPEC_LDS_LIMIT_TEST")
+    assert st["spec_group"] == 0 and st["ms_prepass"] > 0.0
+    np.testing.assert_array_equal(img, whole[0])
     # the policy: a frame this small at 40 spp is left to the serial chain unless forced; with the ~17 draws per sample the last render measured, 96 spp is enough
     monkeypatch.delenv("RL_SPEC_FORCE")
     img, st = ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=8))
