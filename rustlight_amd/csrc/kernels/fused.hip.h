@@ -98,7 +98,61 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
             RL_T1(3, has_shadow)
         }
     } else
-    while (!(PU(U_FLAGS) & ST_FINISHED)) {
+    {
+    // ---- the evaluation pass overlapped with the chain pass (rc.queue_mode != 0, reference-order streams): the lanes take their pixel items from the completion
+    // queue the chain kernel feeds (pathstate.hip.h: DoneQueue) instead of by lane index / from the dispenser.  A lane that needs work claims the next item position
+    // c (block position c / 256 split in completion order, item c % 256 split of that block); while the block's chain is still running the claim is PENDING and the
+    // lane sits out.  Mode 1 runs beside the chain pass (started by the host once every chain workgroup runs: waiting is then free of deadlock, the chain kernel
+    // never waits for this one); mode 2 after it, for whatever mode 1 did not take.
+    const bool qmode = rc_arg.queue_mode != 0u;
+    constexpr unsigned kQDone = 0xffffffffu;
+    if (qmode) {
+        PU(U_ITEM) = 0u;
+        PU(U_FLAGS) = ST_FINISHED;           // "needs a claim"
+        // (mode 1 before every chain workgroup has started — the host's gate kernel prevents it — would hold resources they need: leave at once, mode 2 takes everything)
+        if (rc_arg.queue_mode == 1u && __hip_atomic_load(&rc_arg.queue[Q_STARTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < rc_arg.chain_grid) PU(U_ITEM) = kQDone;
+    }
+    for (;;) {
+    if (qmode) {
+        unsigned* const q = rc_arg.queue;
+        const unsigned ipb = 256u * rc_arg.split, total = rc_arg.n_owned * ipb;
+        unsigned fl = PU(U_FLAGS);
+        for (int tries = 0; tries < 4; tries++) {       // (a claim can land past the end of a ragged block: claim again, a few times per trip)
+            if ((fl & ST_FINISHED) && !(fl & ST_PENDING) && PU(U_ITEM) != kQDone) {
+                const unsigned c = atomicAdd(&q[Q_HEAD], 1u);
+                if (c >= total) PU(U_ITEM) = kQDone;
+                else { PU(U_ITEM) = c; fl |= ST_PENDING; }
+            }
+            if (fl & ST_PENDING) {
+                const unsigned c = PU(U_ITEM);
+                const unsigned e = __hip_atomic_load(&q[Q_HDR + c / ipb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (e) {
+                    const unsigned j = e - 1u, idx = c - (c / ipb) * ipb;
+                    unsigned bx_, by_, bw_, bh_;
+                    block_geometry(rc_arg, rc_arg.owned_blocks[j], &bx_, &by_, &bw_, &bh_);
+                    const unsigned npx = min(rc_arg.cursor_end, bw_ * bh_) - min(rc_arg.cursor_begin, bw_ * bh_);
+                    fl &= ~ST_PENDING;
+                    if (idx < npx * rc_arg.split) {
+                        PU(U_ITEM) = rc_arg.block_item_base[j] * rc_arg.split + idx;
+                        PU(U_PRIM) = 0xffffffffu; PU(U_CURSOR) = 0u; PU(U_SAMPLE) = 0u;
+                        storec(ps, F_AR, czero());
+                        fl = ST_REGEN | ST_FRESH;
+                    } else PU(U_ITEM) = 0u;              // past the block's last pixel: needs another claim
+                }
+            }
+            if (__ballot((fl & ST_FINISHED) && !(fl & ST_PENDING) && PU(U_ITEM) != kQDone) == 0ull) break;
+        }
+        PU(U_FLAGS) = fl;
+        const unsigned long long run = __ballot(!(fl & ST_FINISHED)), pend = __ballot((fl & ST_PENDING) || ((fl & ST_FINISHED) && PU(U_ITEM) != kQDone));
+        if (run == 0ull) {
+            if (pend == 0ull) break;                     // every lane of the wave is done for good
+            __builtin_amdgcn_s_sleep(32);                // blocks still to come
+            continue;
+        }
+        if (__ballot(fl & ST_FRESH) != 0ull) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the sample states of the blocks just taken (their entries were read relaxed)
+    }
+    // (queue mode: ONE trip of the loop body, then back to the claims — a lane whose pixel is done takes its next item while the others go on, like the dispenser's lanes)
+    if (!(PU(U_FLAGS) & ST_FINISHED)) do {
 #if RL_RELOAD_SCENE
         // The scene record (25 pointers, camera matrices, ...) and the render constants do not fit the scalar registers next to the saved
         // exec masks of the stage functions: kept live across the loop they are spilled to VGPR lanes (v_writelane / v_readlane were ~600 of
@@ -133,6 +187,9 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
 #endif
         if (PU(U_FLAGS) & ST_SHADOW) shadow_slot(sc, recs, stack, ps);
         RL_T1(3, c3)
+    } while (!qmode && !(PU(U_FLAGS) & ST_FINISHED));
+    if (!qmode) break;
+    }
     }
 #ifdef RL_STAGE_TIMERS
     if ((threadIdx.x & 63u) == 0u) { for (int k = 0; k < 4; k++) { atomicAdd(&g_stage_timers[k], tm[k]); atomicAdd(&g_stage_timers[4 + k], ln[k]); } atomicAdd(&g_stage_timers[8], ln[4]); }

@@ -33,6 +33,7 @@ enum : unsigned {
     ST_PREV_SHIFT = 5u,    // 2 bits: kind of the vertex the traced edge leaves
     ST_PDF_SA = 128u,      // edge pdf is PDF::SolidAngle (else Discrete)
     ST_ZEROED = 256u,      // single_scattering: a surface vertex has been passed (path.rs:122-124)
+    ST_PENDING = 512u,     // k_path_fused fed from the completion queue: the lane holds a claim (in U_ITEM) on a block whose chain is not complete yet
 };
 enum : unsigned { PREV_SENSOR = 0u, PREV_SURFACE = 1u, PREV_SURFACE_SMOOTH = 2u, PREV_VOLUME = 3u };
 
@@ -123,7 +124,21 @@ struct RenderConst {
     unsigned n_state_pixels;            // pixels of this chunk (second index of sample_states)
     unsigned cursor_begin, cursor_end;  // k_stream_chain: the block cursors [begin, end) this chunk covers
     unsigned long long* chain_states;   // [owned block][4]: where a block's stream stands between two chunks
+    // the evaluation pass overlapped with the chain pass (round 5): the chain kernels push every block whose states are all recorded onto `queue`
+    // (DoneQueue words below), and k_path_fused — launched on a second stream while the chain pass still runs — takes its work from there, a wave at a time
+    unsigned* queue;                    // null: off
+    unsigned queue_mode;                // k_path_fused: 0 = items by lane index / dispenser, 1 = from the queue, waiting for blocks still to come, 2 = from the queue, what mode 1 left (every block is there)
+    unsigned units_per_block;           // (unused)
+    unsigned chain_grid;                // workgroups of the chain kernel (a waiting wave leaves when some of them have not started: it may be holding their place)
 };
+// DoneQueue: word indices into RenderConst::queue.  entries[k] = owned-block index + 1 of the k-th block whose chain is complete (0: not yet), written with release,
+// read with acquire (agent scope): the sample states of the block are visible to whoever sees its entry.
+enum : unsigned { Q_TAIL = 0, Q_HEAD, Q_STARTED, Q_HDR = 8 };      // then entries[n_owned]
+RL_DEV void queue_push(unsigned* q, unsigned item) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // this wave's stores of the block's sample states (all lanes': the counters the fence waits on are the wave's)
+    const unsigned slot = atomicAdd(&q[Q_TAIL], 1u);
+    __hip_atomic_store(&q[Q_HDR + slot], item + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
 // internal third value of RenderConst::stream_mode (never accepted from a caller): per-pixel work items as in RL_STREAM_PER_SAMPLE, but every
 // camera sample starts from the sampler state k_stream_chain recorded for it — the image and the counters of RL_STREAM_REFERENCE_ORDER
 enum : int { kStreamGivenStates = 2 };

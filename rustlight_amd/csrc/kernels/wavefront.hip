@@ -74,6 +74,14 @@ __global__ void k_chunk_pixels(RenderConst rc) {
     for (unsigned c = rc.cursor_begin; c < c_end; c++) rc.item_pixel[base + (c - rc.cursor_begin)] = (by + c / bw) * rc.W + (bx + c % bw);
 }
 
+// the gate of the overlapped evaluation pass (second stream): returns once EVERY workgroup of the chain kernel has started (or every block is already done), so that the
+// evaluation kernel enqueued behind it only ever takes resources the chain pass has no further use for — one wave, no LDS: it cannot be in a chain workgroup's way itself
+__global__ void k_queue_gate(const unsigned* q, unsigned chain_grid, unsigned n_owned) {
+    if (threadIdx.x == 0u)
+        while (__hip_atomic_load(&q[Q_STARTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chain_grid && __hip_atomic_load(&q[Q_TAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_owned)
+            __builtin_amdgcn_s_sleep(127);
+}
+
 __global__ void k_init(RenderConst rc, Pool pool) {
     unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= pool.P) return;
@@ -291,6 +299,7 @@ struct rl_context {
     Counters* h_counters = nullptr;   // pinned
     unsigned long long* d_partials = nullptr; size_t partials_capacity = 0;
     int* d_overflow = nullptr; size_t overflow_capacity = 0;
+    int* d_overflow2 = nullptr; size_t overflow2_capacity = 0;      // the overlapped evaluation pass's own overflow levels (it runs beside the chain pass, which uses d_overflow)
     float* d_sample_buf = nullptr; size_t sample_buf_capacity = 0;   // sample-parallel pixels: [spp][pixel item][3]
     unsigned long long* d_sample_states = nullptr; size_t sample_states_capacity = 0;   // reference-order streams, two passes: [spp][chunk pixel][4]
     unsigned long long* d_chain_states = nullptr; size_t chain_states_capacity = 0;     // [owned block][4]
@@ -302,6 +311,10 @@ struct rl_context {
     uint64_t trivial_key = ~0ull;         // (shard index, shard count, sensor expanded?) the masks on the device were computed for
     unsigned long long* d_spec_stats = nullptr; size_t spec_stats_capacity = 0;
     std::vector<hipEvent_t> events;
+    // the evaluation pass overlapped with the chain pass (reference-order streams): its own low-priority stream, the completion queue, ordering events
+    hipStream_t stream2 = nullptr;
+    unsigned* d_queue = nullptr; size_t done_queue_capacity = 0;
+    hipEvent_t ev_ready = nullptr, ev_overlap_done = nullptr, ev_chain_done = nullptr;
     BvhBuild bvh_dump;                // kept for rl_debug_bvh
 };
 
@@ -342,7 +355,14 @@ extern "C" int rl_context_create(const rl_scene* scene, int device, rl_context**
     ctx->width = scene->width; ctx->height = scene->height;
     int rc = RL_OK;
     do {
-        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rl_set_error("hipStreamCreate failed"); rc = RL_ERR_HIP; break; }
+        {   // the context's stream takes the highest priority the device offers, the overlapped evaluation pass's the lowest: where both have workgroups to place, the chain pass goes first
+            int prio_least = 0, prio_greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { (void)hipGetLastError(); prio_least = prio_greatest = 0; }
+            if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) { rl_set_error("hipStreamCreate failed"); rc = RL_ERR_HIP; break; }
+            if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_least) != hipSuccess) { (void)hipGetLastError(); ctx->stream2 = nullptr; }      // (no second stream: no overlap)
+            if (ctx->stream2 && (hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_overlap_done, hipEventDisableTiming) != hipSuccess ||
+                                 hipEventCreateWithFlags(&ctx->ev_chain_done, hipEventDisableTiming) != hipSuccess)) { (void)hipGetLastError(); hipStreamDestroy(ctx->stream2); ctx->stream2 = nullptr; }
+        }
         BvhBuild& bvh = ctx->bvh_dump;
         build_bvh(*scene, &bvh);                  // BVHAccel::new — untimed (mod.rs:280)
         FlatScene flat;
@@ -458,10 +478,12 @@ extern "C" void rl_context_destroy(rl_context* ctx) {
     for (void* p : ctx->allocs) hipFree(p);
     void* scratch[] = {ctx->pool.f, ctx->pool.u, ctx->pool.q, ctx->d_owned, ctx->d_item_base, ctx->d_block_seeds, ctx->d_item_seed,
                        ctx->d_item_pixel, ctx->d_queues, ctx->d_qcounts, ctx->d_out, ctx->d_counters, ctx->d_partials, ctx->d_overflow, ctx->d_sample_buf,
-                       ctx->d_sample_states, ctx->d_chain_states, ctx->d_trk_off, ctx->d_trk_st, ctx->d_trivial, ctx->d_spec_stats};
+                       ctx->d_sample_states, ctx->d_chain_states, ctx->d_trk_off, ctx->d_trk_st, ctx->d_trivial, ctx->d_spec_stats, ctx->d_queue, ctx->d_overflow2};
     for (void* p : scratch) if (p) hipFree(p);
     if (ctx->h_counters) hipHostFree(ctx->h_counters);
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
+    for (hipEvent_t ev : {ctx->ev_ready, ctx->ev_overlap_done, ctx->ev_chain_done}) if (ev) hipEventDestroy(ev);
+    if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -489,7 +511,9 @@ static size_t traversal_lds_bytes(const rl_context* ctx, bool lds_scene, unsigne
     return (lds_scene ? ctx->scene_lds_bytes : 0) + (with_list ? 272 * sizeof(unsigned) : 0) + stack;   // [scene][compaction list][stacks]
 }
 // overflow levels beyond the LDS part, [2 * levels][n_threads] ints
-static int stack_conf(rl_context* ctx, size_t n_threads, StackConf* out) {
+static int stack_conf(rl_context* ctx, size_t n_threads, StackConf* out, bool second = false) {
+    int*& d_overflow = second ? ctx->d_overflow2 : ctx->d_overflow;
+    size_t& overflow_capacity = second ? ctx->overflow2_capacity : ctx->overflow_capacity;
     out->lds_levels = lds_levels_of(ctx);
     out->pre_group = 0;          // only k_stream_chain uses it (its launch code sets it)
     out->overflow = nullptr;
@@ -497,13 +521,14 @@ static int stack_conf(rl_context* ctx, size_t n_threads, StackConf* out) {
     int extra = (int)std::max(ctx->ds.stack_depth, ctx->ds.stack_depth4) - out->lds_levels;     // (the tolerance build's BVH4 stacks are the deeper ones)
     if (extra > 0) {
         size_t need = (size_t)2 * extra * n_threads;
-        if (ctx->overflow_capacity < need) {
-            if (ctx->d_overflow) hipFree(ctx->d_overflow);
-            ctx->d_overflow = nullptr;
-            HIP_OK(hipMalloc((void**)&ctx->d_overflow, need * sizeof(int)));
-            ctx->overflow_capacity = need;
+        if (overflow_capacity < need) {
+            if (d_overflow) hipFree(d_overflow);
+            d_overflow = nullptr;
+            overflow_capacity = 0;
+            HIP_OK(hipMalloc((void**)&d_overflow, need * sizeof(int)));
+            overflow_capacity = need;
         }
-        out->overflow = ctx->d_overflow;
+        out->overflow = d_overflow;
     }
     return RL_OK;
 }
@@ -815,7 +840,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     init.active = std::min(plan.P, n_items);
     init.next_item = item_shift ? n_items : plan.P;
     if (!two_pass) HIP_OK(hipMemcpyAsync(ctx->d_counters, &init, sizeof(init), hipMemcpyHostToDevice, st));
-    const size_t n_partial_rows = (P + 255) / 256;
+    const size_t n_partial_rows = std::max<size_t>((P + 255) / 256, (size_t)cus * 8u);      // (the queue-fed evaluation launches use a grid of the resident workgroups)
     if ((rcode = ensure(&ctx->d_partials, &ctx->partials_capacity, n_partial_rows * STAT_COUNT)) != RL_OK) return rcode;
     HIP_OK(hipMemsetAsync(ctx->d_partials, 0, n_partial_rows * STAT_COUNT * sizeof(unsigned long long), st));
 
@@ -879,8 +904,8 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     // (LDS-staged scenes: k_path_fused stages the nodes as two-level records, 144 instead of 68 bytes each)
     const size_t lds_two_level_extra = (ctx->lds_scene && RL_LDS_TWO_LEVEL) ? (size_t)16 * (lds_scene2_float4s(ctx->ds.n_nodes, ctx->ds.n_prims) - lds_scene_float4s(ctx->ds.n_nodes, ctx->ds.n_prims)) : 0;
     const size_t lds_fused = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + lds_two_level_extra + kFusedColdBytes + ((ctx->lds_scene || RL_COOP_FETCH != 1) ? 0 : (size_t)4 * kCoopStageFloat4s * sizeof(float4));
-    auto launch_fused = [&](const RenderConst& rcl, dim3 grid) {
-        (ctx->lds_scene ? (fast_math ? launch_fused_lds_fast : launch_fused_lds) : (fast_math ? launch_fused_stream_fast : launch_fused_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, ctx->area_lights_only, grid, block, lds_fused, st, rcl, ds, stc);
+    auto launch_fused = [&](const RenderConst& rcl, dim3 grid, hipStream_t on, const StackConf* stcl = nullptr) {
+        (ctx->lds_scene ? (fast_math ? launch_fused_lds_fast : launch_fused_lds) : (fast_math ? launch_fused_stream_fast : launch_fused_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, ctx->area_lights_only, grid, block, lds_fused, on, rcl, ds, stcl ? *stcl : stc);
     };
     if (two_pass) {
         // tiny LDS-staged scenes (the Cornell box: 19 nodes + 36 triangles): the lanes of a chain's group precompute its ray's node / triangle records
@@ -981,38 +1006,75 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         StackConf stc_s = stc;
         if (spec && (rcode = stack_conf(ctx, std::max<size_t>((size_t)((P + 255) / 256) * 256, spec_threads), &stc_s)) != RL_OK) return rcode;
         if (spec) stc = stc_s;      // (one overflow buffer serves both passes: the stride is the larger launch)
+        // ---- the evaluation pass overlapped with the chain pass: one chunk, exact build, a group of the speculative pass inside one wave (the wave that pushes a block
+        // is the wave that wrote its states)
+        const bool overlap = ctx->stream2 && chunks.size() == 1 && !fast_math && !(spec && spc.group > 64u) && !getenv("RL_NO_OVERLAP");
         for (const Chunk& ch : chunks) {
-            // ---- pass 1: the chains
             HIP_OK(hipMemcpyAsync(ctx->d_item_base, ch.base.data(), ch.base.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
             RenderConst ra = rc;
             ra.stream_mode = RL_STREAM_REFERENCE_ORDER;
             ra.n_items = plan_chain.n_items; ra.item_shift = plan_chain.item_shift; ra.split = 1;
             ra.n_state_pixels = ch.n_pix; ra.cursor_begin = ch.c0; ra.cursor_end = ch.c1;
+            const unsigned chain_grid = spec ? spec_threads / 256u : (plan_chain.P + 255u) / 256u;
+            if (overlap) {
+                // the completion queue: header + one entry per owned block
+                if ((rcode = ensure(&ctx->d_queue, &ctx->done_queue_capacity, (size_t)Q_HDR + owned.size())) != RL_OK) return rcode;
+                HIP_OK(hipMemsetAsync(ctx->d_queue, 0, ((size_t)Q_HDR + owned.size()) * sizeof(unsigned), st));
+                ra.queue = ctx->d_queue;
+            }
             hipLaunchKernelGGL(k_chunk_pixels, dim3(((unsigned)owned.size() + 63) / 64), dim3(64), 0, st, ra);
+            // ---- pass 2 (planned before pass 1 is launched: overlapped, it starts beside it): every camera sample of the chunk from its recorded state, per-pixel work items
+            const Plan pb = plan_items(true, ch.n_pix, 0);
+            RenderConst rb = ra;
+            rb.stream_mode = kStreamGivenStates;
+            rb.n_items = pb.n_items; rb.item_shift = pb.item_shift; rb.split = pb.split;
+            rb.queue = nullptr; rb.queue_mode = 0u;
+            Counters cinit{};
+            cinit.active = std::min(pb.P, pb.n_items);
+            cinit.next_item = pb.item_shift ? pb.n_items : pb.P;
+            if (overlap) cinit.next_item = pb.n_items;          // (queue-fed: the dispenser has nothing to hand out)
+            HIP_OK(hipMemcpyAsync(ctx->d_counters, &cinit, sizeof(cinit), hipMemcpyHostToDevice, st));
+            // (overlapped: a grid of the workgroups the chip keeps resident; its overflow stack levels are its own — the chain kernel beside it spills into the context's
+            // first buffer under the same thread indices; allocated before anything is launched: an allocation may wait for the device)
+            const dim3 grid_q((unsigned)cus * (unsigned)(ctx->lds_scene ? RL_FUSED_WAVES : RL_FUSED_WAVES_STREAMING));
+            StackConf stc_q = stc;
+            if (overlap && (rcode = stack_conf(ctx, (size_t)grid_q.x * 256, &stc_q, true)) != RL_OK) return rcode;
+            if (overlap) {
+                HIP_OK(hipEventRecord(ctx->ev_ready, st));                      // counters, queue reset, item tables, framebuffer memset: all enqueued on `st` before this point
+                HIP_OK(hipStreamWaitEvent(ctx->stream2, ctx->ev_ready, 0));
+            }
+            // ---- pass 1: the chains
             if (timing) hipEventRecord(ctx->events[0], st);
             if (spec) (ctx->lds_scene ? launch_spec_lds : launch_spec_stream)(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, dim3(spec_threads / 256u), block, lds_spec, st, ra, ds, stc, spc);
             else
             (ctx->lds_scene ? (fast_math ? launch_chain_lds_fast : launch_chain_lds) : (fast_math ? launch_chain_stream_fast : launch_chain_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, dim3((plan_chain.P + 255) / 256), block, lds_chain, st, ra, ds, stc_c);
             if (timing) hipEventRecord(ctx->events[1], st);
-            // ---- pass 2: every camera sample of the chunk from its recorded state, per-pixel work items
-            const Plan pb = plan_items(true, ch.n_pix, 0);
-            RenderConst rb = ra;
-            rb.stream_mode = kStreamGivenStates;
-            rb.n_items = pb.n_items; rb.item_shift = pb.item_shift; rb.split = pb.split;
-            Counters cinit{};
-            cinit.active = std::min(pb.P, pb.n_items);
-            cinit.next_item = pb.item_shift ? pb.n_items : pb.P;
-            HIP_OK(hipMemcpyAsync(ctx->d_counters, &cinit, sizeof(cinit), hipMemcpyHostToDevice, st));
-            if (timing) hipEventRecord(ctx->events[2], st);
-            launch_fused(rb, dim3((pb.P + 255) / 256));
-            if (timing) hipEventRecord(ctx->events[3], st);
+            if (overlap) {
+                // Overlapped: k_path_fused in queue mode on the context's second (low-priority) stream WHILE the chain pass runs on `st` — its waves take the blocks the chain
+                // kernel reports complete (pathstate.hip.h: DoneQueue) — then once more on `st` for what is left when the chain pass has ended.  Same samples from the same
+                // states, folded per pixel in sample order: same bits (RL_NO_OVERLAP=1 keeps the two passes back to back: the cross-check).
+                rb.queue = ctx->d_queue; rb.chain_grid = chain_grid;
+                RenderConst rq = rb; rq.queue_mode = 1u;
+                hipLaunchKernelGGL(k_queue_gate, dim3(1), dim3(64), 0, ctx->stream2, ctx->d_queue, chain_grid, (unsigned)owned.size());
+                launch_fused(rq, grid_q, ctx->stream2, &stc_q);
+                HIP_OK(hipEventRecord(ctx->ev_overlap_done, ctx->stream2));
+                HIP_OK(hipStreamWaitEvent(st, ctx->ev_overlap_done, 0));
+                rq.queue_mode = 2u;
+                launch_fused(rq, grid_q, st, &stc_q);
+                if (timing) hipEventRecord(ctx->events[3], st);
+            } else {
+                if (timing) hipEventRecord(ctx->events[2], st);
+                launch_fused(rb, dim3((pb.P + 255) / 256), st);
+                if (timing) hipEventRecord(ctx->events[3], st);
+            }
             if (pb.split > 1) hipLaunchKernelGGL(k_fold_samples, dim3((ch.n_pix + 255) / 256), block, 0, st, rb);
             HIP_OK(hipGetLastError());
             HIP_OK(hipStreamSynchronize(st));       // (the chunk's host arrays and the counters block are reused by the next chunk)
             if (timing) {
                 float t = 0.0f;
                 HIP_OK(hipEventElapsedTime(&t, ctx->events[0], ctx->events[1])); ms_chain += t;
-                HIP_OK(hipEventElapsedTime(&t, ctx->events[2], ctx->events[3])); ms_fused += t;
+                // overlapped: what the evaluation pass still takes AFTER the chain pass has ended (the part of it that is not hidden)
+                HIP_OK(hipEventElapsedTime(&t, ctx->events[overlap ? 1 : 2], ctx->events[3])); ms_fused += t;
             }
             launches += 3 + (pb.split > 1 ? 1 : 0);
         }
@@ -1047,7 +1109,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         iterations = chunks.size();
     } else if (fused) {
         if (timing) hipEventRecord(ctx->events[0], st);
-        launch_fused(rc, grid_all);
+        launch_fused(rc, grid_all, st);
         if (timing) hipEventRecord(ctx->events[1], st);
         HIP_OK(hipGetLastError());          // a refused launch configuration is not sticky: without this the sync below would "succeed"
         HIP_OK(hipStreamSynchronize(st));

@@ -931,6 +931,43 @@ def test_reference_order_two_pass_equals_single_pass(built, monkeypatch):
     assert all(sa[k] == sb[k] for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws"))
 
 
+def test_overlapped_evaluation_pass_equals_back_to_back(built, monkeypatch):
+    """Reference-order streams, round 5: the evaluation pass (k_path_fused from the recorded sampler states) runs BESIDE the chain pass on a second stream — the chain kernels
+    push every block whose states are all recorded onto a completion queue (release), the evaluation kernel's lanes claim pixel items of completed blocks from it (acquire)
+    — instead of after it (RL_NO_OVERLAP=1: the two passes back to back, the form rounds 3-4 shipped).  Same samples from the same states, folded per pixel in sample
+    order: the image and every counter must be identical, and identical to the oracle's — on LDS-staged and streamed scenes (the streamed ones keep a second set of
+    overflow stack levels for the kernel that runs beside the chain kernel), with a medium, through both chain kernels (speculative, forced; serial), ragged frames,
+    shards with several lanes per pixel, and repeatedly on one context (the queue is reset per render).  src/integrators/mod.rs:420-448."""
+    ref_mode = api.STREAM_REFERENCE_ORDER
+    keys = ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws")
+    cases = [(scenes.cbox(70, 41), dict(spp=24), {}),
+             (scenes.cbox(96, 64), dict(spp=40), dict(RL_SPEC_FORCE="1")),
+             (scenes.cbox_medium(40, 40, 0.8, 0.2, g=0.6), dict(spp=6), {}),
+             (scenes.living_room(64, 48, n_spheres=27, tess=10), dict(spp=12, max_depth=10), {}),
+             (scenes.living_room(64, 48, n_spheres=27, tess=10), dict(spp=16, max_depth=10), dict(RL_SPEC_FORCE="1", RL_FORCE_STREAMING="1")),
+             (scenes.cbox(48, 48), dict(spp=9), dict(RL_FORCE_STREAMING="1")),
+             (scenes.many_lights(48, 48, n=5, use_ats=True), dict(spp=6, max_depth=4), {}),
+             (scenes.cbox(160, 200), dict(spp=32, sample_split=4), {}),
+             (scenes.cbox(160, 200), dict(spp=32, shard_index=1, shard_count=3), dict(RL_SPEC_FORCE="1"))]
+    for n_case, (sd, kw, env) in enumerate(cases):
+        for k, v in env.items(): monkeypatch.setenv(k, v)
+        ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+        seeds = api.IndependentSampler(5).block_seeds(sd.width, sd.height)
+        monkeypatch.setenv("RL_NO_OVERLAP", "1")
+        base, st0 = ctx.render(seeds, api.path_params(stream_mode=ref_mode, **kw))
+        monkeypatch.delenv("RL_NO_OVERLAP")
+        for rep in range(3):
+            img, st = ctx.render(seeds, api.path_params(stream_mode=ref_mode, **kw))
+            np.testing.assert_array_equal(img, base, err_msg=f"case {n_case} rep {rep}")
+            assert all(st[k] == st0[k] for k in keys), (n_case, rep)
+            assert st["ms_prepass"] > 0.0
+        okw = {k: v for k, v in kw.items() if k != "sample_split"}
+        ref, ost = osc.render(seeds=seeds, stream_mode=0, eval_order=1, **okw)
+        np.testing.assert_array_equal(base, ref, err_msg=f"case {n_case} vs the oracle")
+        assert all(st0[k] == ost[k] for k in ("vertices", "rng_draws", "shadow_rays", "extension_rays")), n_case
+        for k in env: monkeypatch.delenv(k)
+
+
 def test_rng_advance_equals_stepping(built):
     """rng_advance (csrc/kernels/rngjump.h: the jump polynomials x^(2^b) mod P of Xoshiro256's state transition, derived by scratch/r4/xoshiro_jump.py and
     checked there against the generator's published JUMP / LONG_JUMP constants) against plain stepping of the oracle's sampler, on the device."""
