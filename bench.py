@@ -396,6 +396,7 @@ def main():
             kernels["k_path_fused"] = {"avg_launch_ms": avg, "launches": args.steps, "algorithmic_bytes_per_unit": "248/sample + 352/vertex + 12/pixel",
                                        "achieved_GBps": gbs, "frac": gbs / PEAK_HBM_GBPS}
         if ms["ms_prepass"] > 0.0:
+            # (two passes: the evaluation kernel runs beside the chain pass since round 5; ms_other is what of it was left after the chain pass ended)
             avg = ms["ms_prepass"] / args.steps
             gbs = (32 * agg["camera_samples"] + 44 * agg["extension_rays"]) / args.steps / (avg * 1e-3) / 1e9
             kernels["k_stream_spec" if main_rec["spec"]["spec_group"] else "k_stream_chain"] = {"avg_launch_ms": avg, "launches": args.steps, "algorithmic_bytes_per_unit": "32/sample + 44/extension ray",
@@ -452,6 +453,9 @@ def main():
                 r["oracle_crc_match"] = None if want is None else want == r["image_crc32"]        # the last timed frame against the CPU oracle's render of it
                 if rec["spec"]["spec_group"]:
                     r["chain_pass"] = dict(rec["spec"], note="k_stream_spec: lanes per block, samples walked speculatively / serially / by the estimate probes in the last step")
+                if m["ms_prepass"] > 0:
+                    r["overlap_note"] = ("reference-order streams: k_path_fused runs BESIDE the chain pass on the context's second stream, fed by the chain kernel's completion queue "
+                                         "(DESIGN.md 4 (4)); its kernel_ms is the part of it that was still running after the chain pass had ended, so the two entries add up to the step")
                 # utilisation of the record's longest kernel, when profiles/pmc_live.json holds its counters
                 longest = max(kernel_ms, key=kernel_ms.get) if kernel_ms else None
                 u = utilisation_fields(live, f"{scene_name}:{width}x{height}x{rec['spp']}:{rec['stream_mode']}:exact", longest, src_hash)

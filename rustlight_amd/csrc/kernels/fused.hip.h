@@ -112,14 +112,22 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
         // (mode 1 before every chain workgroup has started — the host's gate kernel prevents it — would hold resources they need: leave at once, mode 2 takes everything)
         if (rc_arg.queue_mode == 1u && __hip_atomic_load(&rc_arg.queue[Q_STARTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < rc_arg.chain_grid) PU(U_ITEM) = kQDone;
     }
+    unsigned long long q_t0 = qmode ? wall_clock64() : 0ull;      // the last time this wave saw the chain pass make progress
+    unsigned q_tail = 0u;
     for (;;) {
     if (qmode) {
+        // (the render constants re-read from the kernarg segment, like the loop body does: kept in scalar registers across the loop they cost the medium kernel 82 spilled SGPRs)
+        const char __attribute__((address_space(4)))* kq = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kq));
+        const RenderConst& rc_arg = *(const RenderConst*)kq;
         unsigned* const q = rc_arg.queue;
         const unsigned ipb = 256u * rc_arg.split, total = rc_arg.n_owned * ipb;
         unsigned fl = PU(U_FLAGS);
         for (int tries = 0; tries < 4; tries++) {       // (a claim can land past the end of a ragged block: claim again, a few times per trip)
             if ((fl & ST_FINISHED) && !(fl & ST_PENDING) && PU(U_ITEM) != kQDone) {
-                const unsigned c = atomicAdd(&q[Q_HEAD], 1u);
+                unsigned c = 0xffffffffu;
+                if (rc_arg.queue_mode == 2u) { const unsigned li = atomicAdd(&q[Q_LEFT_HEAD], 1u); if (li < min(q[Q_N_LEFT], q[Q_LEFT_CAP])) c = q[Q_HDR + rc_arg.n_owned + li]; }      // claims the launch before this one handed back
+                if (c == 0xffffffffu) c = atomicAdd(&q[Q_HEAD], 1u);
                 if (c >= total) PU(U_ITEM) = kQDone;
                 else { PU(U_ITEM) = c; fl |= ST_PENDING; }
             }
@@ -146,7 +154,17 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
         const unsigned long long run = __ballot(!(fl & ST_FINISHED)), pend = __ballot((fl & ST_PENDING) || ((fl & ST_FINISHED) && PU(U_ITEM) != kQDone));
         if (run == 0ull) {
             if (pend == 0ull) break;                     // every lane of the wave is done for good
-            __builtin_amdgcn_s_sleep(32);                // blocks still to come
+            // blocks still to come — but never wait without bound: no block completed for kQueuePatience ticks => give up (see pathstate.hip.h)
+            const unsigned tail_now = __hip_atomic_load(&q[Q_TAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long now = wall_clock64();
+            if (tail_now != q_tail) { q_tail = tail_now; q_t0 = now; }
+            else if (now - q_t0 > kQueuePatience) {
+                if (rc_arg.queue_mode == 1u) {
+                    if (fl & ST_PENDING) { const unsigned li = atomicAdd(&q[Q_N_LEFT], 1u); if (li < q[Q_LEFT_CAP]) q[Q_HDR + rc_arg.n_owned + li] = PU(U_ITEM); else atomicExch(&q[Q_ERROR], 2u); }
+                } else atomicExch(&q[Q_ERROR], 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(32);
             continue;
         }
         if (__ballot(fl & ST_FRESH) != 0ull) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the sample states of the blocks just taken (their entries were read relaxed)

@@ -133,7 +133,11 @@ struct RenderConst {
 };
 // DoneQueue: word indices into RenderConst::queue.  entries[k] = owned-block index + 1 of the k-th block whose chain is complete (0: not yet), written with release,
 // read with acquire (agent scope): the sample states of the block are visible to whoever sees its entry.
-enum : unsigned { Q_TAIL = 0, Q_HEAD, Q_STARTED, Q_HDR = 8 };      // then entries[n_owned]
+enum : unsigned { Q_TAIL = 0, Q_HEAD, Q_STARTED, Q_N_LEFT, Q_LEFT_HEAD, Q_LEFT_CAP, Q_ERROR, Q_HDR = 8 };      // then entries[n_owned], then left[Q_LEFT_CAP] (claims handed back)
+// No wait on the queue is unbounded: a waiter that sees no block complete for kQueuePatience ticks of the 100 MHz clock gives up — the gate opens, a lane of the
+// launch beside the chain pass hands its claim back (the launch after the chain pass renders it), and that last launch, which finds every entry in place unless
+// something is broken, raises Q_ERROR (the host returns RL_ERR_HIP) instead of spinning.
+static constexpr unsigned long long kQueuePatience = 1500000000ull;      // 15 s
 RL_DEV void queue_push(unsigned* q, unsigned item) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // this wave's stores of the block's sample states (all lanes': the counters the fence waits on are the wave's)
     const unsigned slot = atomicAdd(&q[Q_TAIL], 1u);

@@ -77,9 +77,18 @@ __global__ void k_chunk_pixels(RenderConst rc) {
 // the gate of the overlapped evaluation pass (second stream): returns once EVERY workgroup of the chain kernel has started (or every block is already done), so that the
 // evaluation kernel enqueued behind it only ever takes resources the chain pass has no further use for — one wave, no LDS: it cannot be in a chain workgroup's way itself
 __global__ void k_queue_gate(const unsigned* q, unsigned chain_grid, unsigned n_owned) {
-    if (threadIdx.x == 0u)
-        while (__hip_atomic_load(&q[Q_STARTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chain_grid && __hip_atomic_load(&q[Q_TAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_owned)
+    if (threadIdx.x == 0u) {
+        unsigned long long t0 = wall_clock64();
+        unsigned seen = 0u;
+        for (;;) {
+            const unsigned started = __hip_atomic_load(&q[Q_STARTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (started >= chain_grid || __hip_atomic_load(&q[Q_TAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_owned) break;
+            const unsigned long long now = wall_clock64();
+            if (started != seen) { seen = started; t0 = now; }
+            else if (now - t0 > kQueuePatience) break;      // (never wait without bound: the evaluation kernel behind the gate then leaves at once and the launch after the chain pass renders everything)
             __builtin_amdgcn_s_sleep(127);
+        }
+    }
 }
 
 __global__ void k_init(RenderConst rc, Pool pool) {
@@ -1017,9 +1026,11 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             ra.n_state_pixels = ch.n_pix; ra.cursor_begin = ch.c0; ra.cursor_end = ch.c1;
             const unsigned chain_grid = spec ? spec_threads / 256u : (plan_chain.P + 255u) / 256u;
             if (overlap) {
-                // the completion queue: header + one entry per owned block
-                if ((rcode = ensure(&ctx->d_queue, &ctx->done_queue_capacity, (size_t)Q_HDR + owned.size())) != RL_OK) return rcode;
+                // the completion queue: header + one entry per owned block + one slot per lane of the queue-fed launch for a claim handed back
+                const unsigned left_cap = (unsigned)cus * 8u * 256u;
+                if ((rcode = ensure(&ctx->d_queue, &ctx->done_queue_capacity, (size_t)Q_HDR + owned.size() + left_cap)) != RL_OK) return rcode;
                 HIP_OK(hipMemsetAsync(ctx->d_queue, 0, ((size_t)Q_HDR + owned.size()) * sizeof(unsigned), st));
+                HIP_OK(hipMemcpyAsync(ctx->d_queue + Q_LEFT_CAP, &left_cap, sizeof(unsigned), hipMemcpyHostToDevice, st));
                 ra.queue = ctx->d_queue;
             }
             hipLaunchKernelGGL(k_chunk_pixels, dim3(((unsigned)owned.size() + 63) / 64), dim3(64), 0, st, ra);
@@ -1069,7 +1080,10 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             }
             if (pb.split > 1) hipLaunchKernelGGL(k_fold_samples, dim3((ch.n_pix + 255) / 256), block, 0, st, rb);
             HIP_OK(hipGetLastError());
+            unsigned queue_error = 0u;
+            if (overlap) HIP_OK(hipMemcpyAsync(&queue_error, ctx->d_queue + Q_ERROR, sizeof(unsigned), hipMemcpyDeviceToHost, st));
             HIP_OK(hipStreamSynchronize(st));       // (the chunk's host arrays and the counters block are reused by the next chunk)
+            if (queue_error) { rl_set_error("reference-order streams: the evaluation pass gave up waiting for the chain pass's completion queue (code " + std::to_string(queue_error) + "); RL_NO_OVERLAP=1 renders the two passes back to back"); return RL_ERR_HIP; }
             if (timing) {
                 float t = 0.0f;
                 HIP_OK(hipEventElapsedTime(&t, ctx->events[0], ctx->events[1])); ms_chain += t;
