@@ -12,7 +12,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "librustlight_amd.so")
 BIN = os.path.join(LIB_DIR, "rustlight-amd")
 
-HIP_SOURCES = ["kernels/wavefront.hip", "kernels/fused_lds.hip", "kernels/fused_stream.hip", "kernels/fused_lds_fast.hip", "kernels/fused_stream_fast.hip", "kernels/chain_lds.hip", "kernels/chain_stream.hip", "kernels/chain_lds_fast.hip", "kernels/chain_stream_fast.hip", "kernels/spec_lds.hip", "kernels/spec_stream.hip", "kernels/shade.hip", "kernels/mc.hip", "host/multigpu.hip"]     # multigpu.hip: N device contexts + the RCCL framebuffer reduce
+HIP_SOURCES = ["kernels/wavefront.hip", "kernels/fused_lds.hip", "kernels/fused_stream.hip", "kernels/fusedq_lds.hip", "kernels/fusedq_stream.hip", "kernels/fused_lds_fast.hip", "kernels/fused_stream_fast.hip", "kernels/chain_lds.hip", "kernels/chain_stream.hip", "kernels/chain_lds_fast.hip", "kernels/chain_stream_fast.hip", "kernels/spec_lds.hip", "kernels/spec_stream.hip", "kernels/shade.hip", "kernels/mc.hip", "host/multigpu.hip"]     # multigpu.hip: N device contexts + the RCCL framebuffer reduce
 CXX_SOURCES = ["host/frames.cpp", "host/scene.cpp", "host/bvh.cpp", "host/io.cpp", "host/pbrt.cpp", "host/meshio.cpp", "host/mitsuba.cpp", "host/lighttree.cpp"]
 # -ffp-contract=off: rustlight's f32 arithmetic is never contracted into FMAs
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-value", "-Wno-unused-function"]

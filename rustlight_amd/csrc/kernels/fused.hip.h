@@ -6,6 +6,9 @@
 #ifndef RL_RELOAD_SCENE
 #define RL_RELOAD_SCENE 1    // persistent loop re-reads scene / render constants from the kernarg segment per iteration (see k_path_fused)
 #endif
+#ifndef RL_FUSED_QUEUE
+#define RL_FUSED_QUEUE 0    // 1 (fusedq_lds.hip / fusedq_stream.hip): this translation unit instantiates the queue-fed form of the kernel
+#endif
 #ifndef RL_COOP_FETCH
 #define RL_COOP_FETCH 0     // 1 / 2: streaming scenes fetch BVH records wave-cooperatively (trace.hip.h: traverse_coop; 1 = LDS staging, 2 = registers + ds_bpermute) — both measured slower, kept for the record
 #endif
@@ -21,7 +24,9 @@ namespace rl {
 #ifdef RL_STAGE_TIMERS
 __device__ unsigned long long g_stage_timers[16];
 #endif
-template <int MAT, bool MEDIUM, bool LDS_SCENE, int LIGHTS, int NUM>
+// QUEUE: the form that takes its work from the chain pass's completion queue (the evaluation pass of reference-order streams, launched beside the chain pass): an
+// instantiation of its own (fusedq_lds.hip / fusedq_stream.hip), so that the per-sample kernel's code is exactly what it is without it
+template <int MAT, bool MEDIUM, bool LDS_SCENE, int LIGHTS, int NUM, bool QUEUE = false>
 __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAVES_STREAMING) k_path_fused(RenderConst rc_arg, DeviceScene sc_arg, StackConf stc) {
     const RenderConst& rc = rc_arg;
     const DeviceScene& sc = sc_arg;
@@ -104,18 +109,18 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
     // c (block position c / 256 split in completion order, item c % 256 split of that block); while the block's chain is still running the claim is PENDING and the
     // lane sits out.  Mode 1 runs beside the chain pass (started by the host once every chain workgroup runs: waiting is then free of deadlock, the chain kernel
     // never waits for this one); mode 2 after it, for whatever mode 1 did not take.
-    const bool qmode = rc_arg.queue_mode != 0u;
+    constexpr bool qmode = QUEUE;
     constexpr unsigned kQDone = 0xffffffffu;
-    if (qmode) {
+    if constexpr (qmode) {
         PU(U_ITEM) = 0u;
         PU(U_FLAGS) = ST_FINISHED;           // "needs a claim"
         // (mode 1 before every chain workgroup has started — the host's gate kernel prevents it — would hold resources they need: leave at once, mode 2 takes everything)
         if (rc_arg.queue_mode == 1u && __hip_atomic_load(&rc_arg.queue[Q_STARTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < rc_arg.chain_grid) PU(U_ITEM) = kQDone;
     }
-    unsigned long long q_t0 = qmode ? wall_clock64() : 0ull;      // the last time this wave saw the chain pass make progress
-    unsigned q_tail = 0u;
+    [[maybe_unused]] unsigned long long q_t0 = qmode ? wall_clock64() : 0ull;      // the last time this wave saw the chain pass make progress
+    [[maybe_unused]] unsigned q_tail = 0u;
     for (;;) {
-    if (qmode) {
+    if constexpr (qmode) {
         // (the render constants re-read from the kernarg segment, like the loop body does: kept in scalar registers across the loop they cost the medium kernel 82 spilled SGPRs)
         const char __attribute__((address_space(4)))* kq = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kq));
@@ -222,10 +227,10 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
 
 template <bool LDS_SCENE, int MAT>
 static void launch_fused_mat(bool medium, bool area_only, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc) {
-    if (medium) { if (area_only) hipLaunchKernelGGL((k_path_fused<MAT, true, LDS_SCENE, LIGHTS_AREA_ONLY, RL_NUMERICS_ID>), grid, block, lds_bytes, st, rc, ds, stc);
-                  else hipLaunchKernelGGL((k_path_fused<MAT, true, LDS_SCENE, LIGHTS_ANY, RL_NUMERICS_ID>), grid, block, lds_bytes, st, rc, ds, stc); }
-    else { if (area_only) hipLaunchKernelGGL((k_path_fused<MAT, false, LDS_SCENE, LIGHTS_AREA_ONLY, RL_NUMERICS_ID>), grid, block, lds_bytes, st, rc, ds, stc);
-           else hipLaunchKernelGGL((k_path_fused<MAT, false, LDS_SCENE, LIGHTS_ANY, RL_NUMERICS_ID>), grid, block, lds_bytes, st, rc, ds, stc); }
+    if (medium) { if (area_only) hipLaunchKernelGGL((k_path_fused<MAT, true, LDS_SCENE, LIGHTS_AREA_ONLY, RL_NUMERICS_ID, RL_FUSED_QUEUE != 0>), grid, block, lds_bytes, st, rc, ds, stc);
+                  else hipLaunchKernelGGL((k_path_fused<MAT, true, LDS_SCENE, LIGHTS_ANY, RL_NUMERICS_ID, RL_FUSED_QUEUE != 0>), grid, block, lds_bytes, st, rc, ds, stc); }
+    else { if (area_only) hipLaunchKernelGGL((k_path_fused<MAT, false, LDS_SCENE, LIGHTS_AREA_ONLY, RL_NUMERICS_ID, RL_FUSED_QUEUE != 0>), grid, block, lds_bytes, st, rc, ds, stc);
+           else hipLaunchKernelGGL((k_path_fused<MAT, false, LDS_SCENE, LIGHTS_ANY, RL_NUMERICS_ID, RL_FUSED_QUEUE != 0>), grid, block, lds_bytes, st, rc, ds, stc); }
 }
 template <bool LDS_SCENE>
 static void launch_fused_impl(int mat, bool medium, bool area_only, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc) {

@@ -17,6 +17,9 @@ void launch_fused_stream(int mat, bool medium, bool area_only, dim3 grid, dim3 b
 // the same kernels built with RL_FAST_MATH (fused_*_fast.hip): rl_path_params.numerics = RL_NUMERICS_FAST
 void launch_fused_lds_fast(int mat, bool medium, bool area_only, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc);
 void launch_fused_stream_fast(int mat, bool medium, bool area_only, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc);
+// the queue-fed form (exact build): the evaluation pass of reference-order streams beside the chain pass (fusedq_*.hip)
+void launch_fusedq_lds(int mat, bool medium, bool area_only, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc);
+void launch_fusedq_stream(int mat, bool medium, bool area_only, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc);
 // k_stream_chain (chain.hip.h): first pass of reference-order streams — one lane per 16x16 block records the sampler state at the start of every sample
 void launch_chain_lds(int mat, bool medium, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc);
 void launch_chain_stream(int mat, bool medium, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const RenderConst& rc, const DeviceScene& ds, const StackConf& stc);

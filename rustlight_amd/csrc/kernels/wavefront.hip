@@ -914,6 +914,9 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     const size_t lds_two_level_extra = (ctx->lds_scene && RL_LDS_TWO_LEVEL) ? (size_t)16 * (lds_scene2_float4s(ctx->ds.n_nodes, ctx->ds.n_prims) - lds_scene_float4s(ctx->ds.n_nodes, ctx->ds.n_prims)) : 0;
     const size_t lds_fused = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false) + lds_two_level_extra + kFusedColdBytes + ((ctx->lds_scene || RL_COOP_FETCH != 1) ? 0 : (size_t)4 * kCoopStageFloat4s * sizeof(float4));
     auto launch_fused = [&](const RenderConst& rcl, dim3 grid, hipStream_t on, const StackConf* stcl = nullptr) {
+        if (rcl.queue_mode != 0u)       // (exact build only: `overlap` is off in the tolerance build)
+            (ctx->lds_scene ? launch_fusedq_lds : launch_fusedq_stream)(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, ctx->area_lights_only, grid, block, lds_fused, on, rcl, ds, stcl ? *stcl : stc);
+        else
         (ctx->lds_scene ? (fast_math ? launch_fused_lds_fast : launch_fused_lds) : (fast_math ? launch_fused_stream_fast : launch_fused_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, ctx->area_lights_only, grid, block, lds_fused, on, rcl, ds, stcl ? *stcl : stc);
     };
     if (two_pass) {
