@@ -47,8 +47,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_CHAIN_WAVES : RL_CHAIN_WAV
         recs.tris = reinterpret_cast<const float4*>(sc0.tris);
     }
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rc_arg.queue) __builtin_amdgcn_s_setprio(3);      // the chain pass is the critical path: its waves issue ahead of the evaluation pass's that run beside them
-    if (rc_arg.queue && threadIdx.x == 0u) atomicAdd(&rc_arg.queue[Q_STARTED], 1u);      // (a wave of the overlapped evaluation pass that waits for a block only keeps waiting once every chain workgroup runs)
+    if (rc_arg.queue && threadIdx.x == 0u) queue_workgroup_started(rc_arg);      // (the host launches the evaluation pass beside this kernel once EVERY workgroup of it runs)
     // LDS: [scene][per-lane stacks]; the whole chain state lives in registers (no per-sample-cold radiance state to park)
     const TravStackT<LDS_SCENE> stack = make_stack<LDS_SCENE>(stc, reinterpret_cast<unsigned*>(after_scene), tid);
     RegState ps;

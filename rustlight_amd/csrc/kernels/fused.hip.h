@@ -104,75 +104,47 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
         }
     } else
     {
-    // ---- the evaluation pass overlapped with the chain pass (rc.queue_mode != 0, reference-order streams): the lanes take their pixel items from the completion
-    // queue the chain kernel feeds (pathstate.hip.h: DoneQueue) instead of by lane index / from the dispenser.  A lane that needs work claims the next item position
-    // c (block position c / 256 split in completion order, item c % 256 split of that block); while the block's chain is still running the claim is PENDING and the
-    // lane sits out.  Mode 1 runs beside the chain pass (started by the host once every chain workgroup runs: waiting is then free of deadlock, the chain kernel
-    // never waits for this one); mode 2 after it, for whatever mode 1 did not take.
+    // ---- QUEUE form (the evaluation pass of reference-order streams beside the chain pass): the lanes take their pixel items from this launch's block list — item
+    // position c = block c / (256 split) of the list, item c % (256 split) of that block — through one claim counter, like the dispenser's lanes; every block of the list is
+    // complete (the host only lists blocks the chain kernel has flagged), so nothing here waits.
     constexpr bool qmode = QUEUE;
     constexpr unsigned kQDone = 0xffffffffu;
     if constexpr (qmode) {
         PU(U_ITEM) = 0u;
         PU(U_FLAGS) = ST_FINISHED;           // "needs a claim"
-        // (mode 1 before every chain workgroup has started — the host's gate kernel prevents it — would hold resources they need: leave at once, mode 2 takes everything)
-        if (rc_arg.queue_mode == 1u && __hip_atomic_load(&rc_arg.queue[Q_STARTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < rc_arg.chain_grid) PU(U_ITEM) = kQDone;
     }
-    [[maybe_unused]] unsigned long long q_t0 = qmode ? wall_clock64() : 0ull;      // the last time this wave saw the chain pass make progress
-    [[maybe_unused]] unsigned q_tail = 0u;
     for (;;) {
     if constexpr (qmode) {
         // (the render constants re-read from the kernarg segment, like the loop body does: kept in scalar registers across the loop they cost the medium kernel 82 spilled SGPRs)
         const char __attribute__((address_space(4)))* kq = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kq));
         const RenderConst& rc_arg = *(const RenderConst*)kq;
-        unsigned* const q = rc_arg.queue;
-        const unsigned ipb = 256u * rc_arg.split, total = rc_arg.n_owned * ipb;
+        const unsigned ipb = 256u * rc_arg.split, total = rc_arg.q_n * ipb;
         unsigned fl = PU(U_FLAGS);
         for (int tries = 0; tries < 4; tries++) {       // (a claim can land past the end of a ragged block: claim again, a few times per trip)
-            if ((fl & ST_FINISHED) && !(fl & ST_PENDING) && PU(U_ITEM) != kQDone) {
-                unsigned c = 0xffffffffu;
-                if (rc_arg.queue_mode == 2u) { const unsigned li = atomicAdd(&q[Q_LEFT_HEAD], 1u); if (li < min(q[Q_N_LEFT], q[Q_LEFT_CAP])) c = q[Q_HDR + rc_arg.n_owned + li]; }      // claims the launch before this one handed back
-                if (c == 0xffffffffu) c = atomicAdd(&q[Q_HEAD], 1u);
+            if ((fl & ST_FINISHED) && PU(U_ITEM) != kQDone) {
+                const unsigned c = atomicAdd(rc_arg.q_ctr, 1u);
                 if (c >= total) PU(U_ITEM) = kQDone;
-                else { PU(U_ITEM) = c; fl |= ST_PENDING; }
-            }
-            if (fl & ST_PENDING) {
-                const unsigned c = PU(U_ITEM);
-                const unsigned e = __hip_atomic_load(&q[Q_HDR + c / ipb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (e) {
-                    const unsigned j = e - 1u, idx = c - (c / ipb) * ipb;
+                else {
+                    const unsigned j = rc_arg.q_list[c / ipb], idx = c - (c / ipb) * ipb;
                     unsigned bx_, by_, bw_, bh_;
                     block_geometry(rc_arg, rc_arg.owned_blocks[j], &bx_, &by_, &bw_, &bh_);
                     const unsigned npx = min(rc_arg.cursor_end, bw_ * bh_) - min(rc_arg.cursor_begin, bw_ * bh_);
-                    fl &= ~ST_PENDING;
                     if (idx < npx * rc_arg.split) {
                         PU(U_ITEM) = rc_arg.block_item_base[j] * rc_arg.split + idx;
                         PU(U_PRIM) = 0xffffffffu; PU(U_CURSOR) = 0u; PU(U_SAMPLE) = 0u;
                         storec(ps, F_AR, czero());
                         fl = ST_REGEN | ST_FRESH;
-                    } else PU(U_ITEM) = 0u;              // past the block's last pixel: needs another claim
+                    }                                   // else: past the block's last pixel, claim again
                 }
             }
-            if (__ballot((fl & ST_FINISHED) && !(fl & ST_PENDING) && PU(U_ITEM) != kQDone) == 0ull) break;
+            if (__ballot((fl & ST_FINISHED) && PU(U_ITEM) != kQDone) == 0ull) break;
         }
         PU(U_FLAGS) = fl;
-        const unsigned long long run = __ballot(!(fl & ST_FINISHED)), pend = __ballot((fl & ST_PENDING) || ((fl & ST_FINISHED) && PU(U_ITEM) != kQDone));
-        if (run == 0ull) {
-            if (pend == 0ull) break;                     // every lane of the wave is done for good
-            // blocks still to come — but never wait without bound: no block completed for kQueuePatience ticks => give up (see pathstate.hip.h)
-            const unsigned tail_now = __hip_atomic_load(&q[Q_TAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long now = wall_clock64();
-            if (tail_now != q_tail) { q_tail = tail_now; q_t0 = now; }
-            else if (now - q_t0 > kQueuePatience) {
-                if (rc_arg.queue_mode == 1u) {
-                    if (fl & ST_PENDING) { const unsigned li = atomicAdd(&q[Q_N_LEFT], 1u); if (li < q[Q_LEFT_CAP]) q[Q_HDR + rc_arg.n_owned + li] = PU(U_ITEM); else atomicExch(&q[Q_ERROR], 2u); }
-                } else atomicExch(&q[Q_ERROR], 1u);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(32);
-            continue;
+        if (__ballot(!(fl & ST_FINISHED)) == 0ull) {
+            if (__ballot((fl & ST_FINISHED) && PU(U_ITEM) != kQDone) == 0ull) break;      // every lane of the wave is done
+            continue;                                                                      // (only claims past ragged ends so far: claim on)
         }
-        if (__ballot(fl & ST_FRESH) != 0ull) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the sample states of the blocks just taken (their entries were read relaxed)
     }
     // (queue mode: ONE trip of the loop body, then back to the claims — a lane whose pixel is done takes its next item while the others go on, like the dispenser's lanes)
     if (!(PU(U_FLAGS) & ST_FINISHED)) do {

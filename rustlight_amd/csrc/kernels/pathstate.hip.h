@@ -33,7 +33,6 @@ enum : unsigned {
     ST_PREV_SHIFT = 5u,    // 2 bits: kind of the vertex the traced edge leaves
     ST_PDF_SA = 128u,      // edge pdf is PDF::SolidAngle (else Discrete)
     ST_ZEROED = 256u,      // single_scattering: a surface vertex has been passed (path.rs:122-124)
-    ST_PENDING = 512u,     // k_path_fused fed from the completion queue: the lane holds a claim (in U_ITEM) on a block whose chain is not complete yet
 };
 enum : unsigned { PREV_SENSOR = 0u, PREV_SURFACE = 1u, PREV_SURFACE_SMOOTH = 2u, PREV_VOLUME = 3u };
 
@@ -124,24 +123,28 @@ struct RenderConst {
     unsigned n_state_pixels;            // pixels of this chunk (second index of sample_states)
     unsigned cursor_begin, cursor_end;  // k_stream_chain: the block cursors [begin, end) this chunk covers
     unsigned long long* chain_states;   // [owned block][4]: where a block's stream stands between two chunks
-    // the evaluation pass overlapped with the chain pass (round 5): the chain kernels push every block whose states are all recorded onto `queue`
-    // (DoneQueue words below), and k_path_fused — launched on a second stream while the chain pass still runs — takes its work from there, a wave at a time
-    unsigned* queue;                    // null: off
-    unsigned queue_mode;                // k_path_fused: 0 = items by lane index / dispenser, 1 = from the queue, waiting for blocks still to come, 2 = from the queue, what mode 1 left (every block is there)
-    unsigned units_per_block;           // (unused)
-    unsigned chain_grid;                // workgroups of the chain kernel (a waiting wave leaves when some of them have not started: it may be holding their place)
+    // the evaluation pass overlapped with the chain pass (round 5).  NOTHING ON THE DEVICE WAITS: the chain kernels flag every block whose sample states are all recorded
+    // (a word per owned block in mapped host memory), the host thread inside rl_render_path collects the flagged blocks and launches k_path_fused<.., QUEUE = true> over
+    // explicit lists of complete blocks on other streams while the chain pass still runs.  (The first forms of this pass kept evaluation waves waiting on the device for
+    // blocks to come — s_sleep + polling loads: about one render in a hundred the whole device then stood still, a 512-byte copy included, until the waiters gave up:
+    // scratch/r5/stall_repro.py, profiles/NEGATIVES.md round 5.)
+    unsigned* queue;                    // chain kernels: device word counting their workgroups that have started (null: no overlap);
+    unsigned* done_flags;               // ... mapped host memory, [owned block]: `queue_seq` once the block's states are all recorded;
+    unsigned* started_flag;             // ... mapped host word: the workgroup that starts LAST stores `queue_seq` (the host launches nothing beside the chain pass before every workgroup of it runs)
+    unsigned queue_seq, chain_grid;     // this render's tag; workgroups of the chain kernel
+    unsigned queue_mode;                // k_path_fused: != 0 = the QUEUE form
+    const unsigned* q_list;             // QUEUE form: owned-block indices this launch renders, q_n of them; q_ctr: its item-claim counter
+    unsigned q_n;
+    unsigned* q_ctr;
 };
-// DoneQueue: word indices into RenderConst::queue.  entries[k] = owned-block index + 1 of the k-th block whose chain is complete (0: not yet), written with release,
-// read with acquire (agent scope): the sample states of the block are visible to whoever sees its entry.
-enum : unsigned { Q_TAIL = 0, Q_HEAD, Q_STARTED, Q_N_LEFT, Q_LEFT_HEAD, Q_LEFT_CAP, Q_ERROR, Q_HDR = 8 };      // then entries[n_owned], then left[Q_LEFT_CAP] (claims handed back)
-// No wait on the queue is unbounded: a waiter that sees no block complete for kQueuePatience ticks of the 100 MHz clock gives up — the gate opens, a lane of the
-// launch beside the chain pass hands its claim back (the launch after the chain pass renders it), and that last launch, which finds every entry in place unless
-// something is broken, raises Q_ERROR (the host returns RL_ERR_HIP) instead of spinning.
-static constexpr unsigned long long kQueuePatience = 1500000000ull;      // 15 s
-RL_DEV void queue_push(unsigned* q, unsigned item) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // this wave's stores of the block's sample states (all lanes': the counters the fence waits on are the wave's)
-    const unsigned slot = atomicAdd(&q[Q_TAIL], 1u);
-    __hip_atomic_store(&q[Q_HDR + slot], item + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+// called by thread 0 of every workgroup of a chain kernel
+RL_DEV void queue_workgroup_started(const RenderConst& rc) {
+    if (atomicAdd(rc.queue, 1u) + 1u == rc.chain_grid) __hip_atomic_store(rc.started_flag, rc.queue_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// a block's chain is complete: its sample states (this wave's stores — all lanes': the counters the fence waits on are the wave's) are made visible, then the host is told
+RL_DEV void queue_push(const RenderConst& rc, unsigned item) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_store(&rc.done_flags[item], rc.queue_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // internal third value of RenderConst::stream_mode (never accepted from a caller): per-pixel work items as in RL_STREAM_PER_SAMPLE, but every
 // camera sample starts from the sampler state k_stream_chain recorded for it — the image and the counters of RL_STREAM_REFERENCE_ORDER

@@ -73,8 +73,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
         recs.tris = reinterpret_cast<const float4*>(sc0.tris);
     }
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, tid0 = blockIdx.x * blockDim.x;
-    if (rc_arg.queue) __builtin_amdgcn_s_setprio(3);      // the chain pass is the critical path: its waves issue ahead of the evaluation pass's that run beside them
-    if (rc_arg.queue && threadIdx.x == 0u) atomicAdd(&rc_arg.queue[Q_STARTED], 1u);      // (see k_stream_chain)
+    if (rc_arg.queue && threadIdx.x == 0u) queue_workgroup_started(rc_arg);      // (the host launches the evaluation pass beside this kernel once EVERY workgroup of it runs)
     const TravStackT<LDS_SCENE> stack = make_stack<LDS_SCENE>(stc, reinterpret_cast<unsigned*>(after_scene), tid);
     RegState ps;
 #pragma unroll
@@ -104,7 +103,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
         else { const unsigned long long* q = rc_arg.chain_states + 4 * (size_t)item; anc.s0 = q[0]; anc.s1 = q[1]; anc.s2 = q[2]; anc.s3 = q[3]; }
     }
     unsigned phase = (have_block && c_begin < c_end) ? SP_PROBE : SP_DONE;
-    if (rc_arg.queue && have_block && !(c_begin < c_end) && (threadIdx.x & (spc_arg.group - 1u)) == 0u) queue_push(rc_arg.queue, item);      // nothing of the block in this chunk: done as it stands
+    if (rc_arg.queue && have_block && !(c_begin < c_end) && (threadIdx.x & (spc_arg.group - 1u)) == 0u) queue_push(rc_arg, item);      // nothing of the block in this chunk: done as it stands
     const unsigned* const triv_bits = spc.trivial + (size_t)(have_block ? item : 0u) * 8u;
     // a lane's track: trk_off / trk_st rows of workgroup thread t
 #define OFF_OF(t) (spc.trk_off + (size_t)(tid0 + (t)) * spc.cap)
@@ -609,8 +608,8 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
                 own = 0u;
                 if (q0 >= c_end) {
                     if (gl == 0u) { unsigned long long* q = rc.chain_states + 4 * (size_t)item; q[0] = last.s0; q[1] = last.s1; q[2] = last.s2; q[3] = last.s3; }   // the next chunk resumes here
-                    // every sample state of the block is recorded (by lanes of this wave: the host only hands a queue to groups of one wave): the evaluation pass may start on it
-                    if (rc.queue && gl == 0u) queue_push(rc.queue, item);
+                    // every sample state of the block is recorded (by lanes of this wave: the host only overlaps with groups of one wave): the evaluation pass may start on it
+                    if (rc.queue && gl == 0u) queue_push(rc, item);
                     phase = SP_DONE;
                 } else phase = SP_PROBE;
             }

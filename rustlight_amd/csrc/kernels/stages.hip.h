@@ -52,7 +52,7 @@ RL_DEV void raygen_chain_slot(const RenderConst& rc, const DeviceScene& sc, PS& 
     Rng rng;
     if (flags & ST_FRESH) {
         cursor = rc.cursor_begin; s = 0;
-        if (cursor >= c_end) { if (rc.queue) queue_push(rc.queue, item); PU(U_FLAGS) = ST_FINISHED; return; }
+        if (cursor >= c_end) { if (rc.queue) queue_push(rc, item); PU(U_FLAGS) = ST_FINISHED; return; }
         if (rc.cursor_begin == 0u) rng = rng_seed(rc.block_seeds[b], rc.seed_variant);      // the block's own sampler (mod.rs:371)
         else { const unsigned long long* q = rc.chain_states + 4 * (size_t)item; rng.s0 = q[0]; rng.s1 = q[1]; rng.s2 = q[2]; rng.s3 = q[3]; }
     } else {
@@ -62,7 +62,7 @@ RL_DEV void raygen_chain_slot(const RenderConst& rc, const DeviceScene& sc, PS& 
         if (cursor == c_end) {
             unsigned long long* q = rc.chain_states + 4 * (size_t)item;                     // the next chunk resumes here
             q[0] = rng.s0; q[1] = rng.s1; q[2] = rng.s2; q[3] = rng.s3;
-            if (rc.queue) queue_push(rc.queue, item);           // every sample state of the block is recorded: the evaluation pass may start on it
+            if (rc.queue) queue_push(rc, item);           // every sample state of the block is recorded: the evaluation pass may start on it
             PU(U_FLAGS) = ST_FINISHED;
             return;
         }

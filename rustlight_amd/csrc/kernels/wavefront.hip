@@ -35,6 +35,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.hip.h"
@@ -72,23 +73,6 @@ __global__ void k_chunk_pixels(RenderConst rc) {
     block_geometry(rc, rc.owned_blocks[j], &bx, &by, &bw, &bh);
     const unsigned c_end = min(rc.cursor_end, bw * bh), base = rc.block_item_base[j];
     for (unsigned c = rc.cursor_begin; c < c_end; c++) rc.item_pixel[base + (c - rc.cursor_begin)] = (by + c / bw) * rc.W + (bx + c % bw);
-}
-
-// the gate of the overlapped evaluation pass (second stream): returns once EVERY workgroup of the chain kernel has started (or every block is already done), so that the
-// evaluation kernel enqueued behind it only ever takes resources the chain pass has no further use for — one wave, no LDS: it cannot be in a chain workgroup's way itself
-__global__ void k_queue_gate(const unsigned* q, unsigned chain_grid, unsigned n_owned) {
-    if (threadIdx.x == 0u) {
-        unsigned long long t0 = wall_clock64();
-        unsigned seen = 0u;
-        for (;;) {
-            const unsigned started = __hip_atomic_load(&q[Q_STARTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (started >= chain_grid || __hip_atomic_load(&q[Q_TAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_owned) break;
-            const unsigned long long now = wall_clock64();
-            if (started != seen) { seen = started; t0 = now; }
-            else if (now - t0 > kQueuePatience) break;      // (never wait without bound: the evaluation kernel behind the gate then leaves at once and the launch after the chain pass renders everything)
-            __builtin_amdgcn_s_sleep(127);
-        }
-    }
 }
 
 __global__ void k_init(RenderConst rc, Pool pool) {
@@ -321,9 +305,13 @@ struct rl_context {
     unsigned long long* d_spec_stats = nullptr; size_t spec_stats_capacity = 0;
     std::vector<hipEvent_t> events;
     // the evaluation pass overlapped with the chain pass (reference-order streams): its own low-priority stream, the completion queue, ordering events
-    hipStream_t stream2 = nullptr;
-    unsigned* d_queue = nullptr; size_t done_queue_capacity = 0;
-    hipEvent_t ev_ready = nullptr, ev_overlap_done = nullptr, ev_chain_done = nullptr;
+    static constexpr int kEvalStreams = 4;      // the evaluation launches beside the chain pass go round these (a launch lasts as long as its slowest pixel: several may have to be in flight)
+    hipStream_t stream2 = nullptr; hipStream_t eval_streams[kEvalStreams] = {};
+    unsigned* d_queue = nullptr; size_t done_queue_capacity = 0;       // device: [0] chain workgroups started, [16 + k] item-claim counter of the k-th evaluation launch, then the block lists
+    hipEvent_t ev_chain_done = nullptr;
+    unsigned* h_flags = nullptr; unsigned* d_flags = nullptr; size_t flags_capacity = 0;      // pinned, mapped: [0] the chain kernel's "every workgroup runs" word, [16 + j] block j's chain is complete
+    unsigned* h_list = nullptr; size_t list_capacity = 0;              // pinned: the block lists of the evaluation launches (staging of the copies to the device)
+    unsigned queue_seq = 0;
     BvhBuild bvh_dump;                // kept for rl_debug_bvh
 };
 
@@ -369,8 +357,12 @@ extern "C" int rl_context_create(const rl_scene* scene, int device, rl_context**
             if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { (void)hipGetLastError(); prio_least = prio_greatest = 0; }
             if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) { rl_set_error("hipStreamCreate failed"); rc = RL_ERR_HIP; break; }
             if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_least) != hipSuccess) { (void)hipGetLastError(); ctx->stream2 = nullptr; }      // (no second stream: no overlap)
-            if (ctx->stream2 && (hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_overlap_done, hipEventDisableTiming) != hipSuccess ||
-                                 hipEventCreateWithFlags(&ctx->ev_chain_done, hipEventDisableTiming) != hipSuccess)) { (void)hipGetLastError(); hipStreamDestroy(ctx->stream2); ctx->stream2 = nullptr; }
+            if (ctx->stream2 && hipEventCreateWithFlags(&ctx->ev_chain_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); hipStreamDestroy(ctx->stream2); ctx->stream2 = nullptr; }
+            if (ctx->stream2) {
+                ctx->eval_streams[0] = ctx->stream2;
+                for (int k = 1; k < rl_context::kEvalStreams; k++)
+                    if (hipStreamCreateWithPriority(&ctx->eval_streams[k], hipStreamNonBlocking, prio_least) != hipSuccess) { (void)hipGetLastError(); ctx->eval_streams[k] = ctx->stream2; }      // (fewer streams: launches share them)
+            }
         }
         BvhBuild& bvh = ctx->bvh_dump;
         build_bvh(*scene, &bvh);                  // BVHAccel::new — untimed (mod.rs:280)
@@ -491,7 +483,10 @@ extern "C" void rl_context_destroy(rl_context* ctx) {
     for (void* p : scratch) if (p) hipFree(p);
     if (ctx->h_counters) hipHostFree(ctx->h_counters);
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
-    for (hipEvent_t ev : {ctx->ev_ready, ctx->ev_overlap_done, ctx->ev_chain_done}) if (ev) hipEventDestroy(ev);
+    if (ctx->ev_chain_done) hipEventDestroy(ctx->ev_chain_done);
+    if (ctx->h_flags) hipHostFree(ctx->h_flags);
+    if (ctx->h_list) hipHostFree(ctx->h_list);
+    for (int k = 1; k < rl_context::kEvalStreams; k++) if (ctx->eval_streams[k] && ctx->eval_streams[k] != ctx->stream2) hipStreamDestroy(ctx->eval_streams[k]);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -708,6 +703,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     // ---- how a set of work items is laid over the lanes.  per_pixel: pixel items (RL_STREAM_PER_SAMPLE, or the second pass of reference-order
     // streams), else one item per owned block.
     struct Plan { unsigned split, n_items, P, item_shift; };
+    bool overlap_wanted = false;         // set once the chunks are known (below): the two-pass form's second pass will run beside the first
     auto plan_items = [&](bool per_pixel, unsigned n_pix, unsigned n_chains) -> Plan {
         // sample-parallel pixels: `split` lanes per pixel, per-sample radiances parked in HBM ([spp][pixel][3] floats) and folded
         // in order.  Auto: scenes that traverse out of L2 / HBM want ~8 M paths in flight per wavefront launch (measured on the
@@ -724,9 +720,12 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             // nearly identical and fetch the same nodes (508 k triangles, 32 spp: 1 / 4 / 16 / 32 lanes per pixel = 108.9 / 104.0 / 100.8 / 97.4 ms).
             const unsigned fused_groups = (n_pix + 255u) / 256u;
             const unsigned fused_auto = fused_groups >= 6000u ? 1u : std::max(1u, 16384u / std::max(1u, fused_groups));
-            const unsigned want = params->sample_split ? params->sample_split
+            unsigned want = params->sample_split ? params->sample_split
                                 : (fused ? (ctx->lds_scene ? fused_auto : std::max(fused_auto, 64u))
                                          : (ctx->lds_scene ? 1u : std::max(1u, (8u << 20) / std::max(1u, n_pix))));
+            // the evaluation pass beside the chain pass: its last launch — the blocks that completed last — is what is left to do when the chain pass ends, and a launch
+            // lasts as long as its slowest pixel: several lanes per pixel cut that tail (1080p x 128 spp, 1 / 4 / 8 lanes: see profiles/NEGATIVES.md round 5)
+            if (overlap_wanted && !params->sample_split) want = std::max(want, getenv("RL_EVAL_SPLIT") ? (unsigned)std::max(1, atoi(getenv("RL_EVAL_SPLIT"))) : 4u);
             pl.split = std::max(1u, std::min(want, params->spp));
             if ((size_t)n_pix * params->spp * 3 * sizeof(float) > kSampleBufBudget) pl.split = 1;
             while (pl.split > 1 && (size_t)n_pix * pl.split > (size_t)0x7fffff00u) pl.split--;
@@ -792,6 +791,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     }
     unsigned max_chunk_pix = 0;
     for (const Chunk& ch : chunks) max_chunk_pix = std::max(max_chunk_pix, ch.n_pix);
+    overlap_wanted = two_pass && ctx->stream2 && chunks.size() == 1 && !fast_math && !getenv("RL_NO_OVERLAP");
     Plan plan = two_pass ? plan_items(true, max_chunk_pix, 0) : plan_items(per_sample, n_pixels, (unsigned)owned.size());   // two-pass: the largest second pass
     // (a SMALLER chunk can ask for MORE lanes per pixel, hence more slots and statistics rows than the largest one: uneven chunks at 1080p — 131 + 125 cursors — lost
     // 1 % of the counters and wrote past the rows; everything sized from `plan` below covers every chunk's own plan)
@@ -849,7 +849,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
     init.active = std::min(plan.P, n_items);
     init.next_item = item_shift ? n_items : plan.P;
     if (!two_pass) HIP_OK(hipMemcpyAsync(ctx->d_counters, &init, sizeof(init), hipMemcpyHostToDevice, st));
-    const size_t n_partial_rows = std::max<size_t>((P + 255) / 256, (size_t)cus * 8u);      // (the queue-fed evaluation launches use a grid of the resident workgroups)
+    const size_t n_partial_rows = std::max<size_t>((P + 255) / 256, (size_t)cus * 8u * rl_context::kEvalStreams);      // (the queue-fed evaluation launches use a grid of the resident workgroups)
     if ((rcode = ensure(&ctx->d_partials, &ctx->partials_capacity, n_partial_rows * STAT_COUNT)) != RL_OK) return rcode;
     HIP_OK(hipMemsetAsync(ctx->d_partials, 0, n_partial_rows * STAT_COUNT * sizeof(unsigned long long), st));
 
@@ -1020,7 +1020,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
         if (spec) stc = stc_s;      // (one overflow buffer serves both passes: the stride is the larger launch)
         // ---- the evaluation pass overlapped with the chain pass: one chunk, exact build, a group of the speculative pass inside one wave (the wave that pushes a block
         // is the wave that wrote its states)
-        const bool overlap = ctx->stream2 && chunks.size() == 1 && !fast_math && !(spec && spc.group > 64u) && !getenv("RL_NO_OVERLAP");
+        const bool overlap = overlap_wanted && !(spec && spc.group > 64u);
         for (const Chunk& ch : chunks) {
             HIP_OK(hipMemcpyAsync(ctx->d_item_base, ch.base.data(), ch.base.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
             RenderConst ra = rc;
@@ -1028,13 +1028,31 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             ra.n_items = plan_chain.n_items; ra.item_shift = plan_chain.item_shift; ra.split = 1;
             ra.n_state_pixels = ch.n_pix; ra.cursor_begin = ch.c0; ra.cursor_end = ch.c1;
             const unsigned chain_grid = spec ? spec_threads / 256u : (plan_chain.P + 255u) / 256u;
+            constexpr unsigned kMaxEvalLaunches = 256u;
             if (overlap) {
-                // the completion queue: header + one entry per owned block + one slot per lane of the queue-fed launch for a claim handed back
-                const unsigned left_cap = (unsigned)cus * 8u * 256u;
-                if ((rcode = ensure(&ctx->d_queue, &ctx->done_queue_capacity, (size_t)Q_HDR + owned.size() + left_cap)) != RL_OK) return rcode;
-                HIP_OK(hipMemsetAsync(ctx->d_queue, 0, ((size_t)Q_HDR + owned.size()) * sizeof(unsigned), st));
-                HIP_OK(hipMemcpyAsync(ctx->d_queue + Q_LEFT_CAP, &left_cap, sizeof(unsigned), hipMemcpyHostToDevice, st));
-                ra.queue = ctx->d_queue;
+                // device: [0] started workgroups, [16 + k] the claim counter of the k-th evaluation launch, [16 + kMaxEvalLaunches + i] the block lists (completion order);
+                // mapped host memory: [0] "every chain workgroup runs", [16 + j] "block j is complete"; pinned staging of the lists
+                const size_t n_dev = 16 + (size_t)kMaxEvalLaunches + owned.size(), n_flags = 16 + owned.size();
+                if ((rcode = ensure(&ctx->d_queue, &ctx->done_queue_capacity, n_dev)) != RL_OK) return rcode;
+                if (ctx->flags_capacity < n_flags) {
+                    if (ctx->h_flags) hipHostFree(ctx->h_flags);
+                    ctx->h_flags = nullptr; ctx->d_flags = nullptr; ctx->flags_capacity = 0;
+                    HIP_OK(hipHostMalloc((void**)&ctx->h_flags, n_flags * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
+                    HIP_OK(hipHostGetDevicePointer((void**)&ctx->d_flags, ctx->h_flags, 0));
+                    std::memset(ctx->h_flags, 0, n_flags * sizeof(unsigned));
+                    ctx->flags_capacity = n_flags;
+                }
+                if (ctx->list_capacity < owned.size()) {
+                    if (ctx->h_list) hipHostFree(ctx->h_list);
+                    ctx->h_list = nullptr; ctx->list_capacity = 0;
+                    HIP_OK(hipHostMalloc((void**)&ctx->h_list, owned.size() * sizeof(unsigned), hipHostMallocDefault));
+                    ctx->list_capacity = owned.size();
+                }
+                HIP_OK(hipMemsetAsync(ctx->d_queue, 0, (16 + (size_t)kMaxEvalLaunches) * sizeof(unsigned), st));
+                ra.queue = ctx->d_queue; ra.chain_grid = chain_grid;
+                ra.done_flags = ctx->d_flags + 16; ra.started_flag = ctx->d_flags;
+                ra.queue_seq = ++ctx->queue_seq;
+                if (ra.queue_seq == 0u) { std::memset(ctx->h_flags, 0, ctx->flags_capacity * sizeof(unsigned)); ra.queue_seq = ++ctx->queue_seq; }      // (the tag wrapped: 0 is the words' idle value)
             }
             hipLaunchKernelGGL(k_chunk_pixels, dim3(((unsigned)owned.size() + 63) / 64), dim3(64), 0, st, ra);
             // ---- pass 2 (planned before pass 1 is launched: overlapped, it starts beside it): every camera sample of the chunk from its recorded state, per-pixel work items
@@ -1042,7 +1060,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             RenderConst rb = ra;
             rb.stream_mode = kStreamGivenStates;
             rb.n_items = pb.n_items; rb.item_shift = pb.item_shift; rb.split = pb.split;
-            rb.queue = nullptr; rb.queue_mode = 0u;
+            rb.queue = nullptr; rb.queue_mode = 0u; rb.done_flags = nullptr; rb.started_flag = nullptr;
             Counters cinit{};
             cinit.active = std::min(pb.P, pb.n_items);
             cinit.next_item = pb.item_shift ? pb.n_items : pb.P;
@@ -1052,11 +1070,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             // first buffer under the same thread indices; allocated before anything is launched: an allocation may wait for the device)
             const dim3 grid_q((unsigned)cus * (unsigned)(ctx->lds_scene ? RL_FUSED_WAVES : RL_FUSED_WAVES_STREAMING));
             StackConf stc_q = stc;
-            if (overlap && (rcode = stack_conf(ctx, (size_t)grid_q.x * 256, &stc_q, true)) != RL_OK) return rcode;
-            if (overlap) {
-                HIP_OK(hipEventRecord(ctx->ev_ready, st));                      // counters, queue reset, item tables, framebuffer memset: all enqueued on `st` before this point
-                HIP_OK(hipStreamWaitEvent(ctx->stream2, ctx->ev_ready, 0));
-            }
+            if (overlap && (rcode = stack_conf(ctx, (size_t)grid_q.x * 256 * rl_context::kEvalStreams, &stc_q, true)) != RL_OK) return rcode;      // (one column range per evaluation stream)
             // ---- pass 1: the chains
             if (timing) hipEventRecord(ctx->events[0], st);
             if (spec) (ctx->lds_scene ? launch_spec_lds : launch_spec_stream)(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, dim3(spec_threads / 256u), block, lds_spec, st, ra, ds, stc, spc);
@@ -1064,17 +1078,57 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             (ctx->lds_scene ? (fast_math ? launch_chain_lds_fast : launch_chain_lds) : (fast_math ? launch_chain_stream_fast : launch_chain_stream))(ctx->single_bsdf ? ctx->bsdf_type : -1, medium, dim3((plan_chain.P + 255) / 256), block, lds_chain, st, ra, ds, stc_c);
             if (timing) hipEventRecord(ctx->events[1], st);
             if (overlap) {
-                // Overlapped: k_path_fused in queue mode on the context's second (low-priority) stream WHILE the chain pass runs on `st` — its waves take the blocks the chain
-                // kernel reports complete (pathstate.hip.h: DoneQueue) — then once more on `st` for what is left when the chain pass has ended.  Same samples from the same
-                // states, folded per pixel in sample order: same bits (RL_NO_OVERLAP=1 keeps the two passes back to back: the cross-check).
-                rb.queue = ctx->d_queue; rb.chain_grid = chain_grid;
-                RenderConst rq = rb; rq.queue_mode = 1u;
-                hipLaunchKernelGGL(k_queue_gate, dim3(1), dim3(64), 0, ctx->stream2, ctx->d_queue, chain_grid, (unsigned)owned.size());
-                launch_fused(rq, grid_q, ctx->stream2, &stc_q);
-                HIP_OK(hipEventRecord(ctx->ev_overlap_done, ctx->stream2));
-                HIP_OK(hipStreamWaitEvent(st, ctx->ev_overlap_done, 0));
-                rq.queue_mode = 2u;
-                launch_fused(rq, grid_q, st, &stc_q);
+                // Overlapped: k_path_fused<.., QUEUE = true> on the context's low-priority streams WHILE the chain pass runs on `st`.  Nothing on the device waits for anything:
+                // the chain kernels flag completed blocks in mapped host memory, THIS host thread (the call is synchronous anyway) collects them and launches the evaluation
+                // kernel over explicit lists of complete blocks — not before the chain kernel has reported that every one of its workgroups runs (so the launches beside it
+                // only take resources it has no further use for), then whenever a third of the blocks still to come have come in (at least 64: a launch lasts as long as its
+                // slowest pixel and should fill a good part of the chip), the rest when the chain pass has ended.  Same samples from the same states, folded per pixel in
+                // sample order: same bits (RL_NO_OVERLAP=1 keeps the two passes back to back: the cross-check).
+                rb.queue = ctx->d_queue; rb.queue_mode = 1u; rb.chain_grid = chain_grid;
+                HIP_OK(hipEventRecord(ctx->ev_chain_done, st));
+                const unsigned seq = ra.queue_seq, n_blocks_owned = (unsigned)owned.size();
+                volatile unsigned* hf = ctx->h_flags;
+                std::vector<unsigned char> listed(n_blocks_owned, 0);
+                unsigned n_listed = 0, n_launches = 0, scan_from = 0;
+                bool chain_over = false, started = false;
+                const unsigned resident = grid_q.x;
+                auto launch_batch = [&](unsigned first, unsigned count) -> int {
+                    const unsigned k = n_launches % (unsigned)rl_context::kEvalStreams;
+                    hipStream_t on = ctx->eval_streams[k];
+                    HIP_OK(hipMemcpyAsync(ctx->d_queue + 16 + kMaxEvalLaunches + first, ctx->h_list + first, count * sizeof(unsigned), hipMemcpyHostToDevice, on));
+                    RenderConst rq = rb;
+                    rq.q_list = ctx->d_queue + 16 + kMaxEvalLaunches + first; rq.q_n = count; rq.q_ctr = ctx->d_queue + 16 + n_launches;
+                    // launches on different streams run side by side: each stream has its own statistics rows and its own columns of the overflow stack levels
+                    rq.partials = rb.partials + (size_t)k * resident * STAT_COUNT;
+                    StackConf stc_k = stc_q;
+                    if (stc_k.overflow) stc_k.overflow += (size_t)k * resident * 256u * 2u;      // ([level][thread] pairs of ints)
+                    const unsigned wgs = std::min<unsigned>(resident, (unsigned)(((size_t)count * 256u * pb.split + 255u) / 256u));
+                    launch_fused(rq, dim3(std::max(1u, wgs)), on, &stc_k);
+                    HIP_OK(hipGetLastError());
+                    n_launches++; launches++;
+                    return RL_OK;
+                };
+                while (n_listed < n_blocks_owned) {
+                    if (!chain_over) {
+                        const hipError_t qe = hipEventQuery(ctx->ev_chain_done);
+                        if (qe == hipSuccess) chain_over = true;
+                        else if (qe != hipErrorNotReady) { rl_set_error(std::string("hipEventQuery(chain pass): ") + hipGetErrorString(qe)); (void)hipGetLastError(); return RL_ERR_HIP; }
+                    }
+                    if (!started && hf[0] == seq) started = true;
+                    if (started || chain_over)      // newly flagged blocks, appended in the order found (once the chain pass is over every block is complete)
+                        for (unsigned j = 0; j < n_blocks_owned; j++)
+                            if (!listed[j] && (chain_over || hf[16 + j] == seq)) { listed[j] = 1; ctx->h_list[n_listed++] = j; }
+                    const unsigned fresh = n_listed - scan_from, to_come = n_blocks_owned - scan_from;
+                    if (fresh > 0 && (chain_over || (fresh >= std::max(64u, to_come / 3u) && n_launches + 2u < kMaxEvalLaunches))) {
+                        if ((rcode = launch_batch(scan_from, fresh)) != RL_OK) return rcode;
+                        scan_from = n_listed;
+                    }
+                    if (n_listed < n_blocks_owned) std::this_thread::sleep_for(std::chrono::microseconds(50));
+                }
+                if (scan_from < n_listed && (rcode = launch_batch(scan_from, n_listed - scan_from)) != RL_OK) return rcode;      // the blocks listed last
+                if (getenv("RL_QUEUE_DEBUG")) std::fprintf(stderr, "[queue] %u evaluation launches beside / after the chain pass, %u blocks, started flag %s\n", n_launches, n_listed, started ? "seen" : "not seen");
+                HIP_OK(hipStreamSynchronize(st));                      // the chain pass (over already: every block was flagged or its event had fired)
+                for (int k = 0; k < rl_context::kEvalStreams; k++) HIP_OK(hipStreamSynchronize(ctx->eval_streams[k]));      // the last evaluation launches
                 if (timing) hipEventRecord(ctx->events[3], st);
             } else {
                 if (timing) hipEventRecord(ctx->events[2], st);
@@ -1083,10 +1137,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
             }
             if (pb.split > 1) hipLaunchKernelGGL(k_fold_samples, dim3((ch.n_pix + 255) / 256), block, 0, st, rb);
             HIP_OK(hipGetLastError());
-            unsigned queue_error = 0u;
-            if (overlap) HIP_OK(hipMemcpyAsync(&queue_error, ctx->d_queue + Q_ERROR, sizeof(unsigned), hipMemcpyDeviceToHost, st));
             HIP_OK(hipStreamSynchronize(st));       // (the chunk's host arrays and the counters block are reused by the next chunk)
-            if (queue_error) { rl_set_error("reference-order streams: the evaluation pass gave up waiting for the chain pass's completion queue (code " + std::to_string(queue_error) + "); RL_NO_OVERLAP=1 renders the two passes back to back"); return RL_ERR_HIP; }
             if (timing) {
                 float t = 0.0f;
                 HIP_OK(hipEventElapsedTime(&t, ctx->events[0], ctx->events[1])); ms_chain += t;
