@@ -309,6 +309,9 @@ int rl_generate_block_seeds(rl_sampler* master, uint32_t width, uint32_t height,
  * out_is_device != 0: `out_rgb` is a device pointer on the context's device (e.g. a torch tensor
  * that is then reduced with RCCL); otherwise a host pointer (the framebuffer download is timed).
  * `stream`: a hipStream_t to enqueue on, or NULL for the context's own stream.  Blocking.
+ * In RL_STREAM_REFERENCE_ORDER (two passes through the persistent kernel) the call also launches on low-priority streams the context owns: the evaluation pass runs beside the
+ * chain pass, launched by THIS thread over the blocks the chain kernel reports complete through a few words of mapped host memory (the thread polls them every 50 us until the
+ * chain pass has ended; nothing on the device waits).  The image and the counters are those of the two passes back to back (RL_NO_OVERLAP=1: a test knob that keeps them so).
  * Frames in flight: contexts share nothing mutable (each owns its stream and buffers; rl_last_error is per thread), so independent frames may be
  * rendered concurrently from several host threads, one context each, on the same device — a frame's render is a chain of dependent launches whose
  * tail leaves much of the chip idle, and another context's frame fills it (Cornell box 1080p x 128 spp in reference-order streams: 1.07 -> 1.4 G
