@@ -1081,7 +1081,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
                 // Overlapped: k_path_fused<.., QUEUE = true> on the context's low-priority streams WHILE the chain pass runs on `st`.  Nothing on the device waits for anything:
                 // the chain kernels flag completed blocks in mapped host memory, THIS host thread (the call is synchronous anyway) collects them and launches the evaluation
                 // kernel over explicit lists of complete blocks — not before the chain kernel has reported that every one of its workgroups runs (so the launches beside it
-                // only take resources it has no further use for), then whenever a third of the blocks still to come have come in (at least 64: a launch lasts as long as its
+                // only take resources it has no further use for), then whenever a fifth of the blocks still to come have come in (at least 64: a launch lasts as long as its
                 // slowest pixel and should fill a good part of the chip), the rest when the chain pass has ended.  Same samples from the same states, folded per pixel in
                 // sample order: same bits (RL_NO_OVERLAP=1 keeps the two passes back to back: the cross-check).
                 rb.queue = ctx->d_queue; rb.queue_mode = 1u; rb.chain_grid = chain_grid;
@@ -1092,6 +1092,8 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
                 unsigned n_listed = 0, n_launches = 0, scan_from = 0;
                 bool chain_over = false, started = false;
                 const unsigned resident = grid_q.x;
+                // (a launch when a 1 / batch_div of the blocks still to come — at least batch_min — have come in; RL_EVAL_MIN / RL_EVAL_DIV: dev knobs of the sweep in NEGATIVES round 5)
+                const unsigned batch_min = getenv("RL_EVAL_MIN") ? (unsigned)std::max(1, atoi(getenv("RL_EVAL_MIN"))) : 64u, batch_div = getenv("RL_EVAL_DIV") ? (unsigned)std::max(1, atoi(getenv("RL_EVAL_DIV"))) : 5u;
                 auto launch_batch = [&](unsigned first, unsigned count) -> int {
                     const unsigned k = n_launches % (unsigned)rl_context::kEvalStreams;
                     hipStream_t on = ctx->eval_streams[k];
@@ -1119,7 +1121,7 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
                         for (unsigned j = 0; j < n_blocks_owned; j++)
                             if (!listed[j] && (chain_over || hf[16 + j] == seq)) { listed[j] = 1; ctx->h_list[n_listed++] = j; }
                     const unsigned fresh = n_listed - scan_from, to_come = n_blocks_owned - scan_from;
-                    if (fresh > 0 && (chain_over || (fresh >= std::max(64u, to_come / 3u) && n_launches + 2u < kMaxEvalLaunches))) {
+                    if (fresh > 0 && (chain_over || (fresh >= std::max(batch_min, to_come / batch_div) && n_launches + 2u < kMaxEvalLaunches))) {
                         if ((rcode = launch_batch(scan_from, fresh)) != RL_OK) return rcode;
                         scan_from = n_listed;
                     }
