@@ -1088,8 +1088,13 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
                 HIP_OK(hipEventRecord(ctx->ev_chain_done, st));
                 const unsigned seq = ra.queue_seq, n_blocks_owned = (unsigned)owned.size();
                 volatile unsigned* hf = ctx->h_flags;
-                std::vector<unsigned char> listed(n_blocks_owned, 0);
+                std::vector<unsigned> waiting(n_blocks_owned);          // owned blocks not listed yet (the scan below only looks at these; it shrinks as blocks complete)
+                for (unsigned j = 0; j < n_blocks_owned; j++) waiting[j] = j;
                 unsigned n_listed = 0, n_launches = 0, scan_from = 0;
+                // an error in here must not leave kernels running on the context's streams behind the caller's back
+                auto drain = [&]() { (void)hipStreamSynchronize(st); for (int k = 0; k < rl_context::kEvalStreams; k++) (void)hipStreamSynchronize(ctx->eval_streams[k]); (void)hipGetLastError(); };
+                // the poll interval grows with the number of flags a poll reads (50 us for a 1080p frame's 8160 blocks, ~1 ms per 100 k blocks)
+                const auto poll_us = std::chrono::microseconds(50 + n_blocks_owned / 100u);
                 bool chain_over = false, started = false;
                 const unsigned resident = grid_q.x;
                 // (a launch when a 1 / batch_div of the blocks still to come — at least batch_min — have come in; RL_EVAL_MIN / RL_EVAL_DIV: dev knobs of the sweep in NEGATIVES round 5)
@@ -1114,20 +1119,25 @@ extern "C" int rl_render_path(rl_context* ctx, const rl_path_params* params, con
                     if (!chain_over) {
                         const hipError_t qe = hipEventQuery(ctx->ev_chain_done);
                         if (qe == hipSuccess) chain_over = true;
-                        else if (qe != hipErrorNotReady) { rl_set_error(std::string("hipEventQuery(chain pass): ") + hipGetErrorString(qe)); (void)hipGetLastError(); return RL_ERR_HIP; }
+                        else if (qe != hipErrorNotReady) { rl_set_error(std::string("hipEventQuery(chain pass): ") + hipGetErrorString(qe)); (void)hipGetLastError(); drain(); return RL_ERR_HIP; }
                     }
                     if (!started && hf[0] == seq) started = true;
-                    if (started || chain_over)      // newly flagged blocks, appended in the order found (once the chain pass is over every block is complete)
-                        for (unsigned j = 0; j < n_blocks_owned; j++)
-                            if (!listed[j] && (chain_over || hf[16 + j] == seq)) { listed[j] = 1; ctx->h_list[n_listed++] = j; }
+                    if (started || chain_over) {    // newly flagged blocks, appended in the order found (once the chain pass is over every block is complete)
+                        size_t keep = 0;
+                        for (size_t w = 0; w < waiting.size(); w++) {
+                            const unsigned j = waiting[w];
+                            if (chain_over || hf[16 + j] == seq) ctx->h_list[n_listed++] = j; else waiting[keep++] = j;
+                        }
+                        waiting.resize(keep);
+                    }
                     const unsigned fresh = n_listed - scan_from, to_come = n_blocks_owned - scan_from;
                     if (fresh > 0 && (chain_over || (fresh >= std::max(batch_min, to_come / batch_div) && n_launches + 2u < kMaxEvalLaunches))) {
-                        if ((rcode = launch_batch(scan_from, fresh)) != RL_OK) return rcode;
+                        if ((rcode = launch_batch(scan_from, fresh)) != RL_OK) { drain(); return rcode; }
                         scan_from = n_listed;
                     }
-                    if (n_listed < n_blocks_owned) std::this_thread::sleep_for(std::chrono::microseconds(50));
+                    if (n_listed < n_blocks_owned && !chain_over) std::this_thread::sleep_for(poll_us);
                 }
-                if (scan_from < n_listed && (rcode = launch_batch(scan_from, n_listed - scan_from)) != RL_OK) return rcode;      // the blocks listed last
+                if (scan_from < n_listed && (rcode = launch_batch(scan_from, n_listed - scan_from)) != RL_OK) { drain(); return rcode; }      // the blocks listed last
                 if (getenv("RL_QUEUE_DEBUG")) std::fprintf(stderr, "[queue] %u evaluation launches beside / after the chain pass, %u blocks, started flag %s\n", n_launches, n_listed, started ? "seen" : "not seen");
                 HIP_OK(hipStreamSynchronize(st));                      // the chain pass (over already: every block was flagged or its event had fired)
                 for (int k = 0; k < rl_context::kEvalStreams; k++) HIP_OK(hipStreamSynchronize(ctx->eval_streams[k]));      // the last evaluation launches
