@@ -2,6 +2,11 @@
 // and fused_stream.hip (BVH streamed from L2 / HBM) so that the two families compile in parallel, and once more each by fused_*_fast.hip with
 // RL_FAST_MATH (NUM = 1: the opt-in tolerance build; the template parameter only keeps the kernel symbols of the two builds apart).
 #pragma once
+#ifdef RL_STAGE_TIMERS
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+#endif
 
 #ifndef RL_RELOAD_SCENE
 #define RL_RELOAD_SCENE 1    // persistent loop re-reads scene / render constants from the kernarg segment per iteration (see k_path_fused)
@@ -22,7 +27,7 @@ namespace rl {
 // traversal stacks in LDS.  Same functions, same order of operations, same results as the wavefront kernels;
 // what disappears is ~1.4 KB/sample of state traffic through HBM and ~2000 kernel boundaries per render.
 #ifdef RL_STAGE_TIMERS
-__device__ unsigned long long g_stage_timers[16];
+__device__ unsigned long long g_stage_timers[32];      // [0..3] cycles per stage, [4..7] live lanes per stage, [8] lane slots, [16..] shadow-stage occupancy (dump_stage_timers_impl)
 #endif
 // QUEUE: the form that takes its work from the chain pass's completion queue (the evaluation pass of reference-order streams, launched beside the chain pass): an
 // instantiation of its own (fusedq_lds.hip / fusedq_stream.hip), so that the per-sample kernel's code is exactly what it is without it
@@ -76,6 +81,9 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
     unsigned n_samples = 0, n_draws = 0, n_vertices = 0, n_shadow = 0, n_ext = 0;
 #ifdef RL_STAGE_TIMERS
     unsigned long long tm[4] = {0, 0, 0, 0}, ln[5] = {0, 0, 0, 0, 0};
+    // the shadow stage where it runs: wave-iterations by the number of lanes that hold a shadow ray (0 | 1-16 | 17-32 | 33-48 | 49-64), and what packing the shadow rays of
+    // TWO consecutive iterations into one traversal could save: pairs of iterations by (both empty | one empty | both hold rays and together <= 64 | together > 64)
+    unsigned long long sh_hist[5] = {0, 0, 0, 0, 0}, sh_pair[4] = {0, 0, 0, 0}, sh_cyc_exec = 0; unsigned sh_prev = 0, sh_parity = 0;
 #define RL_T0 { t0 = __builtin_readcyclecounter(); }
 #define RL_T1(K, COND) { unsigned long long t1 = __builtin_readcyclecounter(); tm[K] += t1 - t0; ln[K] += __popcll(__ballot(COND)); t0 = t1; }
     unsigned long long t0;
@@ -181,13 +189,20 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
         const bool c3 = PU(U_FLAGS) & ST_SHADOW;
 #endif
         if (PU(U_FLAGS) & ST_SHADOW) shadow_slot(sc, recs, stack, ps);
+#ifdef RL_STAGE_TIMERS
+        { const unsigned nsh = (unsigned)__popcll(__ballot(c3)); sh_hist[nsh == 0u ? 0 : 1 + (nsh - 1u) / 16u]++;
+          if (nsh) sh_cyc_exec += __builtin_readcyclecounter() - t0;
+          if (sh_parity) { const unsigned a = sh_prev, b = nsh; sh_pair[(a == 0u && b == 0u) ? 0 : ((a == 0u || b == 0u) ? 1 : (a + b <= 64u ? 2 : 3))]++; }
+          sh_prev = nsh; sh_parity ^= 1u; }
+#endif
         RL_T1(3, c3)
     } while (!qmode && !(PU(U_FLAGS) & ST_FINISHED));
     if (!qmode) break;
     }
     }
 #ifdef RL_STAGE_TIMERS
-    if ((threadIdx.x & 63u) == 0u) { for (int k = 0; k < 4; k++) { atomicAdd(&g_stage_timers[k], tm[k]); atomicAdd(&g_stage_timers[4 + k], ln[k]); } atomicAdd(&g_stage_timers[8], ln[4]); }
+    if ((threadIdx.x & 63u) == 0u) { for (int k = 0; k < 4; k++) { atomicAdd(&g_stage_timers[k], tm[k]); atomicAdd(&g_stage_timers[4 + k], ln[k]); } atomicAdd(&g_stage_timers[8], ln[4]);
+        for (int k = 0; k < 5; k++) atomicAdd(&g_stage_timers[16 + k], sh_hist[k]); for (int k = 0; k < 4; k++) atomicAdd(&g_stage_timers[21 + k], sh_pair[k]); atomicAdd(&g_stage_timers[25], sh_cyc_exec); }
 #endif
     {
         const int which[5] = {STAT_SAMPLES, STAT_VERTICES, STAT_DRAWS, STAT_SHADOW_RAYS, STAT_EXT_RAYS};
@@ -219,11 +234,18 @@ template <bool LDS_SCENE>
 static void dump_stage_timers_impl() {
 #ifdef RL_STAGE_TIMERS
     // dev-only build: per-stage cycle shares and active-lane fractions of the fused loop
-    unsigned long long h[16];
+    unsigned long long h[32];
     hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stage_timers), sizeof(h));
     const double tot = (double)(h[0] + h[1] + h[2] + h[3]);
     const char* names[4] = {"raygen", "extend", "shade", "shadow"};
     for (int k = 0; k < 4; k++) std::fprintf(stderr, "[stage] %-7s cycles %5.1f %%  lanes %5.1f %%\n", names[k], 100.0 * h[k] / tot, 100.0 * h[4 + k] / (double)h[8]);
+    {
+        const double it = (double)(h[16] + h[17] + h[18] + h[19] + h[20]), ex = it - (double)h[16], pr = (double)(h[21] + h[22] + h[23] + h[24]);
+        if (it > 0) std::fprintf(stderr, "[stage] shadow stage: runs in %.1f %% of the wave-iterations; where it runs the wave holds 1-16 / 17-32 / 33-48 / 49-64 shadow rays in %.1f / %.1f / %.1f / %.1f %% (%.1f lanes on average)\n",
+                                 100.0 * ex / it, 100.0 * h[17] / std::max(1.0, ex), 100.0 * h[18] / std::max(1.0, ex), 100.0 * h[19] / std::max(1.0, ex), 100.0 * h[20] / std::max(1.0, ex), (double)h[7] / std::max(1.0, ex));
+        if (pr > 0) std::fprintf(stderr, "[stage] pairs of consecutive iterations: neither holds shadow rays %.1f %%, one does %.1f %%, both and <= 64 together %.1f %% (one traversal could serve both), both and > 64 %.1f %%\n",
+                                 100.0 * h[21] / pr, 100.0 * h[22] / pr, 100.0 * h[23] / pr, 100.0 * h[24] / pr);
+    }
     std::memset(h, 0, sizeof(h)); hipMemcpyToSymbol(HIP_SYMBOL(g_stage_timers), h, sizeof(h));
 #endif
 }
