@@ -219,7 +219,7 @@ def main():
     assert stream != 0
     pipeline = {"auto": 0, "wavefront": 1, "fused": 2}[args.pipeline]
     STAT_KEYS = ("camera_samples", "vertices", "extension_rays", "shadow_rays", "iterations", "n_extend_launches", "kernel_launches")
-    MS_KEYS = ("ms_raygen", "ms_extend", "ms_shade", "ms_shadow", "ms_other", "ms_prepass")
+    MS_KEYS = ("ms_raygen", "ms_extend", "ms_shade", "ms_shadow", "ms_other", "ms_prepass", "ms_eval_span")
 
     def build_scene(name, width, height, tris=0):
         if name == "cbox":
@@ -231,8 +231,9 @@ def main():
         sd = scenes.living_room(width, height, tess=tess)
         return sd, f"living-room-class synthetic stand-in ({sd.n_triangles} tris, 6 BSDF types; the real pbrt-v3 living-room is not available) {width}x{height}"
 
-    def time_workload(ctx, width, height, spp_total, stream_mode, numerics, steps, warmup, shard=(0, 1), pool=0, pipe=0):
-        """`steps` timed renders (+ reduce + download) between barriers; returns the record the JSON lines are made of."""
+    def time_workload(ctx, width, height, spp_total, stream_mode, numerics, steps, warmup, shard=(0, 1), pool=0, pipe=0, per_step=False):
+        """`steps` timed renders (+ reduce + download) between barriers; returns the record the JSON lines are made of.  per_step (the `also` records of the slow default-mode
+        configs only, never the headline): the device is synchronised after every step and each step's wall time kept, so that the record can quote its worst step."""
         fb = torch.zeros((height, width, 3), dtype=torch.float32, device=dev)
         host_fb = torch.zeros((height, width, 3), dtype=torch.float32).pin_memory() if rank == 0 else None
 
@@ -261,7 +262,16 @@ def main():
         rd.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        stats = [step(s) for s in range(steps)]
+        step_ms = []
+        if per_step:
+            stats = []
+            for s in range(steps):
+                ts = time.perf_counter()
+                stats.append(step(s))
+                torch.cuda.synchronize()
+                step_ms.append((time.perf_counter() - ts) * 1e3)
+        else:
+            stats = [step(s) for s in range(steps)]
         rd.barrier()
         torch.cuda.synchronize()
         dt = rd.max_over_ranks(time.perf_counter() - t0)
@@ -271,7 +281,8 @@ def main():
         # (this rank's wait for the slowest shard is part of its reduce time: the collective cannot start before every rank has arrived)
         reduce_ms = sum(a.elapsed_time(b) for a, b in reduce_events[-steps:]) / steps if reduce_events else 0.0
         return {"reduce_ms": reduce_ms, "dt": dt, "agg": agg, "ms": ms, "host_img": host_img, "params": params, "steps": steps, "samples_per_step": width * height * spp_total,
-                "last_seed": steps - 1, "spp": spp_total, "stream_mode": stream_mode,
+                "last_seed": steps - 1, "spp": spp_total, "stream_mode": stream_mode, "step_ms": step_ms,
+                "overlapped": bool(stats[-1].get("overlapped")), "chunks": int(stats[-1].get("chunks", 0)),
                 "spec": {k: stats[-1][k] for k in ("spec_group", "spec_samples", "spec_serial_samples", "spec_probe_samples")}}
 
     # ---- the headline workload
@@ -294,8 +305,8 @@ def main():
     ref_multi = None
     if world > 1 and args.scene == "cbox" and args.stream_mode == "per_sample" and args.numerics == "exact" and not args.no_also:
         rrec = time_workload(ctx, args.width, args.height, spp_total, "reference", "exact", 2, 1, shard=(rank, world))
-        per_rank = rd.gather_objects({"rank": rank, "chain_ms": rrec["ms"]["ms_prepass"] / 2, "kernel_ms": rrec["ms"]["ms_other"] / 2, "reduce_ms": rrec["reduce_ms"],
-                                      "chain_pass": rrec["spec"]})
+        per_rank = rd.gather_objects({"rank": rank, "chain_ms": rrec["ms"]["ms_prepass"] / 2, "eval_span_ms": rrec["ms"]["ms_eval_span"] / 2, "eval_tail_after_chain_ms": rrec["ms"]["ms_other"] / 2,
+                                      "overlapped": rrec["overlapped"], "reduce_ms": rrec["reduce_ms"], "chain_pass": rrec["spec"]})
         # the same shards with three frames in flight per rank (three contexts, one host thread each: the chain pass of a shard leaves most of its GPU idle — one wave per
         # block — and another frame's fills it); the frames' reduces follow in frame order on the main thread once every render has returned, so every rank issues the
         # same collectives in the same order.  A failure here is reported in the record, never raised: the headline above does not depend on it.
@@ -353,7 +364,9 @@ def main():
         strong = []
         for mode in ("per_sample", "reference"):
             srec = time_workload(ctx, args.width, args.height, args.spp, mode, "exact", 3, 1, shard=(rank, world))
-            per_rank = rd.gather_objects({"rank": rank, "kernel_ms": srec["ms"]["ms_other"] / 3, "chain_ms": srec["ms"]["ms_prepass"] / 3, "reduce_ms": srec["reduce_ms"]})
+            # (reference mode: the evaluation pass runs beside the chain pass — eval_span_ms is its own span, kernel_ms the critical path = chain pass + the tail left after it)
+            per_rank = rd.gather_objects({"rank": rank, "kernel_ms": (srec["ms"]["ms_other"] + srec["ms"]["ms_prepass"]) / 3, "chain_ms": srec["ms"]["ms_prepass"] / 3,
+                                          "eval_span_ms": srec["ms"]["ms_eval_span"] / 3, "reduce_ms": srec["reduce_ms"]})
             if rank == 0:
                 crc_s = f"{zlib.crc32(srec['host_img'].tobytes()):08x}"
                 want_s = oracle_crc("cbox", args.width, args.height, args.spp, mode, 2)
@@ -391,12 +404,18 @@ def main():
                 gbs = per_unit[k] * units[k] / n_launch[k] / (avg * 1e-3) / 1e9
                 kernels[names[k]] = {"avg_launch_ms": avg, "launches": n_launch[k], "algorithmic_bytes_per_unit": per_unit[k], "achieved_GBps": gbs, "frac": gbs / PEAK_HBM_GBPS}
         if fused:
-            avg = ms["ms_other"] / args.steps
+            # two passes (reference-order streams): the evaluation kernel runs BESIDE the chain pass, `ms_other` is only what of it was left after the chain pass had
+            # ended — its roofline divides by its own span, first launch to last completion (rl_render_stats.ms_eval_span; ADVICE r5: dividing the pipeline's
+            # bytes by the tail inflated the fraction past 1)
+            two_pass_run = ms["ms_prepass"] > 0.0
+            avg = (ms["ms_eval_span"] if two_pass_run and ms["ms_eval_span"] > 0.0 else ms["ms_other"]) / args.steps
             gbs = pipe_bytes / args.steps / (avg * 1e-3) / 1e9
             kernels["k_path_fused"] = {"avg_launch_ms": avg, "launches": args.steps, "algorithmic_bytes_per_unit": "248/sample + 352/vertex + 12/pixel",
                                        "achieved_GBps": gbs, "frac": gbs / PEAK_HBM_GBPS}
+            if two_pass_run:
+                kernels["k_path_fused"].update({"overlapped_with_chain_pass": main_rec["overlapped"], "tail_after_chain_pass_ms": ms["ms_other"] / args.steps,
+                                                "note": "avg_launch_ms = the evaluation pass's span (its launches run on several streams beside the chain kernel, sharing the chip with it)"})
         if ms["ms_prepass"] > 0.0:
-            # (two passes: the evaluation kernel runs beside the chain pass since round 5; ms_other is what of it was left after the chain pass ended)
             avg = ms["ms_prepass"] / args.steps
             gbs = (32 * agg["camera_samples"] + 44 * agg["extension_rays"]) / args.steps / (avg * 1e-3) / 1e9
             kernels["k_stream_spec" if main_rec["spec"]["spec_group"] else "k_stream_chain"] = {"avg_launch_ms": avg, "launches": args.steps, "algorithmic_bytes_per_unit": "32/sample + 44/extension ray",
@@ -439,8 +458,10 @@ def main():
                 a, m = rec["agg"], rec["ms"]
                 width, height = rec["host_img"].shape[1], rec["host_img"].shape[0]
                 chain_kernel = "k_stream_spec" if rec["spec"]["spec_group"] else "k_stream_chain"
-                kernel_ms = {k: v / rec["steps"] for k, v in (("k_path_fused", m["ms_other"]), (chain_kernel, m["ms_prepass"])) if v > 0}
-                kms = sum(kernel_ms.values())
+                two_pass_rec = m["ms_prepass"] > 0
+                # two passes: k_path_fused's entry is its own span (it runs beside the chain pass), the step's critical path is chain pass + the tail left after it
+                kernel_ms = {k: v / rec["steps"] for k, v in (("k_path_fused", m["ms_eval_span"] if two_pass_rec and m["ms_eval_span"] > 0 else m["ms_other"]), (chain_kernel, m["ms_prepass"])) if v > 0}
+                kms = (m["ms_prepass"] + m["ms_other"]) / rec["steps"] if two_pass_rec else sum(kernel_ms.values())
                 r = {"workload": tag, "what": what, "steps": rec["steps"], "ms_per_step": rec["dt"] / rec["steps"] * 1e3,
                      "value": rec["samples_per_step"] * rec["steps"] / rec["dt"] / 1e6, "unit": "Msamples/s",
                      "kernel_ms": {k: round(v, 3) for k, v in kernel_ms.items()}, "kernel_ms_total": round(kms, 3),
@@ -454,8 +475,17 @@ def main():
                 if rec["spec"]["spec_group"]:
                     r["chain_pass"] = dict(rec["spec"], note="k_stream_spec: lanes per block, samples walked speculatively / serially / by the estimate probes in the last step")
                 if m["ms_prepass"] > 0:
-                    r["overlap_note"] = ("reference-order streams: k_path_fused runs BESIDE the chain pass on the context's second stream, fed by the chain kernel's completion queue "
-                                         "(DESIGN.md 4 (4)); its kernel_ms is the part of it that was still running after the chain pass had ended, so the two entries add up to the step")
+                    r["overlapped"], r["chunks"] = rec["overlapped"], rec["chunks"]
+                    r["eval_tail_after_chain_ms"] = round(m["ms_other"] / rec["steps"], 3)
+                    r["overlap_note"] = ("reference-order streams: k_path_fused runs BESIDE the chain pass on the context's low-priority streams, over lists of complete blocks "
+                                         "(DESIGN.md 4 (4)); kernel_ms.k_path_fused is its own span (first launch to last completion), eval_tail_after_chain_ms the part of it "
+                                         "left after the chain pass had ended, kernel_ms_total = chain pass + that tail = the step's critical path")
+                if rec["step_ms"]:
+                    sm = sorted(rec["step_ms"])
+                    per = [rec["samples_per_step"] / (t * 1e-3) / 1e6 for t in sm]          # fastest step first
+                    r["step_ms"] = [round(t, 1) for t in rec["step_ms"]]
+                    r["value_min"], r["value_median"], r["value_max"] = per[-1], per[len(per) // 2], per[0]
+                    r["value_note"] = "`value` = all timed steps together; value_min = the WORST single step (each step synchronised and timed on its own)"
                 # utilisation of the record's longest kernel, when profiles/pmc_live.json holds its counters
                 longest = max(kernel_ms, key=kernel_ms.get) if kernel_ms else None
                 u = utilisation_fields(live, f"{scene_name}:{width}x{height}x{rec['spp']}:{rec['stream_mode']}:exact", longest, src_hash)
@@ -465,7 +495,7 @@ def main():
                 also.append(r)
                 return r
 
-            r = time_workload(ctx, 1920, 1080, 128, "reference", "exact", 3, 1)
+            r = time_workload(ctx, 1920, 1080, 128, "reference", "exact", 3, 1, per_step=True)
             rr = sub("cbox_1080p_128spp_reference_order", r, "BASELINE configs[1] in RL_STREAM_REFERENCE_ORDER: rustlight's own stream assignment (one sampler per 16x16 block, "
                      "src/integrators/mod.rs:420-435), the plugin / CLI default; two passes: k_stream_spec (the block chains, speculative windows) + k_path_fused")
             reference_order_value = rr["value"]
@@ -532,9 +562,10 @@ def main():
                 r = time_workload(ctx2, w, h, 128, "per_sample", "exact", steps, 1)
                 sub(tag, r, what, {"context_build_s": round(t_build, 2), "triangles": int(sd2.n_triangles)}, scene_name=name)
                 if name != "cbox":
-                    # the drop-in default on the two slow configs: rustlight's own reference-order streams, ONE timed step (seed 0) after one
-                    # warm-up render, against the oracle's CRC of that frame — the weakest numbers of the product's default mode, driver-timed
-                    r = time_workload(ctx2, w, h, 128, "reference", "exact", 1, 1)
+                    # the drop-in default on the two slow configs: rustlight's own reference-order streams, THREE timed steps after one
+                    # warm-up render, each synchronised and timed on its own (value_min = the worst of them), the last frame (seed 2) against the oracle's CRC —
+                    # the weakest numbers of the product's default mode, driver-timed
+                    r = time_workload(ctx2, w, h, 128, "reference", "exact", 3, 1, per_step=True)
                     sub(tag + "_reference_order", r, what + " — in RL_STREAM_REFERENCE_ORDER (the plugin / CLI default): chain pass + k_path_fused", {"triangles": int(sd2.n_triangles)}, scene_name=name)
                 ctx2.close()
 
@@ -580,7 +611,8 @@ def main():
                                "ranks": ranks, "image_crc32": f"{crc:08x}", "single_gpu_image_crc32": None if crc_single is None else f"{crc_single:08x}",
                                "crc_match": None if crc_single is None else crc_single == crc},
                "roofline": roofline, "cpu_baseline": cpu}
-        want = oracle_crc(args.scene, args.width, args.height, spp_total, args.stream_mode, args.steps - 1) if world == 1 and args.numerics == "exact" and args.tris == 0 else None
+        # (N > 1: the reduced N-shard frame against the oracle's render of the WHOLE frame at spp_total — BASELINE configs[3] is `--gpus 8 --steps 1`: cbox 1080p x 1024 spp, seed 0)
+        want = oracle_crc(args.scene, args.width, args.height, spp_total, args.stream_mode, args.steps - 1) if args.numerics == "exact" and args.tris == 0 else None
         out["oracle_crc32"] = want
         out["oracle_crc_match"] = None if want is None else want == f"{crc:08x}"        # the last timed frame == the CPU oracle's render of the same frame (tests/golden/bench_crcs.json)
         out["distributed"]["rccl_check"] = rccl_check
@@ -592,6 +624,9 @@ def main():
             out["reference_order"] = ref_multi
         if also is not None:
             out["reference_order_value"] = reference_order_value
+            # the default mode's weakest step over ALL configs the line times in it (cfg 2, cfg 5, the cfg 3 stand-in; three steps each): what "every config >= X" may quote
+            worst = [a_["value_min"] for a_ in also if a_.get("workload", "").endswith("reference_order") and a_.get("value_min") is not None]
+            out["reference_order_worst_step_value"] = min(worst) if worst else None
             out["reference_order_oracle_crc_match"] = rr["oracle_crc_match"]
             out["reference_order_in_flight_value"] = reference_order_in_flight["value"]      # three independent frames in flight (see `also`); `reference_order_value` is one frame at a time
             out["also"] = also

@@ -13,20 +13,25 @@
  *   - colours are linear RGB f32 triples (src/structure.rs:105-110);
  *   - images are row-major, origin top-left, W*H*3 f32 (src/structure.rs:383-402).
  *
- * Environment variables read by the library.  None of them changes a result; they exist for the tests and for measurements
- * and are NOT part of the drop-in surface:
- *   RL_FORCE_STREAMING=1      rl_context_create: keep small scenes out of LDS (the kernels that stream the BVH from L2 / HBM on scenes the
- *                             oracle finishes in seconds)
- *   RL_ITEM_SHIFT=k           reference-order streams: one block chain per 2^k lanes (auto: 5 at 1080p)
- *   RL_REF_SINGLE_PASS=1      reference-order streams through the persistent kernel in ONE pass (the form of rounds 1-2) instead of
- *                             k_stream_chain + per-sample evaluation
- *   RL_CHAIN_NO_PRE=1         k_stream_chain on tiny scenes without the lane-parallel node / triangle records (the plain one-lane traversal)
- *   RL_CHAIN_NO_TREELETS=1    k_stream_chain on streaming scenes without the 16-node treelet blocks (plain per-node fetches)
- *   RL_STATE_BUDGET_MB=n      bytes the recorded sampler states of the two-pass form may take (default 24 GB): small values force several chunks
- *   RL_FUSED_DYNAMIC=0|1      persistent kernel: static tile order / work items from the atomic dispenser
- *   RL_GENERIC_LIGHTS=1       do not specialise the NEE code for area-light-only scenes
- *   RL_NO_EVENTS=1            no HIP events around the kernels (rl_render_stats.ms_* stay 0)
- *   RL_MULTI_FORCE_HOST_MERGE=1, RL_MULTI_NO_FALLBACK=1, RL_MULTI_REDUCE_TIMEOUT_S=s    rl_multi_*: see rl_multi_describe
+ * Execution options.  None of them changes a result; they exist for the tests and for measurements and are NOT part of the
+ * drop-in surface.  rl_context_create copies them ONCE from the process environment (RL_<NAME>) into the context; afterwards
+ * rl_context_set_option(ctx, "<name>", value) changes them per context, and no render entry point ever reads the environment
+ * (a render works on the copy of the table it took when it started).  The full list is rustlight_amd/csrc/kernels/knobs.h; the ones the tests use:
+ *   force_streaming = 1       (creation time: environment RL_FORCE_STREAMING only) keep small scenes out of LDS — the kernels that stream the BVH
+ *                             from L2 / HBM on scenes the oracle finishes in seconds
+ *   generic_lights = 1        (creation time: RL_GENERIC_LIGHTS) do not specialise the NEE code for area-light-only scenes
+ *   item_shift = k            reference-order streams: one block chain per 2^k lanes
+ *   ref_single_pass = 1       reference-order streams through the persistent kernel in ONE pass (the form of rounds 1-2) instead of
+ *                             chain pass + per-sample evaluation
+ *   chain_serial = 1          the chain pass by k_stream_chain (one lane per block) instead of k_stream_spec; spec_force = 1: the opposite
+ *   spec_draws_per_sample = x the draws a camera sample takes on this scene (the choice between the two chain kernels; default 150 with a medium, 12 without —
+ *                             rl_render_stats.rng_draws / camera_samples of an earlier render is the measured figure)
+ *   chain_no_pre = 1, chain_no_treelets = 1     k_stream_chain without its lane-parallel records / treelet blocks
+ *   no_overlap = 1            the evaluation pass after the chain pass instead of beside it
+ *   state_budget_mb = n       MB the recorded sampler states of the two-pass form may take (default 24 GB): small values force several chunks
+ *   fused_dynamic = 0|1       persistent kernel: static tile order / work items from the atomic dispenser
+ *   no_events = 1             no HIP events around the kernels (rl_render_stats.ms_* stay 0)
+ * rl_multi_* reads RL_MULTI_FORCE_HOST_MERGE=1, RL_MULTI_NO_FALLBACK=1, RL_MULTI_REDUCE_TIMEOUT_S=s when the communicator is built / a reduce runs: see rl_multi_describe.
  */
 #ifndef RUSTLIGHT_AMD_H
 #define RUSTLIGHT_AMD_H
@@ -281,7 +286,13 @@ typedef struct rl_render_stats {
     /* per-kernel accumulated device time from HIP events on the render stream (ms) */
     double ms_raygen, ms_extend, ms_shade, ms_shadow, ms_prepass, ms_other;   /* ms_other = the fused kernel; ms_prepass = k_stream_chain, the draw-count pass of reference-order streams */
     uint64_t n_extend_launches;
-    uint64_t reserved[4];
+    uint64_t reserved[4];         /* k_stream_spec: samples walked speculatively / serially / by the probes, lanes per block (0: k_stream_chain ran) */
+    /* reference-order streams in two passes (round 6): */
+    uint32_t chunks;              /* chunks of block cursors the frame was cut into (the recorded sampler states fit their buffer); 0 = not the two-pass form */
+    uint32_t overlapped;          /* 1: the evaluation pass ran BESIDE the chain pass (every chunk) — then ms_other is only the part of it left after the chain pass
+                                   * had ended; 0: after it */
+    double ms_eval_span;          /* the evaluation pass from its first launch to its last completion (overlapped: host clock over launches on several streams;
+                                   * otherwise = ms_other): what a roofline of k_path_fused must divide by */
 } rl_render_stats;
 
 /* Opaque device context: BVHAccel::new(scene) (src/accel.rs:202-239) + flattened scene in HBM. */
@@ -295,6 +306,11 @@ int rl_device_count(int* count);
  * Fails with RL_ERR_NO_DEVICE when no GPU is present — there is no CPU fallback. */
 int rl_context_create(const rl_scene* scene, int device, rl_context** out);
 void rl_context_destroy(rl_context* ctx);
+/* Execution options of a context (see the list at the top of this header): `value` as text, NULL = back to the default.  RL_ERR_INVALID_ARGUMENT for an unknown
+ * name, RL_ERR_UNSUPPORTED for the two creation-time options.  Not to be called while a render runs on the same context.  rl_context_get_option returns the text
+ * an option holds, NULL when it is not set.  (No counterpart in rustlight: these are test / measurement hooks of this implementation.) */
+int rl_context_set_option(rl_context* ctx, const char* name, const char* value);
+const char* rl_context_get_option(const rl_context* ctx, const char* name);
 const char* rl_last_error(void);
 
 /* generate_img_blocks (src/integrators/mod.rs:351-374): number of <=16x16 blocks, and the

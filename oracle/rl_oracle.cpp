@@ -20,6 +20,10 @@
 //   * transcendentals go through oracle/detmath.h instead of the platform libm (see there);
 //   * a path is cut when `generate`'s depth counter reaches 2048 (the reference loops forever on NaN
 //     throughput: `rr_weight < next()` is false for NaN, directional.rs:77-85);
+//   * the SAH builder sorts primitive boxes by centre with std::stable_sort and the comparator `a < b` (accel.rs:125-131: `sort_by(|a, b| if a < b {Less} else
+//     {Greater})`).  For finite centres that is the order Rust's stable merge sort gives.  With a NaN centre (non-finite vertices) `<` is not a strict weak order:
+//     libstdc++'s merge sort and Rust's then both return SOME permutation, not provably the same one — this oracle and the product's host builder (csrc/host/bvh.cpp,
+//     same libstdc++ call) agree with each other on such meshes (tests: test_non_finite_and_degenerate_geometry_parity), nothing says they agree with rustlight;
 //   * `eval_order = 1` ("forward") evaluates the same path graph front-to-back the way the GPU
 //     wavefront accumulates it; `eval_order = 0` is the reference's inner-first recursion
 //     (explicit/path.rs:113-184).  They differ only in f32 rounding of the final radiance.

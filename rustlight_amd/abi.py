@@ -69,7 +69,7 @@ class RenderStats(C.Structure):
                 ("kernel_launches", C.c_uint64), ("render_ms", C.c_double), ("ms_raygen", C.c_double),
                 ("ms_extend", C.c_double), ("ms_shade", C.c_double), ("ms_shadow", C.c_double),
                 ("ms_prepass", C.c_double), ("ms_other", C.c_double), ("n_extend_launches", C.c_uint64),
-                ("reserved", C.c_uint64 * 4)]
+                ("reserved", C.c_uint64 * 4), ("chunks", C.c_uint32), ("overlapped", C.c_uint32), ("ms_eval_span", C.c_double)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -7,6 +7,7 @@ The library must already be built in-tree (``python -m rustlight_amd.build`` or
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from typing import Optional
@@ -32,7 +33,7 @@ PUBLIC_SYMBOLS = [
     "rl_scene_add_bitmap", "rl_scene_set_medium", "rl_scene_add_point_light", "rl_scene_add_directional_light",
     "rl_scene_set_environment", "rl_scene_set_environment_map", "rl_scene_build_emitters", "rl_scene_enable_ats", "rl_scene_load_pbrt", "rl_scene_load_mitsuba", "rl_scene_load",
     "rl_scene_image_size", "rl_scene_counts", "rl_sampler_seed", "rl_sampler_next_u64", "rl_sampler_next_f32",
-    "rl_path_params_default", "rl_device_count", "rl_context_create", "rl_context_destroy", "rl_last_error", "rl_block_count",
+    "rl_path_params_default", "rl_device_count", "rl_context_create", "rl_context_destroy", "rl_context_set_option", "rl_context_get_option", "rl_last_error", "rl_block_count",
     "rl_generate_block_seeds", "rl_render_path", "rl_render_path_frames", "rl_multi_create", "rl_multi_destroy", "rl_multi_info", "rl_multi_describe", "rl_multi_shard_stats", "rl_multi_render_path", "rl_render_ao", "rl_render_direct", "rl_trace_batch", "rl_visible_batch", "rl_load_pfm", "rl_load_image", "rl_save_pfm", "rl_save_png", "rl_save_exr", "rl_save_image", "rl_build_info",
 ]
 
@@ -59,6 +60,9 @@ def lib():
                            "(the HIP extension is mandatory, there is no fallback path)")
     L = C.CDLL(LIB_PATH)
     vp, f32p, u32p, u64p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    L.rl_context_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.rl_context_get_option.argtypes = [vp, C.c_char_p]
+    L.rl_context_get_option.restype = C.c_char_p
     L.rl_scene_create.argtypes = [C.POINTER(vp)]
     L.rl_scene_create_from_desc.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(vp)]
     L.rl_scene_destroy.argtypes = [vp]
@@ -385,6 +389,27 @@ class Context:
         if getattr(self, "h", None):
             lib().rl_context_destroy(self.h)
             self.h = None
+
+    def set_option(self, name: str, value=None):
+        """rl_context_set_option: an execution option of this context (csrc/kernels/knobs.h: "spec_force", "no_overlap", "state_budget_mb", ...; none changes a
+        result), `None` = back to the default.  The context took the environment's RL_<NAME> values when it was created; renders never read the environment."""
+        _check(lib().rl_context_set_option(self.h, name.lower().encode(), None if value is None else str(value).encode()))
+
+    def get_option(self, name: str):
+        v = lib().rl_context_get_option(self.h, name.lower().encode())
+        return None if v is None else v.decode()
+
+    @contextlib.contextmanager
+    def options(self, **kw):
+        """`with ctx.options(spec_force=1, no_overlap=1): ...` — the options set inside the block, back to what they were after it."""
+        before = {k: self.get_option(k) for k in kw}
+        try:
+            for k, v in kw.items():
+                self.set_option(k, v)
+            yield self
+        finally:
+            for k, v in before.items():
+                self.set_option(k, v)
 
     def __del__(self):
         try:

@@ -14,6 +14,12 @@
 #ifndef RL_FUSED_QUEUE
 #define RL_FUSED_QUEUE 0    // 1 (fusedq_lds.hip / fusedq_stream.hip): this translation unit instantiates the queue-fed form of the kernel
 #endif
+#ifndef RL_FUSED_COLD_SCRATCH
+#define RL_FUSED_COLD_SCRATCH 0   // 1 (experiment, round 6, measured: profiles/NEGATIVES.md): scenes that stream their BVH keep the per-sample-cold path state in registers / scratch instead of LDS (the freed LDS takes more stack levels: -DRL_LDS_LEVELS_STREAMING)
+#endif
+#ifndef RL_SHADE_NOINLINE
+#define RL_SHADE_NOINLINE 0       // 1 (experiment, round 6, measured): the run-time-switch shading of scenes that stream their BVH as an out-of-line function, its live-in set passed by value
+#endif
 #ifndef RL_COOP_FETCH
 #define RL_COOP_FETCH 0     // 1 / 2: streaming scenes fetch BVH records wave-cooperatively (trace.hip.h: traverse_coop; 1 = LDS staging, 2 = registers + ds_bpermute) — both measured slower, kept for the record
 #endif
@@ -29,6 +35,13 @@ namespace rl {
 #ifdef RL_STAGE_TIMERS
 __device__ unsigned long long g_stage_timers[32];      // [0..3] cycles per stage, [4..7] live lanes per stage, [8] lane slots, [16..] shadow-stage occupancy (dump_stage_timers_impl)
 #endif
+// RL_SHADE_NOINLINE: shade_slot out of line — the path state and the counters go in and come back by value, so that the traversal loops' live set need not include the material switch's
+template <class PS> struct ShadeIO { PS ps; unsigned nv, nd, ns, ne; };
+template <int MAT, bool MEDIUM, int LIGHTS, class PS>
+__device__ __attribute__((noinline)) ShadeIO<PS> shade_outlined(const RenderConst* rc, const DeviceScene* sc, ShadeIO<PS> io) {
+    shade_slot<MAT, MEDIUM, LIGHTS>(*rc, *sc, io.ps, io.ps.u(U_FLAGS), io.nv, io.nd, io.ns, io.ne);
+    return io;
+}
 // QUEUE: the form that takes its work from the chain pass's completion queue (the evaluation pass of reference-order streams, launched beside the chain pass): an
 // instantiation of its own (fusedq_lds.hip / fusedq_stream.hip), so that the per-sample kernel's code is exactly what it is without it
 template <int MAT, bool MEDIUM, bool LDS_SCENE, int LIGHTS, int NUM, bool QUEUE = false>
@@ -57,12 +70,13 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
     float* cold_f = reinterpret_cast<float*>(cold_q + 256 * FusedState::kColdQ);
     unsigned* cold_u = reinterpret_cast<unsigned*>(cold_f + 256 * FusedState::kColdF);
     using StackT = typename std::conditional<LDS2, TravStackLds2, TravStackT<LDS_SCENE>>::type;
-    const StackT stack(make_stack<LDS_SCENE>(stc, cold_u + 256 * FusedState::kColdU, tid));
+    constexpr bool COLD_LDS = LDS_SCENE || !RL_FUSED_COLD_SCRATCH;
+    const StackT stack(make_stack<LDS_SCENE>(stc, COLD_LDS ? cold_u + 256 * FusedState::kColdU : reinterpret_cast<unsigned*>(after_scene), tid));
     // streaming scenes: per-wave staging area of the cooperative record fetch, after the stacks
     constexpr bool COOP = !LDS_SCENE && RL_COOP_FETCH;
     float4* stage = reinterpret_cast<float4*>(cold_u + 256 * FusedState::kColdU + 2 * 256 * stc.lds_levels) + (threadIdx.x >> 6) * kCoopStageFloat4s;
-    FusedState ps;
-    ps.cold_q = cold_q + threadIdx.x; ps.cold_f = cold_f + threadIdx.x; ps.cold_u = cold_u + threadIdx.x;
+    typename std::conditional<COLD_LDS, FusedState, RegState>::type ps;
+    if constexpr (COLD_LDS) { ps.cold_q = cold_q + threadIdx.x; ps.cold_f = cold_f + threadIdx.x; ps.cold_u = cold_u + threadIdx.x; }
 #pragma unroll
     for (int i = 0; i < F_COUNT; i++) ps.fv[i] = 0.0f;
 #pragma unroll
@@ -182,6 +196,11 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_FUSED_WAVES : RL_FUSED_WAV
         if (PU(U_FLAGS) & ST_RAY) {
             extend_slot(sc, recs, stack, ps);
             RL_T1(1, c1)
+            if constexpr (RL_SHADE_NOINLINE && MAT == -1 && !LDS_SCENE) {
+                ShadeIO<decltype(ps)> io{ps, n_vertices, n_draws, n_shadow, n_ext};
+                io = shade_outlined<MAT, MEDIUM, LIGHTS>(&rc, &sc, io);
+                ps = io.ps; n_vertices = io.nv; n_draws = io.nd; n_shadow = io.ns; n_ext = io.ne;
+            } else
             shade_slot<MAT, MEDIUM, LIGHTS>(rc, sc, ps, PU(U_FLAGS), n_vertices, n_draws, n_shadow, n_ext);
         }
         RL_T1(2, c1)

@@ -27,10 +27,14 @@ FRAMES = [  # (workload, scene factory, width, height, spp, stream mode name, or
     ("cbox_medium", lambda w, h: scenes.cbox_medium(w, h, 0.5), 1920, 1080, 128, "per_sample", 1, (2,)),   # configs[4]
     # round 5: the drop-in default (reference-order streams) on the two slow configs, one timed step (seed 0), and configs[3]'s per-rank workload
     # (shard 0 of 8 at 1024 spp: key suffix ":shard0of8"), both stream modes
-    ("living_room", lambda w, h: scenes.living_room(w, h), 1920, 1080, 128, "reference", 0, (0,)),
-    ("cbox_medium", lambda w, h: scenes.cbox_medium(w, h, 0.5), 1920, 1080, 128, "reference", 0, (0,)),
+    # (round 6: three timed steps each — the last one is seed 2)
+    ("living_room", lambda w, h: scenes.living_room(w, h), 1920, 1080, 128, "reference", 0, (0, 2)),
+    ("cbox_medium", lambda w, h: scenes.cbox_medium(w, h, 0.5), 1920, 1080, 128, "reference", 0, (0, 2)),
     ("cbox", lambda w, h: scenes.cbox(w, h), 1920, 1080, 1024, "reference", 0, (0,), (0, 8)),
     ("cbox", lambda w, h: scenes.cbox(w, h), 1920, 1080, 1024, "per_sample", 1, (0,), (0, 8)),
+    # round 6: configs[3] WHOLE — the full 1920 x 1080 x 1024 spp frame (what the eight shards sum to), both stream modes (~7 min each on 8 cores)
+    ("cbox", lambda w, h: scenes.cbox(w, h), 1920, 1080, 1024, "reference", 0, (0,)),
+    ("cbox", lambda w, h: scenes.cbox(w, h), 1920, 1080, 1024, "per_sample", 1, (0,)),
 ]
 
 

@@ -119,11 +119,8 @@ def run(budget=20.0, seed=0, verbose=True, fast=False):
                                 RL_SPEC_DENSE=str(int(rng.choice([0, 2, 5, 16, 64]))), RL_SPEC_DENSE_FRAC=str(float(rng.choice([0.0, 0.3, 0.6, 0.9]))))      # (serial walks on the group's idle lanes)
                 if rng.random() < 0.2: spec_env["RL_SPEC_NO_TRIVIAL"] = "1"
                 if rng.random() < 0.2: spec_env["RL_STATE_BUDGET_MB"] = "1"
-            os.environ.update(spec_env)
-            try:
+            with ctx.options(**{k[3:].lower(): v for k, v in spec_env.items()}):      # (rl_context_set_option: the render path never reads the environment)
                 img, st = ctx.render(api.IndependentSampler(seed, kw["seed_variant"]).block_seeds(sd.width, sd.height), api.path_params(pipeline=pipe, sample_split=split, pool_slots=pool, **kw))
-            finally:
-                for k in spec_env: os.environ.pop(k, None)
             if spec_env: kw = dict(kw, _spec=spec_env)
             ref, ost = osc.render(master_seed=seed, eval_order=1, **{k: v for k, v in kw.items() if k != "_spec"})
             ok = np.array_equal(img, ref) and all(st[k] == ost[k] for k in ("camera_samples", "vertices", "extension_rays", "rng_draws", "shadow_rays"))

@@ -334,9 +334,8 @@ def test_small_scenes_through_the_streaming_kernels(built, monkeypatch, pipeline
         if pipeline == api.PIPELINE_FUSED:
             # the chain pass of reference-order streams reads the BVH through 16-node treelet blocks (traverse_treelet): against the plain per-node fetches
             a = ctx.render(api.IndependentSampler(0).block_seeds(sd.width, sd.height), api.path_params(stream_mode=api.STREAM_REFERENCE_ORDER, **kw))[0]
-            monkeypatch.setenv("RL_CHAIN_NO_TREELETS", "1")
-            b = ctx.render(api.IndependentSampler(0).block_seeds(sd.width, sd.height), api.path_params(stream_mode=api.STREAM_REFERENCE_ORDER, **kw))[0]
-            monkeypatch.delenv("RL_CHAIN_NO_TREELETS")
+            with ctx.options(chain_no_treelets=1):
+                b = ctx.render(api.IndependentSampler(0).block_seeds(sd.width, sd.height), api.path_params(stream_mode=api.STREAM_REFERENCE_ORDER, **kw))[0]
             np.testing.assert_array_equal(a, b)
     sd = scenes.living_room(48, 32, n_spheres=20, tess=8)
     ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
@@ -426,12 +425,9 @@ def test_ao_and_direct_integrators_parity(built, mode):
             two_ao, sa = ctx.render_ao(seeds, spp=3, stream_mode=mode, max_distance=0.3, normal_correction=True)
             two_di, sd2 = ctx.render_direct(seeds, spp=3, stream_mode=mode, nb_bsdf_samples=2, nb_light_samples=3)
             assert sa["ms_prepass"] > 0.0 and sd2["ms_prepass"] > 0.0
-            os.environ["RL_REF_SINGLE_PASS"] = "1"
-            try:
+            with ctx.options(ref_single_pass=1):
                 one_ao, sb = ctx.render_ao(seeds, spp=3, stream_mode=mode, max_distance=0.3, normal_correction=True)
                 one_di, _ = ctx.render_direct(seeds, spp=3, stream_mode=mode, nb_bsdf_samples=2, nb_light_samples=3)
-            finally:
-                del os.environ["RL_REF_SINGLE_PASS"]
             assert sb["ms_prepass"] == 0.0
             np.testing.assert_array_equal(two_ao, one_ao)
             np.testing.assert_array_equal(two_di, one_di)
@@ -547,11 +543,9 @@ def test_frames_in_flight_render_the_same_frames(built, cbox64, tmp_path):
         jobs = [(api.IndependentSampler(100 + f).block_seeds(64, 64), api.path_params(spp=spp, stream_mode=mode)) for f in range(7)]
         one = api.Context(scene, 0)
         want = [one.render(*j) for j in jobs]
-        os.environ["RL_SPEC_FORCE"] = "1"           # (64 x 64 x 48 spp would pick the serial chain pass)
-        try:
-            got = api.render_in_flight([api.Context(scene, 0) for _ in range(3)], jobs)
-        finally:
-            del os.environ["RL_SPEC_FORCE"]
+        flying = [api.Context(scene, 0) for _ in range(3)]
+        for c in flying: c.set_option("spec_force", 1)           # (64 x 64 x 48 spp would pick the serial chain pass)
+        got = api.render_in_flight(flying, jobs)
         for (wi, ws), (gi, gs) in zip(want, got):
             np.testing.assert_array_equal(gi, wi)
             assert gs["rng_draws"] == ws["rng_draws"] and gs["vertices"] == ws["vertices"]
@@ -801,18 +795,12 @@ def _full_size_default_mode(sd, ctx, osc, seeds, blocks, spp, min_verts):
     passes: the blocks equal the oracle's walk of the same block streams bit for bit, and the two forms of the chain pass — the speculative one
     (k_stream_spec, forced: `spp` is too small for it to be chosen) and the one-lane-per-block walk (k_stream_chain) — give the same frame and counters."""
     keys = ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws")
-    os.environ["RL_SPEC_FORCE"] = "1"
-    try:
+    with ctx.options(spec_force=1):
         r, st = ctx.render(seeds, api.path_params(spp=spp, stream_mode=api.STREAM_REFERENCE_ORDER))
-    finally:
-        del os.environ["RL_SPEC_FORCE"]
     assert st["ms_prepass"] > 0.0 and st["spec_group"] > 0 and st["camera_samples"] == sd.width * sd.height * spp and np.isfinite(r).all()
     assert _oracle_blocks_match(sd, osc, r, seeds, blocks, stream_mode=0, spp=spp) > min_verts
-    os.environ["RL_CHAIN_SERIAL"] = "1"
-    try:
+    with ctx.options(chain_serial=1):
         r2, st2 = ctx.render(seeds, api.path_params(spp=spp, stream_mode=api.STREAM_REFERENCE_ORDER))
-    finally:
-        del os.environ["RL_CHAIN_SERIAL"]
     assert st2["spec_group"] == 0
     np.testing.assert_array_equal(r, r2)
     assert all(st[k] == st2[k] for k in keys)
@@ -870,17 +858,14 @@ def test_reference_order_two_pass_equals_single_pass(built, monkeypatch):
              (scenes.many_lights(48, 48, n=5, use_ats=True), dict(spp=2, max_depth=4))]
     for sd, kw in cases:
         ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
-        monkeypatch.delenv("RL_REF_SINGLE_PASS", raising=False)
-        monkeypatch.delenv("RL_STATE_BUDGET_MB", raising=False)
         two = _render_pair(sd, ctx, osc, seed=3, stream_mode=ref_mode, **kw)
         _assert_parity(*two)
         assert two[1]["ms_prepass"] > 0.0 and two[1]["ms_other"] > 0.0          # both passes ran
-        monkeypatch.setenv("RL_REF_SINGLE_PASS", "1")
-        one = _render_pair(sd, ctx, osc, seed=3, stream_mode=ref_mode, **kw)
+        with ctx.options(ref_single_pass=1):
+            one = _render_pair(sd, ctx, osc, seed=3, stream_mode=ref_mode, **kw)
         assert one[1]["ms_prepass"] == 0.0
         np.testing.assert_array_equal(two[0], one[0])
         assert all(two[1][k] == one[1][k] for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws"))
-        monkeypatch.delenv("RL_REF_SINGLE_PASS")
         for split in (0, 3):
             img, st = ctx.render(api.IndependentSampler(3).block_seeds(sd.width, sd.height), api.path_params(stream_mode=ref_mode, sample_split=split, **kw))
             np.testing.assert_array_equal(img, two[0])
@@ -891,10 +876,9 @@ def test_reference_order_two_pass_equals_single_pass(built, monkeypatch):
         assert ctx.debug_sizes()["lds_scene"] and sd.n_triangles <= 64
         base = _render_pair(sd, ctx, osc, seed=9, stream_mode=ref_mode, **kw)
         _assert_parity(*base)
-        for env in (dict(RL_ITEM_SHIFT="5"), dict(RL_ITEM_SHIFT="6"), dict(RL_CHAIN_NO_PRE="1"), dict(RL_ITEM_SHIFT="4")):
-            for k, v in env.items(): monkeypatch.setenv(k, v)
-            img, st = ctx.render(api.IndependentSampler(9).block_seeds(sd.width, sd.height), api.path_params(stream_mode=ref_mode, **kw))
-            for k in env: monkeypatch.delenv(k)
+        for env in (dict(item_shift=5), dict(item_shift=6), dict(chain_no_pre=1), dict(item_shift=4)):
+            with ctx.options(**env):
+                img, st = ctx.render(api.IndependentSampler(9).block_seeds(sd.width, sd.height), api.path_params(stream_mode=ref_mode, **kw))
             np.testing.assert_array_equal(img, base[0], err_msg=str(env))
             assert all(st[k] == base[1][k] for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws"))
     # several chunks: 1 MB of states = a few block cursors per chunk on this frame (130 blocks x 24 spp x 32 B per cursor)
@@ -902,15 +886,16 @@ def test_reference_order_two_pass_equals_single_pass(built, monkeypatch):
     ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
     whole = _render_pair(sd, ctx, osc, seed=1, stream_mode=ref_mode, spp=24)
     _assert_parity(*whole)
-    monkeypatch.setenv("RL_STATE_BUDGET_MB", "1")
+    ctx.set_option("state_budget_mb", 1)
     img, st = ctx.render(api.IndependentSampler(1).block_seeds(160, 200), api.path_params(stream_mode=ref_mode, spp=24))
-    assert st["iterations"] > 10                                                  # chunks
+    assert st["iterations"] > 10 and st["chunks"] == st["iterations"]             # chunks
+    assert st["overlapped"] == 1                                                  # (round 6: the evaluation pass runs beside the chain pass chunk by chunk)
     np.testing.assert_array_equal(img, whole[0])
     assert all(st[k] == whole[1][k] for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws"))
     # a budget that not even one cursor position of every block fits (130 blocks x 300 spp x 32 B > 1 MB): the single-pass walk takes over, same image
     big, stb = ctx.render(api.IndependentSampler(2).block_seeds(160, 200), api.path_params(stream_mode=ref_mode, spp=300))
-    assert stb["ms_prepass"] == 0.0
-    monkeypatch.delenv("RL_STATE_BUDGET_MB")
+    assert stb["ms_prepass"] == 0.0 and stb["chunks"] == 0
+    ctx.set_option("state_budget_mb", None)
     big2, stb2 = ctx.render(api.IndependentSampler(2).block_seeds(160, 200), api.path_params(stream_mode=ref_mode, spp=300))
     assert stb2["ms_prepass"] > 0.0 and stb2["rng_draws"] == stb["rng_draws"]
     np.testing.assert_array_equal(big, big2)
@@ -923,49 +908,57 @@ def test_reference_order_two_pass_equals_single_pass(built, monkeypatch):
     ctx = api.Context(api.Scene(sd), 0)
     seeds = api.IndependentSampler(2).block_seeds(1280, 800)
     a, sa = ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=8))
-    monkeypatch.setenv("RL_STATE_BUDGET_MB", "143")
-    b, sb = ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=8))
-    monkeypatch.delenv("RL_STATE_BUDGET_MB")
-    assert sa["iterations"] == 1 and sb["iterations"] == 2
+    with ctx.options(state_budget_mb=143):
+        b, sb = ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=8))
+    assert sa["iterations"] == 1 and sb["iterations"] == 2 and sa["chunks"] == 1 and sb["chunks"] == 2 and sb["overlapped"] == 1
     np.testing.assert_array_equal(a, b)
     assert all(sa[k] == sb[k] for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws"))
 
 
 def test_overlapped_evaluation_pass_equals_back_to_back(built, monkeypatch):
-    """Reference-order streams, round 5: the evaluation pass (k_path_fused from the recorded sampler states) runs BESIDE the chain pass on a second stream — the chain kernels
-    push every block whose states are all recorded onto a completion queue (release), the evaluation kernel's lanes claim pixel items of completed blocks from it (acquire)
-    — instead of after it (RL_NO_OVERLAP=1: the two passes back to back, the form rounds 3-4 shipped).  Same samples from the same states, folded per pixel in sample
-    order: the image and every counter must be identical, and identical to the oracle's — on LDS-staged and streamed scenes (the streamed ones keep a second set of
-    overflow stack levels for the kernel that runs beside the chain kernel), with a medium, through both chain kernels (speculative, forced; serial), ragged frames,
-    shards with several lanes per pixel, and repeatedly on one context (the queue is reset per render).  src/integrators/mod.rs:420-448."""
+    """Reference-order streams, round 5: the evaluation pass (k_path_fused from the recorded sampler states) runs BESIDE the chain pass — the chain kernels flag every
+    block whose sample states are all recorded (a release fence, then the render's tag into the block's word in mapped host memory), the host thread inside rl_render_path
+    polls those words and launches k_path_fused<.., QUEUE = true> over explicit lists of complete blocks on the context's low-priority streams; nothing on the device
+    waits — instead of after it (option no_overlap: the two passes back to back, the form rounds 3-4 shipped).  Same samples from the same states, folded per pixel in
+    sample order: the image and every counter must be identical, and identical to the oracle's — on LDS-staged and streamed scenes (the streamed ones keep a second set
+    of overflow stack levels for the kernel that runs beside the chain kernel), with a medium, through both chain kernels (speculative, forced; serial), ragged frames,
+    shards with several lanes per pixel, a frame cut into several chunks (round 6: every chunk's evaluation runs beside its chain pass), and repeatedly on one context
+    (the flags are re-tagged per render).  rl_render_stats.overlapped / .chunks say which form ran.  src/integrators/mod.rs:420-448."""
     ref_mode = api.STREAM_REFERENCE_ORDER
     keys = ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws")
     cases = [(scenes.cbox(70, 41), dict(spp=24), {}),
-             (scenes.cbox(96, 64), dict(spp=40), dict(RL_SPEC_FORCE="1")),
+             (scenes.cbox(96, 64), dict(spp=40), dict(spec_force=1)),
              (scenes.cbox_medium(40, 40, 0.8, 0.2, g=0.6), dict(spp=6), {}),
              (scenes.living_room(64, 48, n_spheres=27, tess=10), dict(spp=12, max_depth=10), {}),
-             (scenes.living_room(64, 48, n_spheres=27, tess=10), dict(spp=16, max_depth=10), dict(RL_SPEC_FORCE="1", RL_FORCE_STREAMING="1")),
+             (scenes.living_room(64, 48, n_spheres=27, tess=10), dict(spp=16, max_depth=10), dict(spec_force=1, RL_FORCE_STREAMING="1")),
              (scenes.cbox(48, 48), dict(spp=9), dict(RL_FORCE_STREAMING="1")),
+             (scenes.cbox(160, 200), dict(spp=24), dict(state_budget_mb=1)),          # several chunks: the evaluation pass beside the chain pass chunk by chunk (round 6)
              (scenes.many_lights(48, 48, n=5, use_ats=True), dict(spp=6, max_depth=4), {}),
              (scenes.cbox(160, 200), dict(spp=32, sample_split=4), {}),
-             (scenes.cbox(160, 200), dict(spp=32, shard_index=1, shard_count=3), dict(RL_SPEC_FORCE="1"))]
+             (scenes.cbox(160, 200), dict(spp=32, shard_index=1, shard_count=3), dict(spec_force=1))]
     for n_case, (sd, kw, env) in enumerate(cases):
-        for k, v in env.items(): monkeypatch.setenv(k, v)
+        # (RL_* entries: the creation-time options, which a context takes from the environment; the others: rl_context_set_option)
+        for k, v in env.items():
+            if k.startswith("RL_"): monkeypatch.setenv(k, v)
         ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
+        for k, v in env.items():
+            if not k.startswith("RL_"): ctx.set_option(k, v)
         seeds = api.IndependentSampler(5).block_seeds(sd.width, sd.height)
-        monkeypatch.setenv("RL_NO_OVERLAP", "1")
-        base, st0 = ctx.render(seeds, api.path_params(stream_mode=ref_mode, **kw))
-        monkeypatch.delenv("RL_NO_OVERLAP")
+        with ctx.options(no_overlap=1):
+            base, st0 = ctx.render(seeds, api.path_params(stream_mode=ref_mode, **kw))
+        assert st0["overlapped"] == 0 and st0["chunks"] >= 1
         for rep in range(3):
             img, st = ctx.render(seeds, api.path_params(stream_mode=ref_mode, **kw))
             np.testing.assert_array_equal(img, base, err_msg=f"case {n_case} rep {rep}")
             assert all(st[k] == st0[k] for k in keys), (n_case, rep)
-            assert st["ms_prepass"] > 0.0
+            assert st["ms_prepass"] > 0.0 and st["overlapped"] == 1 and st["chunks"] == st0["chunks"], (n_case, rep, st["overlapped"], st["chunks"])
+            assert st["ms_eval_span"] >= st["ms_other"] > 0.0 or st["ms_eval_span"] > 0.0
         okw = {k: v for k, v in kw.items() if k != "sample_split"}
         ref, ost = osc.render(seeds=seeds, stream_mode=0, eval_order=1, **okw)
         np.testing.assert_array_equal(base, ref, err_msg=f"case {n_case} vs the oracle")
         assert all(st0[k] == ost[k] for k in ("vertices", "rng_draws", "shadow_rays", "extension_rays")), n_case
-        for k in env: monkeypatch.delenv(k)
+        for k in env:
+            if k.startswith("RL_"): monkeypatch.delenv(k)
 
 
 def test_rng_advance_equals_stepping(built):
@@ -1003,71 +996,79 @@ def test_reference_order_speculative_chain(built, monkeypatch):
              (scenes.living_room(64, 48, n_spheres=27, tess=10), dict(spp=12, max_depth=10)),          # glass / mirror / phong / substrate
              (scenes.sky_scene(48, 48), dict(spp=8, min_depth=1)),
              (scenes.many_lights(48, 48, n=5, use_ats=True), dict(spp=6, max_depth=4))]
-    shapes = [dict(RL_SPEC_GROUP="16", RL_SPEC_SUB="1"), dict(RL_SPEC_GROUP="32", RL_SPEC_SUB="2"), dict(RL_SPEC_GROUP="64", RL_SPEC_SUB="4"), dict(RL_SPEC_GROUP="64", RL_SPEC_SUB="8"),
-              dict(RL_SPEC_GROUP="32", RL_SPEC_SUB="1", RL_SPEC_CAP="5"), dict(RL_SPEC_GROUP="64", RL_SPEC_SUB="2", RL_SPEC_LEAD="0", RL_SPEC_KS="0", RL_SPEC_KE="0", RL_SPEC_PROBE="0"),
-              dict(RL_SPEC_GROUP="16", RL_SPEC_SUB="4", RL_SPEC_NO_TRIVIAL="1", RL_SPEC_KS="5", RL_SPEC_KE="5"),
-              dict(RL_SPEC_GROUP="256", RL_SPEC_SUB="16"), dict(RL_SPEC_GROUP="256", RL_SPEC_SUB="1", RL_SPEC_EXTRA="1"), dict(RL_SPEC_GROUP="64", RL_SPEC_SUB="16", RL_SPEC_EXTRA="1", RL_SPEC_PROBE_EVERY="1"),
-              dict(RL_SPEC_GROUP="32", RL_SPEC_SUB="2", RL_SPEC_DENSE="32", RL_SPEC_DENSE_FRAC="0"), dict(RL_SPEC_GROUP="64", RL_SPEC_SUB="1", RL_SPEC_DENSE="3", RL_SPEC_DENSE_FRAC="0", RL_SPEC_LEAD="0", RL_SPEC_KS="0", RL_SPEC_KE="0"),
-              dict(RL_SPEC_GROUP="16", RL_SPEC_SUB="2", RL_SPEC_DENSE="0")]   # 256: a whole workgroup per block (votes and sums through the barrier)
+    shapes = [dict(spec_group=16, spec_sub=1), dict(spec_group=32, spec_sub=2), dict(spec_group=64, spec_sub=4), dict(spec_group=64, spec_sub=8),
+              dict(spec_group=32, spec_sub=1, spec_cap=5), dict(spec_group=64, spec_sub=2, spec_lead=0, spec_ks=0, spec_ke=0, spec_probe=0),
+              dict(spec_group=16, spec_sub=4, spec_no_trivial=1, spec_ks=5, spec_ke=5),
+              dict(spec_group=256, spec_sub=16), dict(spec_group=256, spec_sub=1, spec_extra=1), dict(spec_group=64, spec_sub=16, spec_extra=1, spec_probe_every=1),
+              dict(spec_group=32, spec_sub=2, spec_dense=32, spec_dense_frac=0), dict(spec_group=64, spec_sub=1, spec_dense=3, spec_dense_frac=0, spec_lead=0, spec_ks=0, spec_ke=0),
+              dict(spec_group=16, spec_sub=2, spec_dense=0)]   # 256: a whole workgroup per block (votes and sums through the barrier)
     keys = ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws")
     for n_case, (sd, kw) in enumerate(cases):
         ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
         seeds = api.IndependentSampler(7).block_seeds(sd.width, sd.height)
-        monkeypatch.setenv("RL_CHAIN_SERIAL", "1")
-        base = _render_pair(sd, ctx, osc, seed=7, stream_mode=ref_mode, **kw)
+        with ctx.options(chain_serial=1):
+            base = _render_pair(sd, ctx, osc, seed=7, stream_mode=ref_mode, **kw)
         _assert_parity(*base)
         assert base[1]["spec_group"] == 0
-        monkeypatch.delenv("RL_CHAIN_SERIAL")
-        monkeypatch.setenv("RL_SPEC_FORCE", "1")
+        ctx.set_option("spec_force", 1)
         for env in (shapes if n_case < 2 else shapes[n_case % 4::4]):
-            for k, v in env.items(): monkeypatch.setenv(k, v)
-            img, st = ctx.render(seeds, api.path_params(stream_mode=ref_mode, **kw))
-            for k in env: monkeypatch.delenv(k)
-            assert st["spec_group"] == int(env["RL_SPEC_GROUP"]), env
+            with ctx.options(**env):
+                img, st = ctx.render(seeds, api.path_params(stream_mode=ref_mode, **kw))
+            assert st["spec_group"] == int(env["spec_group"]), env
             np.testing.assert_array_equal(img, base[0], err_msg=f"case {n_case} {env}")
             assert all(st[k] == base[1][k] for k in keys), (n_case, env)
-        monkeypatch.delenv("RL_SPEC_FORCE")
+        ctx.set_option("spec_force", None)
     # chunks (the chain is parked between them), shards, and the kernels that stream the BVH
     sd = scenes.cbox(160, 200)
     ctx, osc = api.Context(api.Scene(sd), 0), orc.Scene(sd)
     seeds = api.IndependentSampler(1).block_seeds(160, 200)
-    monkeypatch.setenv("RL_CHAIN_SERIAL", "1")
-    whole = _render_pair(sd, ctx, osc, seed=1, stream_mode=ref_mode, spp=40)
+    with ctx.options(chain_serial=1):
+        whole = _render_pair(sd, ctx, osc, seed=1, stream_mode=ref_mode, spp=40)
     _assert_parity(*whole)
-    monkeypatch.delenv("RL_CHAIN_SERIAL")
-    monkeypatch.setenv("RL_SPEC_FORCE", "1")
+    ctx.set_option("spec_force", 1)
     img, st = ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=40))
     assert st["spec_group"] > 0 and st["spec_samples"] > 0
     np.testing.assert_array_equal(img, whole[0])
-    monkeypatch.setenv("RL_STATE_BUDGET_MB", "2")
-    img, st = ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=40))
-    assert st["iterations"] > 5 and st["spec_group"] > 0
+    with ctx.options(state_budget_mb=2):
+        img, st = ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=40))
+    assert st["iterations"] > 5 and st["spec_group"] > 0 and st["chunks"] == st["iterations"]
     np.testing.assert_array_equal(img, whole[0])
-    monkeypatch.delenv("RL_STATE_BUDGET_MB")
     parts = [ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=40, shard_index=r, shard_count=3))[0] for r in range(3)]
     np.testing.assert_array_equal(parts[0] + parts[1] + parts[2], whole[0])
     monkeypatch.setenv("RL_FORCE_STREAMING", "1")
     sctx = api.Context(api.Scene(sd), 0)
     monkeypatch.delenv("RL_FORCE_STREAMING")
     assert not sctx.debug_sizes()["lds_scene"]
-    for env in (dict(RL_SPEC_GROUP="64", RL_SPEC_SUB="4"), dict(RL_SPEC_GROUP="32", RL_SPEC_SUB="1")):
-        for k, v in env.items(): monkeypatch.setenv(k, v)
-        img, st = sctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=40))
-        for k in env: monkeypatch.delenv(k)
-        assert st["spec_group"] == int(env["RL_SPEC_GROUP"])
+    sctx.set_option("spec_force", 1)
+    for env in (dict(spec_group=64, spec_sub=4), dict(spec_group=32, spec_sub=1)):
+        with sctx.options(**env):
+            img, st = sctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=40))
+        assert st["spec_group"] == int(env["spec_group"])
         np.testing.assert_array_equal(img, whole[0], err_msg=str(env))
     # a device whose workgroups may not ask for the pass's LDS (53 KB on this scene): the serial chain renders the frame instead of a refused launch
-    monkeypatch.setenv("RL_SPEC_LDS_LIMIT_TEST", "32768")
-    img, st = ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=40))
-    monkeypatch.delenv("RL_SPEC_LDS_LIMIT_TEST")
+    with ctx.options(spec_lds_limit_test=32768):
+        img, st = ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=40))
     assert st["spec_group"] == 0 and st["ms_prepass"] > 0.0
     np.testing.assert_array_equal(img, whole[0])
-    # the policy: a frame this small at 40 spp is left to the serial chain unless forced; with the ~17 draws per sample the last render measured, 96 spp is enough
-    monkeypatch.delenv("RL_SPEC_FORCE")
-    img, st = ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=8))
-    assert st["spec_group"] == 0
-    img, st = ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=96))
-    assert st["spec_group"] > 0
+    # the policy: k_stream_spec when a pixel has at least 4 x as many samples as a sample takes draws — 12 on a scene without a medium unless the host says
+    # otherwise (option spec_draws_per_sample) — so 40 spp is left to the serial chain unless forced and 96 spp is enough.  The choice is a pure function
+    # of scene, parameters and options: a context's first frame and its fifth take the same kernels (it used to follow the draws per
+    # sample the context's PREVIOUS render had measured)
+    ctx.set_option("spec_force", None)
+    assert ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=8))[1]["spec_group"] == 0
+    assert ctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=40))[1]["spec_group"] == 0
+    fresh = api.Context(api.Scene(sd), 0)
+    choice = []
+    for frame in range(5):
+        img, st = fresh.render(seeds, api.path_params(stream_mode=ref_mode, spp=96))
+        choice.append(st["spec_group"])
+        if frame == 2: fresh.render(seeds, api.path_params(stream_mode=ref_mode, spp=8, max_depth=2))       # (a render with other parameters in between changes nothing)
+    assert choice[0] > 0 and len(set(choice)) == 1, choice
+    with fresh.options(spec_draws_per_sample=30):
+        assert fresh.render(seeds, api.path_params(stream_mode=ref_mode, spp=96))[1]["spec_group"] == 0
+    with pytest.raises(api.RustlightError): fresh.set_option("no_such_option", 1)
+    with pytest.raises(api.RustlightError): fresh.set_option("force_streaming", 1)        # (creation-time: the environment when the context is made)
+    assert fresh.get_option("spec_force") is None and ctx.get_option("spec_force") is None
 
 
 def test_full_size_reference_order(built):
@@ -1087,11 +1088,8 @@ def test_full_size_reference_order(built):
         np.testing.assert_array_equal(a[y0:y0 + 16, x0:x0 + 16], ref[y0:y0 + 16, x0:x0 + 16], err_msg=f"block {b} at ({x0}, {y0})")
         verts += ost["vertices"]
     assert verts > 8000
-    os.environ["RL_REF_SINGLE_PASS"] = "1"
-    try:
+    with ctx.options(ref_single_pass=1):
         b1, st1 = ctx.render(seeds, api.path_params(spp=8, stream_mode=api.STREAM_REFERENCE_ORDER))
-    finally:
-        del os.environ["RL_REF_SINGLE_PASS"]
     np.testing.assert_array_equal(a, b1)
     assert all(st[k] == st1[k] for k in ("camera_samples", "vertices", "extension_rays", "shadow_rays", "rng_draws"))
     _full_size_default_mode(sd, ctx, osc, seeds, [60 * 68 + 34, 66 * 68 + 46, 66 * 68 + 6, 26 * 68 + 34], spp=8, min_verts=4000)
@@ -1144,6 +1142,47 @@ def test_cfg4_one_rank_of_eight(built):
         assert verts > 500000, verts
         # a block of another rank stays black on this one
         assert not img[16:32, 0:16].any()
+
+
+def test_cfg4_whole_frame_on_one_gpu(built):
+    """BASELINE configs[3] WHOLE, as far as one GPU allows: cbox 1920 x 1080 x 1024 spp cut into the eight shards of `b % 8` (the round-robin deal of compute_mc's
+    block list, src/integrators/mod.rs:351-374) and merged as accumulate_bitmap merges the blocks' bitmaps (mod.rs:445-448) — through rl_multi_create(scene, 8 shards
+    on device 0) + rl_multi_render_path: eight device contexts, eight host threads, the co-resident shards added on the device, the RCCL clique of the one device, one
+    download.  The summed frame and the summed counters must be the oracle's render of the whole 1024-spp frame (CRC and counters from tests/golden/bench_crcs.json,
+    made by the parity build), in both stream modes; and `bench.py --gpus 8` (eight ranks sharing the device: plumbing mode) must report the same CRC match.  What is
+    then still unrun of configs[3] is the xGMI hop of the reduce."""
+    import json
+    import subprocess
+    import sys
+    import zlib
+    table = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_crcs.json")))
+    scene = api.Scene(scenes.cbox(1920, 1080))
+    seeds = api.IndependentSampler(0).block_seeds(1920, 1080)
+    mc = api.MultiContext(scene, 8)
+    assert mc.info()["shards"] == 8
+    for mode, name in ((api.STREAM_PER_SAMPLE, "per_sample"), (api.STREAM_REFERENCE_ORDER, "reference")):
+        e = table[f"cbox:1920x1080x1024:{name}:seed0"]
+        img, st = mc.render(seeds, api.path_params(spp=1024, stream_mode=mode))
+        assert f"{zlib.crc32(img.tobytes()):08x}" == e["crc32"], name
+        assert (st["camera_samples"], st["vertices"], st["rng_draws"]) == (e["camera_samples"], e["vertices"], e["rng_draws"]) and st["camera_samples"] == 1920 * 1080 * 1024, name
+        per_shard = [mc.shard_stats(g)[1] for g in range(8)]
+        assert sum(s["camera_samples"] for s in per_shard) == st["camera_samples"] and all(s["camera_samples"] > 0 for s in per_shard)
+        # shard 0 of the eight is the shard test_cfg4_one_rank_of_eight holds against the oracle's own render of it
+        e0 = table[f"cbox:1920x1080x1024:{name}:seed0:shard0of8"]
+        assert (per_shard[0]["camera_samples"], per_shard[0]["vertices"], per_shard[0]["rng_draws"]) == (e0["camera_samples"], e0["vertices"], e0["rng_draws"]), name
+        if mode == api.STREAM_REFERENCE_ORDER:
+            assert all(s["ms_prepass"] > 0.0 and s["spec_group"] > 0 for s in per_shard)
+    mc.close()
+    # bench.py's own N-rank path on the same frame: eight ranks, one process each, sharing the one device (reduce through gloo — flagged `devices_shared`)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-also", "--no-verify"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["config"]["spp_total"] == 1024 and out["distributed"]["devices_shared"] is True
+    assert out["oracle_crc32"] == table["cbox:1920x1080x1024:per_sample:seed0"]["crc32"] and out["oracle_crc_match"] is True
 
 
 def test_multi_context_rccl_reduce(built, cbox64, ctx_cbox):
@@ -1203,7 +1242,7 @@ def test_bench_two_ranks_on_one_gpu(built):
     # the same shards once more in rustlight's own reference-order streams (the drop-in default), per rank: chain pass, evaluation pass, reduce
     ro = out["reference_order"]
     assert out["reference_order_value"] == ro["value"] > 0 and len(ro["ranks"]) == 2
-    assert all(r["chain_ms"] > 0 and r["kernel_ms"] > 0 and r["reduce_ms"] >= 0 for r in ro["ranks"])
+    assert all(r["chain_ms"] > 0 and r["eval_span_ms"] > 0 and r["eval_tail_after_chain_ms"] >= 0 and r["reduce_ms"] >= 0 for r in ro["ranks"])
     assert all("reduce_ms_per_step" in r for r in out["distributed"]["ranks"])
     # ... and with three frames in flight per rank (three contexts each): the last frame's reduced image is the one-at-a-time image of that frame
     fl = ro["three_frames_in_flight"]
@@ -1256,11 +1295,8 @@ def test_fast_numerics_tolerance_mode(built):
         seeds = api.IndependentSampler(5).block_seeds(sd.width, sd.height)
         exact, st = ctx.render(seeds, api.path_params(stream_mode=api.STREAM_REFERENCE_ORDER, **kw))
         fast, stf = ctx.render(seeds, api.path_params(stream_mode=api.STREAM_REFERENCE_ORDER, numerics=api.NUMERICS_FAST, **kw))
-        os.environ["RL_REF_SINGLE_PASS"] = "1"
-        try:
+        with ctx.options(ref_single_pass=1):
             one, st1 = ctx.render(seeds, api.path_params(stream_mode=api.STREAM_REFERENCE_ORDER, numerics=api.NUMERICS_FAST, **kw))
-        finally:
-            del os.environ["RL_REF_SINGLE_PASS"]
         assert stf["ms_prepass"] > 0.0 and st1["ms_prepass"] == 0.0 and np.isfinite(fast).all() and np.isfinite(one).all()
         # what two independent renders of the scene differ by at this sample count (another master seed): the yardstick for "plain Monte Carlo noise"
         other, _ = ctx.render(api.IndependentSampler(6).block_seeds(sd.width, sd.height), api.path_params(stream_mode=api.STREAM_REFERENCE_ORDER, **kw))

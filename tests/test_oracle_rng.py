@@ -73,6 +73,25 @@ def test_f32_mapping(built):
     assert all(0.0 <= g < 1.0 for g in got)
 
 
+def test_f32_mapping_rand_standard_edge_vectors(built):
+    """rand 0.8.5's own `Standard` f32 vectors (src/distributions/float.rs, test `floats`: a generator that returns all zeros gives 0.0, one that returns 1 << 8 as its
+    u32 gives EPSILON / 2, all ones gives 1 - EPSILON / 2): `gen::<f32>()` is (next_u32() >> 8) * 2^-24, and a 64-bit generator's next_u32 is the upper half of next_u64
+    (rand_xoshiro: `(self.next_u64() >> 32) as u32`).  Xoshiro256++'s output is rotl(s0 + s3, 23) + s0, so states with s0 = 0 and a chosen s3 produce those three words
+    as their first output: checked for the oracle's sampler and for the product's (rl_sampler_next_f32), bit for bit."""
+    eps = float(np.finfo(np.float32).eps)
+    rotr23 = lambda x: ((x >> 23) | (x << 41)) & (2 ** 64 - 1)
+    for word, want in ((0, 0.0), (256 << 32, eps / 2), (2 ** 64 - 1, 1.0 - eps / 2)):
+        state = [0, 0x9e3779b97f4a7c15, 0x0123456789abcdef, rotr23(word)]
+        assert orc.Rng.from_state(state).next_u64() == word
+        got = orc.Rng.from_state(state).next_f32()
+        assert got == np.float32(want) and np.float32(got).tobytes() == np.float32(want).tobytes()
+        s = api.abi.Sampler()
+        for k in range(4): s.s[k] = state[k]
+        fn = api.lib().rl_sampler_next_f32
+        pv = np.float32(fn(s))
+        assert pv.tobytes() == np.float32(want).tobytes(), (word, pv)
+
+
 def test_block_forking_order(built):
     # master independent:0 -> block 0 seed = first next_u64; block sampler's first draws (App. B.3)
     seeds = orc.block_seeds(0, 64, 48)
