@@ -390,9 +390,9 @@ private:
         // its workgroup parks 30 words of state per lane + the groups' scratch in LDS on top of the scene and the stacks: where that exceeds what a workgroup may ask for on
         // this device the launch would be refused — the serial chain (k_stream_chain), whose workgroup is the plain traversal one, renders those scenes instead
         // (scenes that stream their BVH: the kernel's occupancy is set by its LDS — 30 KB of parked state per workgroup + the stacks — so the stack levels kept there are its own
-        // choice, option spec_lds_levels; default: as the other kernels)
-        spec_levels = (!ctx->lds_scene && knobs.has(K_SPEC_LDS_LEVELS)) ? (int)std::max<long long>(0, std::min<long long>(knobs.i(K_SPEC_LDS_LEVELS, 0), lds_levels_of(ctx))) : -1;
-        lds_spec = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false, spec_levels) + (size_t)kSpecColdWords * 256 * 4 + kSpecGroupLdsBytes;
+        // choice: three, which lets a fourth workgroup fit a CU (spec.hip.h: RL_SPEC_WAVES_STREAMING); option spec_lds_levels overrides)
+        spec_levels = ctx->lds_scene ? -1 : (int)std::max<long long>(0, std::min<long long>(knobs.i(K_SPEC_LDS_LEVELS, kSpecLdsLevelsStreaming), lds_levels_of(ctx)));
+        lds_spec = traversal_lds_bytes(ctx, ctx->lds_scene, 256, false, spec_levels) + (size_t)(kSpecColdWords - (ctx->lds_scene ? 0 : kSpecHelperWords)) * 256 * 4 + kSpecGroupLdsBytes;
         const size_t spec_lds_limit = knobs.has(K_SPEC_LDS_LIMIT_TEST) ? (size_t)knobs.i(K_SPEC_LDS_LIMIT_TEST, 0) : ctx->lds_limit;      // (test knob: a device with a smaller limit)
         if (lds_spec > spec_lds_limit) spec = false;
         spc = SpecConf{};
@@ -420,8 +420,7 @@ private:
             spc.extra = (unsigned)knobs.i(K_SPEC_EXTRA, 0);            // (cbox 1080p x 128 spp: 2.84 M instead of 3.57 M serial samples, 383 M instead of 306 M walked: 261 vs 259 ms — a wash, off)
             // (cbox 1080p x 128 spp, three workgroups per CU: 244 -> 198 ms; 8 / 16 / 32 lanes alike.  Scenes that stream their BVH: 2452 -> 2517 ms on the 508 k-triangle scene — a helper's sample is a
             // chain of dependent fetches like any other there — so off)
-            spc.dense = knobs.has(K_SPEC_DENSE) ? std::min(64u, (unsigned)knobs.i(K_SPEC_DENSE, 0)) : (ctx->lds_scene ? 16u : 0u);
-            spc.dense_frac = (float)knobs.f(K_SPEC_DENSE_FRAC, 0.6);
+            spc.dense = !ctx->lds_scene ? 0u : (knobs.has(K_SPEC_DENSE) ? std::min(64u, (unsigned)knobs.i(K_SPEC_DENSE, 0)) : 16u);
             spc.probe_every = (unsigned)knobs.i(K_SPEC_PROBE_EVERY, 0);
             // window margins in standard deviations of the predicted offsets: with one block per wave a pixel the chain has to be walked through stalls the whole wave, so wider
             // (shard 0 of 8, 1024 spp: 1.65 / 2.5 sigma = 714 / 688 ms; full frame, two blocks per wave: 281 / 292)

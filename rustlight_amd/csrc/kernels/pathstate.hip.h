@@ -62,7 +62,12 @@ static constexpr size_t kSampleBufBudget = (size_t)16 << 30;   // bytes of HBM t
 // traversal stack configuration (see TravStack)
 struct StackConf { int lds_levels; int* overflow; size_t overflow_stride; int pre_group; };   // pre_group: k_stream_chain on tiny LDS scenes — lanes per chain that precompute its ray's records (0: off; trace.hip.h: precompute_records)
 
-static constexpr int kSpecColdWords = 30;      // k_stream_spec: words of per-thread state parked in LDS, + 4 u64 + 16 words per group (host: LDS bytes of the launch)
+#ifndef RL_SPEC_LDS_LEVELS_STREAMING
+#define RL_SPEC_LDS_LEVELS_STREAMING 4
+#endif
+static constexpr int kSpecLdsLevelsStreaming = RL_SPEC_LDS_LEVELS_STREAMING;      // k_stream_spec on scenes that stream their BVH: traversal-stack levels in LDS (spec.hip.h)
+static constexpr int kSpecColdWords = 30;
+static constexpr int kSpecHelperWords = 2;       // ... of which the helpers' (K_DN, K_DR): not parked on scenes that stream their BVH (no helpers there)
 static constexpr size_t kSpecGroupLdsBytes = (256 / 16) * 32 + 64 + (256 / 16) * 64 + (256 / 16) * 16;      // per workgroup: the groups' anchors, the scan scratch, the groups' serial-walk heads, their counters
 // k_stream_spec (spec.hip.h): launch configuration and scratch of the speculative first pass of reference-order streams
 struct SpecConf {

@@ -40,9 +40,15 @@
 #ifndef RL_SPEC_WAVES
 #define RL_SPEC_WAVES 3
 #endif
+// Scenes that stream their BVH (round 6): the kernel waits on dependent record fetches half of its wave time with 18 % of the VALU issue slots busy
+// (profiles/r06_pmc_living_reference.json) and 8160 blocks at one per wave run in 2.7 generations of 3072 waves — a fourth wave per SIMD pays for its price: 128 VGPRs
+// (56 spilled, 96 B of scratch per lane) and three instead of six traversal-stack levels in LDS (38.8 KB per workgroup: four of them per CU).  508 k triangles, 1080p x
+// 128 spp, same box: 3 waves x 6 levels 2479-2540 ms, 4 x 4 (40.8 KB: does not fit four) 2589-2707, 4 x 3 2335-2348, 4 x 2 2321-2397, 4 x 1 2397-2447, 4 x 0 2487-2500,
+// 5 x 0 2793-2850 (profiles/r06_spec_occupancy_ab_living.txt).
 #ifndef RL_SPEC_WAVES_STREAMING
-#define RL_SPEC_WAVES_STREAMING 3
+#define RL_SPEC_WAVES_STREAMING 4
 #endif
+// (the stack levels kept in LDS there: pathstate.hip.h, RL_SPEC_LDS_LEVELS_STREAMING)
 
 namespace rl {
 
@@ -119,6 +125,9 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
     enum { K_CUR_OFF, K_M, K_STOP, K_NB_LO, K_CNT, K_SUM_N, K_SUM_N2, K_LINK_I, K_LINK_J, K_CP_I0, K_CP_J0, K_CP_K0, K_Q0,
            K_EST_L, K_EST_V, K_RES_I, K_RES_J, K_RES_K, K_RES_OFF, K_RES_ST, K_NMIN = K_RES_ST + 8, K_DN, K_DR, K_COLD_COUNT };
     static_assert(K_COLD_COUNT == kSpecColdWords, "LDS budget of k_stream_spec (host: wavefront.hip)");
+    // scenes that stream their BVH run without helpers (measured: between 0 and - 2 % there once a fourth wave fits a SIMD), so their lanes do not park the two helper words
+    constexpr int kCold = LDS_SCENE ? (int)K_COLD_COUNT : (int)K_COLD_COUNT - kSpecHelperWords;
+    static_assert(K_DN == K_COLD_COUNT - 2 && K_DR == K_COLD_COUNT - 1, "the helper words are the last two");
 #define COLD(k) cold[(k) * 256]
 #define COLD_OF(t, k) coldbase[(k) * 256 + (t)]
     unsigned& cur_off = COLD(K_CUR_OFF);          // stream offset (relative to the anchor) where the sample being walked started
@@ -135,16 +144,16 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
     unsigned& res_off = COLD(K_RES_OFF);          // leader: where the chain stands after the pixel (offset; the state: K_RES_ST, 8 words)
     unsigned& nmin_cnt = COLD(K_NMIN);            // fewest draws a sample of this lane's walk took (<< 16) | how many of its samples took exactly that
     // K_DN / K_DR: helper of a serial walk (below): draws of the sample it evaluated (0: not yet), the round it belongs to; its sampler after the sample: the lane's K_RES_ST
-    for (int k = 0; k < K_COLD_COUNT; k++) COLD(k) = 0u;
+    for (int k = 0; k < kCold; k++) COLD(k) = 0u;
     q0 = c_begin;
     // the block sampler where the batch begins: one copy per group, after the per-thread planes
-    unsigned long long* const ganc = reinterpret_cast<unsigned long long*>(coldbase + K_COLD_COUNT * 256) + 4u * (threadIdx.x / G);
+    unsigned long long* const ganc = reinterpret_cast<unsigned long long*>(coldbase + kCold * 256) + 4u * (threadIdx.x / G);
     auto load_anc = [&]() -> Rng { Rng r; r.s0 = ganc[0]; r.s1 = ganc[1]; r.s2 = ganc[2]; r.s3 = ganc[3]; return r; };
     auto store_anc = [&](const Rng& r) { ganc[0] = r.s0; ganc[1] = r.s1; ganc[2] = r.s2; ganc[3] = r.s3; };      // (every lane of the group writes the same value)
     store_anc(anc);
     // group-wide votes and sums: within a wave by ballot / shuffles; a group that spans the workgroup (G = 256) through the barrier (every thread of the
     // workgroup then belongs to the one group, so every call site is reached by all of them together)
-    float* const gscratch = reinterpret_cast<float*>(coldbase + K_COLD_COUNT * 256 + 8 * (256 / 16));
+    float* const gscratch = reinterpret_cast<float*>(coldbase + kCold * 256 + 8 * (256 / 16));
     // ---- a serial walk taken several samples at a time (HELPERS).  Where the chain leaves the tracks inside a pixel whose samples nearly all take the same number of draws c,
     // two walks of the pixel stay apart for long (they sit on different residues of c) and the serial walk is most of the pixel.  But then the chain's next positions are
     // predictable: from the head at offset b they are b + c, b + 2c, ... until a sample takes another count.  The group's lanes — idle while a pixel is threaded — evaluate
@@ -166,7 +175,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_SPEC_WAVES : RL_SPEC_WAVES
 #ifdef RL_PROBE_NO_DENSE
     const unsigned H = 0u;
 #else
-    const unsigned H = (G <= 64u && spc.dense > 1u) ? min(spc.dense, G) : 0u;
+    const unsigned H = (LDS_SCENE && G <= 64u && spc.dense > 1u) ? min(spc.dense, G) : 0u;
 #endif
     auto group_any = [&](bool p) -> bool { return G <= 64u ? (__ballot(p) & gmask) != 0ull : __syncthreads_or((int)p) != 0; };
     auto group_scan2 = [&](float& a, float& b) {      // inclusive prefix sums over the lanes of the group

@@ -1,6 +1,6 @@
 """Resource usage of every kernel in the built library, read from the AMDGPU code-object notes of rustlight_amd/lib/*.hip.o (llvm-objdump --offloading
 + llvm-readelf --notes): VGPRs, SGPRs, spilled registers, scratch bytes per lane, static LDS, and the waves per SIMD the register file allows.
-`python -m rustlight_amd.resources` rewrites profiles/r05_kernel_resources.csv; tests/test_resources.py regenerates the table and compares (so a change
+`python -m rustlight_amd.resources` rewrites profiles/r06_kernel_resources.csv; tests/test_resources.py regenerates the table and compares (so a change
 that makes a kernel spill shows up as a test diff, which is how VERDICT r3's 123-VGPR / 241-SGPR spill finding should have been caught)."""
 from __future__ import annotations
 
@@ -14,7 +14,7 @@ import tempfile
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
-CSV = os.path.join(os.path.dirname(_HERE), "profiles", "r05_kernel_resources.csv")
+CSV = os.path.join(os.path.dirname(_HERE), "profiles", "r06_kernel_resources.csv")
 FIELDS = ["object", "kernel", "vgpr", "agpr", "sgpr", "vgpr_spill", "sgpr_spill", "scratch_bytes_per_lane", "lds_static_bytes", "max_waves_per_simd_by_vgpr"]
 
 

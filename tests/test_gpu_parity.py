@@ -1040,7 +1040,7 @@ def test_reference_order_speculative_chain(built, monkeypatch):
     monkeypatch.delenv("RL_FORCE_STREAMING")
     assert not sctx.debug_sizes()["lds_scene"]
     sctx.set_option("spec_force", 1)
-    for env in (dict(spec_group=64, spec_sub=4), dict(spec_group=32, spec_sub=1)):
+    for env in (dict(spec_group=64, spec_sub=4), dict(spec_group=64, spec_sub=2, spec_cap=5, spec_lead=0, spec_ks=0, spec_ke=0, spec_lds_levels=0), dict(spec_group=32, spec_sub=1)):
         with sctx.options(**env):
             img, st = sctx.render(seeds, api.path_params(stream_mode=ref_mode, spp=40))
         assert st["spec_group"] == int(env["spec_group"])

@@ -1,4 +1,4 @@
-"""profiles/r05_kernel_resources.csv — VGPRs, spills, scratch, static LDS and waves per SIMD of EVERY kernel instantiation of the product library, read from
+"""profiles/r06_kernel_resources.csv — VGPRs, spills, scratch, static LDS and waves per SIMD of EVERY kernel instantiation of the product library, read from
 the code-object notes (rustlight_amd/resources.py) — is regenerated from the library this tree builds and must equal the committed table: a change that
 makes a kernel spill (or stops one spilling) has to show up in the table it is judged by."""
 import csv
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_committed_resource_table_matches_the_built_kernels(built):
     rows = resources.kernel_resources()
     assert len(rows) > 150 and any(r["kernel"].startswith("k_stream_spec") for r in rows) and any(r["kernel"].startswith("k_path_fused") for r in rows)
-    want = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r05_kernel_resources.csv"))))
+    want = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_kernel_resources.csv"))))
     got = [{k: str(v) for k, v in r.items()} for r in rows]
     assert [r["kernel"] for r in got] == [r["kernel"] for r in want], "kernel list changed: python -m rustlight_amd.resources"
     diff = [(g["kernel"], {k: (w[k], g[k]) for k in g if g[k] != w[k]}) for g, w in zip(got, want) if g != w]
