@@ -31,7 +31,7 @@ namespace rl {
 #ifdef RL_STAGE_TIMERS
 static __device__ unsigned long long g_chain_timers[8];      // dev-only (one copy per translation unit: read by that unit's own dump function): cycles in raygen / extend / shade, wave-iterations, lane-iterations of each
 static constexpr unsigned kChainWaveSlots = 1u << 16;
-static __device__ unsigned long long g_chain_waves[3 * kChainWaveSlots];      // dev-only: per wave (start, end) on the 100 MHz wall clock and its iteration count — the lifetime histogram of dump_chain_timers
+static __device__ unsigned long long g_chain_waves[4 * kChainWaveSlots];      // dev-only: per wave (start, end) on the 100 MHz wall clock and its iteration count — the lifetime histogram of dump_chain_timers
 #define RL_CT0 { ct0 = __builtin_readcyclecounter(); }
 #define RL_CT1(K, COND) { const unsigned long long t1 = __builtin_readcyclecounter(); ctm[K] += t1 - ct0; cln[K] += __popcll(__ballot(COND)); ct0 = t1; }
 #else
@@ -178,7 +178,9 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? RL_CHAIN_WAVES : RL_CHAIN_WAV
 #undef RL_CHAIN_KERNARGS
 #ifdef RL_STAGE_TIMERS
     if ((threadIdx.x & 63u) == 0u) { for (int k = 0; k < 3; k++) { atomicAdd(&g_chain_timers[k], ctm[k]); atomicAdd(&g_chain_timers[3 + k], cln[k]); } atomicAdd(&g_chain_timers[6], n_it);
-        const unsigned w = tid >> 6; if (w < kChainWaveSlots) { g_chain_waves[3 * w] = wave_t0; g_chain_waves[3 * w + 1] = wall_clock64(); g_chain_waves[3 * w + 2] = n_it; } }
+        // (+ where the wave ran: HW_ID (SIMD, CU, shader array / engine) and XCC_ID — is a grid of a few hundred workgroups spread over the chip's 256 CUs?)
+        const unsigned w = tid >> 6; if (w < kChainWaveSlots) { g_chain_waves[4 * w] = wave_t0; g_chain_waves[4 * w + 1] = wall_clock64(); g_chain_waves[4 * w + 2] = n_it;
+            g_chain_waves[4 * w + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4); } }
 #endif
 }
 
@@ -193,18 +195,18 @@ static void dump_chain_timers_impl() {
     if (h[7]) std::fprintf(stderr, "[chain] treelet walk: %llu node steps, %llu block fetches (%.2f steps per fetch)\n", h[7] & 0xffffffffull, h[7] >> 32, (double)(h[7] & 0xffffffffull) / (double)(h[7] >> 32));
     std::memset(h, 0, sizeof(h)); hipMemcpyToSymbol(HIP_SYMBOL(g_chain_timers), h, sizeof(h));
     {   // wave lifetimes: when the waves started (generations), how long they lived, percentiles over the waves that did work
-        std::vector<unsigned long long> w(3 * (size_t)kChainWaveSlots);
+        std::vector<unsigned long long> w(4 * (size_t)kChainWaveSlots);
         hipMemcpyFromSymbol(w.data(), HIP_SYMBOL(g_chain_waves), w.size() * 8);
         unsigned long long t0 = ~0ull, t1 = 0; size_t n = 0;
-        for (size_t i = 0; i < kChainWaveSlots; i++) if (w[3 * i]) { t0 = std::min(t0, w[3 * i]); t1 = std::max(t1, w[3 * i + 1]); n++; }
+        for (size_t i = 0; i < kChainWaveSlots; i++) if (w[4 * i]) { t0 = std::min(t0, w[4 * i]); t1 = std::max(t1, w[4 * i + 1]); n++; }
         if (n) {
             std::vector<double> life, start; size_t heavy = 0;
-            for (size_t i = 0; i < kChainWaveSlots; i++) if (w[3 * i]) { const double l = (w[3 * i + 1] - w[3 * i]) * 1e-5; if (w[3 * i + 2] > 1000) { life.push_back(l); start.push_back((w[3 * i] - t0) * 1e-5); heavy++; } }
+            for (size_t i = 0; i < kChainWaveSlots; i++) if (w[4 * i]) { const double l = (w[4 * i + 1] - w[4 * i]) * 1e-5; if (w[4 * i + 2] > 1000) { life.push_back(l); start.push_back((w[4 * i] - t0) * 1e-5); heavy++; } }
             std::sort(life.begin(), life.end()); std::sort(start.begin(), start.end());
             auto pc = [](const std::vector<double>& v, double q) { return v.empty() ? 0.0 : v[std::min(v.size() - 1, (size_t)(q * v.size()))]; };
             std::fprintf(stderr, "[chain] %zu waves, %zu with > 1000 iterations; kernel span %.1f ms; heavy waves' lifetime ms: p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f; their start ms: p50 %.2f p90 %.2f p99 %.2f max %.2f\n",
                          n, heavy, (t1 - t0) * 1e-5, pc(life, 0.1), pc(life, 0.5), pc(life, 0.9), pc(life, 0.99), life.empty() ? 0.0 : life.back(), pc(start, 0.5), pc(start, 0.9), pc(start, 0.99), start.empty() ? 0.0 : start.back());
-            if (getenv("RL_CHAIN_WAVE_TIMES")) { FILE* f = std::fopen(getenv("RL_CHAIN_WAVE_TIMES"), "w"); if (f) { for (size_t i = 0; i < kChainWaveSlots; i++) if (w[3 * i]) std::fprintf(f, "%zu %.3f %.3f %llu\n", i, (w[3 * i] - t0) * 1e-5, (w[3 * i + 1] - t0) * 1e-5, w[3 * i + 2]); std::fclose(f); } }
+            if (getenv("RL_CHAIN_WAVE_TIMES")) { FILE* f = std::fopen(getenv("RL_CHAIN_WAVE_TIMES"), "w"); if (f) { for (size_t i = 0; i < kChainWaveSlots; i++) if (w[4 * i]) std::fprintf(f, "%zu %.3f %.3f %llu %llu %llu\n", i, (w[4 * i] - t0) * 1e-5, (w[4 * i + 1] - t0) * 1e-5, w[4 * i + 2], w[4 * i + 3] & 0xffffffffull, w[4 * i + 3] >> 32); std::fclose(f); } }
         }
         std::fill(w.begin(), w.end(), 0ull); hipMemcpyToSymbol(HIP_SYMBOL(g_chain_waves), w.data(), w.size() * 8);
     }

@@ -421,6 +421,7 @@ private:
             // (cbox 1080p x 128 spp, three workgroups per CU: 244 -> 198 ms; 8 / 16 / 32 lanes alike.  Scenes that stream their BVH: 2452 -> 2517 ms on the 508 k-triangle scene — a helper's sample is a
             // chain of dependent fetches like any other there — so off)
             spc.dense = !ctx->lds_scene ? 0u : (knobs.has(K_SPEC_DENSE) ? std::min(64u, (unsigned)knobs.i(K_SPEC_DENSE, 0)) : 16u);
+            spc.dense_frac = (float)knobs.f(K_SPEC_DENSE_FRAC, 0.6);
             spc.probe_every = (unsigned)knobs.i(K_SPEC_PROBE_EVERY, 0);
             // window margins in standard deviations of the predicted offsets: with one block per wave a pixel the chain has to be walked through stalls the whole wave, so wider
             // (shard 0 of 8, 1024 spp: 1.65 / 2.5 sigma = 714 / 688 ms; full frame, two blocks per wave: 281 / 292)
