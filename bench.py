@@ -21,7 +21,11 @@ configurations and stream modes timed the same way in the same process (configs[
 rustlight's own reference-order streams, configs[1] on a square frame), and `reference_order_value` at the top level.
 `value`, `reference_order_value` and every `ms_per_step` are ONE frame at a time (rl_render_path is synchronous, like Integrator::compute).  Next to
 them, never in their place: `reference_order_in_flight_value` and the `*_3_in_flight` records — the same frames with three of them on the GPU at once
-(three contexts of the scene, one host thread each; DESIGN.md 5 "Frames in flight") — and, for N > 1, `reference_order.three_frames_in_flight` per rank."""
+(three contexts of the scene, one host thread each; DESIGN.md 5 "Frames in flight") — and, for N > 1, `reference_order.three_frames_in_flight` per rank.
+The reference-order `also` records (configs[1], configs[4], the configs[2] stand-in in rustlight's own streams: the drop-in default) are THREE timed steps each, every step
+synchronised and timed on its own: `step_ms`, `value_min` (the worst single step) / `value_median` / `value_max`, and `reference_order_worst_step_value` at the top level = the
+weakest step of the default mode over all three.  In that mode k_path_fused runs BESIDE the chain pass: its `kernel_ms` / roofline entry use its own span
+(rl_render_stats.ms_eval_span), `eval_tail_after_chain_ms` is what of it was left after the chain pass had ended."""
 from __future__ import annotations
 
 import argparse
