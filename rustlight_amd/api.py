@@ -561,7 +561,7 @@ class IntegratorPathTracing:
     """struct IntegratorPathTracing (src/integrators/explicit/path.rs:14-20) + Integrator::compute."""
 
     def __init__(self, min_depth=0, max_depth=None, rr_depth=0, strategy=STRATEGY_ALL, single_scattering=False,
-                 stream_mode=STREAM_REFERENCE_ORDER, device=0, numerics=NUMERICS_EXACT, frames_in_flight=1):
+                 stream_mode=STREAM_REFERENCE_ORDER, device=0, numerics=NUMERICS_EXACT, frames_in_flight=1, options=None):
         """stream_mode: the plugin's default is rustlight's own per-block stream order (seed-for-seed the reference's image);
         STREAM_PER_SAMPLE is the opt-in throughput decomposition.  frames_in_flight (MI355X-specific, not in the reference): how many
         independent frames `compute_frames` — and the progressive wrappers through it — keep on the GPU at once (one device context and
@@ -570,14 +570,21 @@ class IntegratorPathTracing:
         self.strategy, self.single_scattering = strategy, single_scattering
         self.stream_mode, self.device, self.numerics = stream_mode, device, numerics
         self.frames_in_flight = max(1, int(frames_in_flight))
+        self.options = dict(options or {})          # execution options of every context this integrator creates (Context.set_option; none changes an image)
         self.last_stats = None
         self._ctx = None
         self._extra = []
 
+    def _new_context(self, scene: Scene) -> "Context":
+        c = Context(scene, self.device)
+        for k, v in self.options.items():
+            c.set_option(k, v)
+        return c
+
     def compute(self, sampler: IndependentSampler, scene: Scene, nb_samples: int = 1):
         """IntegratorType::compute (integrators/mod.rs:274-338): BVH build (untimed) then the render."""
         if self._ctx is None or self._ctx.scene is not scene:
-            self._ctx = Context(scene, self.device)
+            self._ctx = self._new_context(scene)
         w, h = scene.size
         seeds = sampler.block_seeds(w, h)
         p = path_params(nb_samples, self.min_depth, self.max_depth, self.rr_depth, self.strategy, self.single_scattering,
@@ -591,11 +598,11 @@ class IntegratorPathTracing:
         chain of dependent launches that leaves much of the chip idle at its tail (reference-order streams: the chain pass ends with its
         slowest wave); another context's frame fills it.  Returns the images in frame order."""
         if self._ctx is None or self._ctx.scene is not scene:
-            self._ctx = Context(scene, self.device)
+            self._ctx = self._new_context(scene)
             self._extra = []
         k = min(self.frames_in_flight, max(1, n_frames))
         while len(self._extra) < k - 1:
-            self._extra.append(Context(scene, self.device))
+            self._extra.append(self._new_context(scene))
         w, h = scene.size
         jobs = [(sampler.block_seeds(w, h),
                  path_params(nb_samples, self.min_depth, self.max_depth, self.rr_depth, self.strategy, self.single_scattering,

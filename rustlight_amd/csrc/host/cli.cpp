@@ -1,7 +1,7 @@
 // cli.cpp — `rustlight-amd`: the reference CLI's flags for the `path` subcommand (examples/cli.rs:
 // global flags 106-145, `path` 162-169, medium 355-399, sampler 876-896, run/save 898-923).
 //   rustlight-amd <scene.pbrt|scene.xml> -n SPP -o out.pfm [-r independent:SEED] [-m s[:a[:g]]] [-s SCALE] [-t N]
-//                 [--device D] [--gpus N] [--frames-in-flight K] [--stream-mode reference|per-sample] [--numerics exact|fast]
+//                 [--device D] [--gpus N] [--frames-in-flight K] [--stream-mode reference|per-sample] [--numerics exact|fast] [--option name=value ...]
 //                 path [-m MAX|inf] [-n MIN] [-r RR|inf] [-x] [-s all|bsdf|emitter]
 //               | ao [-d DIST|inf] [-n]            (examples/cli.rs:149-154)
 //               | direct [-b NB_BSDF] [-l NB_LIGHT] (examples/cli.rs:155-160)
@@ -41,6 +41,7 @@ int main(int argc, char** argv) {
     rl_stream_mode mode = RL_STREAM_REFERENCE_ORDER;   // like rustlight; `--stream-mode per-sample` trades the seed-for-seed image for throughput
     uint32_t numerics = RL_NUMERICS_EXACT;
     int frames_in_flight = 1;
+    std::vector<std::pair<std::string, std::string>> options;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() -> std::string { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -57,6 +58,11 @@ int main(int argc, char** argv) {
             else if (a == "--frames-in-flight") frames_in_flight = std::max(1, std::atoi(val().c_str()));   // -a / -e: that many independent passes on the GPU at once (same images, more of the chip busy)
             else if (a == "--stream-mode") mode = val() == "reference" ? RL_STREAM_REFERENCE_ORDER : RL_STREAM_PER_SAMPLE;
             else if (a == "--numerics") numerics = val() == "fast" ? RL_NUMERICS_FAST : RL_NUMERICS_EXACT;
+            else if (a == "--option") {   // an execution option of the device context(s): name=value (rl_context_set_option; none changes an image)
+                const std::string o = val();
+                const size_t eq = o.find('=');
+                options.emplace_back(o.substr(0, eq), eq == std::string::npos ? std::string("1") : o.substr(eq + 1));
+            }
             else if (a == "-a" || a == "--average") average = val();
             else if (a == "-e" || a == "--equal-time") equal_time = val();
             else if (a == "-x" || a == "--xtra-options") {   // ExtraOptions (cli.rs:41-50): ats | no-shading are honoured
@@ -137,6 +143,7 @@ int main(int argc, char** argv) {
         integrator.stream_mode = mode;
         integrator.numerics = numerics;
         integrator.frames_in_flight = frames_in_flight;
+        integrator.options = options;
         uint64_t seed;
         if (rng == "independent") seed = std::random_device{}();   // IndependentSampler::default(): OS entropy
         else if (rng.rfind("independent:", 0) == 0) seed = std::strtoull(rng.c_str() + 12, nullptr, 10);

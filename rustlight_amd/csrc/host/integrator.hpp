@@ -84,6 +84,14 @@ struct IntegratorPathTracing {
     // streams: the chain pass ends with its slowest wave); another context's frame fills it.  The images are those of one frame after the other.
     int frames_in_flight = 1;
 
+    // execution options handed to every device context this integrator creates (rl_context_set_option: test / measurement hooks, none changes an image;
+    // e.g. {"spec_draws_per_sample", "40"}); `rustlight-amd --option name=value`
+    std::vector<std::pair<std::string, std::string>> options;
+    void apply_options(rl_context* c) const {
+        for (const auto& o : options)
+            if (rl_context_set_option(c, o.first.c_str(), o.second.c_str()) != RL_OK) throw std::runtime_error(std::string("rl_context_set_option: ") + rl_last_error());
+    }
+
     // the device contexts (BVH + uploaded scene) are built once per scene, like `BVHAccel::new` in IntegratorType::compute
     rl_context* ctx = nullptr;
     std::vector<rl_context*> extra_ctx;      // frames in flight: contexts 2 .. frames_in_flight
@@ -128,12 +136,14 @@ struct IntegratorPathTracing {
         if (ctx_scene != &scene || ctx_gpus != 1 || !ctx) {
             release();
             if (rl_context_create(scene.handle, device, &ctx) != RL_OK) throw std::runtime_error(std::string("rl_context_create: ") + rl_last_error());
+            apply_options(ctx);
             ctx_scene = &scene; ctx_gpus = 1;
         }
         while (extra_ctx.size() + 1 < k) {
             rl_context* c = nullptr;
             if (rl_context_create(scene.handle, device, &c) != RL_OK) throw std::runtime_error(std::string("rl_context_create: ") + rl_last_error());
             extra_ctx.push_back(c);
+            apply_options(c);
         }
         const rl_path_params p = params_for(sampler, scene);
         out.resize(n_frames);
@@ -168,6 +178,7 @@ struct IntegratorPathTracing {
             if (n == 1) {
                 int rc = rl_context_create(scene.handle, device, &ctx);
                 if (rc != RL_OK) throw std::runtime_error(std::string("rl_context_create: ") + rl_last_error());
+                apply_options(ctx);
             } else {
                 int n_dev = 0;
                 rl_device_count(&n_dev);
