@@ -503,6 +503,12 @@ def test_cli_renders_what_the_api_renders(built, tmp_path):
     np.testing.assert_array_equal(run("ao", "-d", "0.5"), flat.render_ao(seeds(), spp=3, max_distance=0.5)[0])
     # the CLI's default stream mode is rustlight's own (one SmallRng per 16x16 block): a later --stream-mode wins, so this is the default path
     np.testing.assert_array_equal(run("--stream-mode", "reference", "path"), flat.render(seeds(), api.path_params(spp=3, stream_mode=api.STREAM_REFERENCE_ORDER))[0])
+    # --option name=value: an execution option of the device context (rl_context_set_option through the C++ integrator mirror) — another form of the same render; an unknown
+    # name is an error, not a silently ignored flag
+    np.testing.assert_array_equal(run("--stream-mode", "reference", "--option", "ref_single_pass=1", "--option", "no_events", "path"),
+                                  flat.render(seeds(), api.path_params(spp=3, stream_mode=api.STREAM_REFERENCE_ORDER))[0])
+    bad = subprocess.run([cli, xml, "-n", "1", "-o", str(tmp_path / "bad.pfm"), "--option", "no_such_option=1", "path"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "no_such_option" in (bad.stderr + bad.stdout)
     # --gpus N: N device contexts (round-robin over the visible devices — three on the one GPU here), one host thread each,
     # per-shard framebuffers added on the host: the single-context image again
     np.testing.assert_array_equal(run("--gpus", "3", "path", "-s", "emitter"), flat.render(seeds(), api.path_params(spp=3, strategy=api.STRATEGY_EMITTER))[0])
