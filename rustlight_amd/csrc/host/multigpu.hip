@@ -291,6 +291,9 @@ extern "C" int rl_multi_render_path(rl_multi* m, const rl_path_params* params, c
             stats->render_ms = std::max(stats->render_ms, st[g].render_ms);
             stats->ms_other = std::max(stats->ms_other, st[g].ms_other);
             stats->ms_prepass = std::max(stats->ms_prepass, st[g].ms_prepass);
+            stats->ms_eval_span = std::max(stats->ms_eval_span, st[g].ms_eval_span);
+            stats->chunks = std::max(stats->chunks, st[g].chunks);                 // (the shard that was cut into the most chunks; 1 = every shard overlapped)
+            stats->overlapped = std::min(stats->overlapped, st[g].overlapped);
         }
     }
     return RL_OK;
