@@ -139,3 +139,24 @@ def test_rust_repr_c_block_matches_the_header(c_layout):
     # the opaque handles are zero-sized on the Rust side
     for opaque in ("rl_scene", "rl_context", "rl_multi"):
         assert structs[opaque] == [] or structs[opaque][0][1].startswith("[u8; 0]"), opaque
+
+
+def test_option_table_is_consistent():
+    """kernels/knobs.h: the enum of execution options and the table of their names (rl_context_set_option looks a name up by its position) must have the same length and order
+    of magnitude of entries, every name must be lower-case `[a-z_]+`, unique, and the ones the header documents must exist."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "rustlight_amd", "csrc", "kernels", "knobs.h")).read()
+    body = src[src.index("enum KnobId {"):src.index("K_COUNT")]
+    body = re.sub(r"//[^\n]*", "", body)
+    ids = re.findall(r"\bK_[A-Z0-9_]+\b", body)
+    table = src[src.index("names[K_COUNT] = {"):src.index("};", src.index("names[K_COUNT] = {"))]
+    names = re.findall(r'"([^"]+)"', table)
+    assert len(ids) == len(names) == len(set(names)) == len(set(ids)), (len(ids), len(names))
+    assert all(re.fullmatch(r"[a-z][a-z0-9_]*", n) for n in names)
+    assert [i[2:].lower() for i in ids] == names          # K_SPEC_FORCE <-> "spec_force": same order, same spelling
+    header = open(os.path.join(root, "include", "rustlight_amd.h")).read()
+    doc = header[header.index("Execution options."):header.index("#ifndef RUSTLIGHT_AMD_H")]
+    documented = set(re.findall(r"\*\s+([a-z][a-z0-9_]*) = ", doc)) | set(re.findall(r", ([a-z][a-z0-9_]*) = 1", doc))
+    assert documented and documented <= set(names), documented - set(names)
